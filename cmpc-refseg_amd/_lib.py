@@ -1,0 +1,163 @@
+"""ctypes binding of libcmpc_hip.so (C ABI declared in include/cmpc.h).
+
+The library is the product's only compute path for the CMPC head: if it is missing the import
+fails loudly -- there is no CPU or PyTorch fallback.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libcmpc_hip.so")
+
+DT_F32, DT_BF16 = 0, 1
+ACT_NONE, ACT_RELU, ACT_TANH, ACT_SIGMOID = 0, 1, 2, 3
+
+
+class CmpcError(RuntimeError):
+    pass
+
+
+def build(force: bool = False) -> str:
+    """Compile every HIP source for gfx950 (hipcc cross-compiles without a GPU)."""
+    csrc = os.path.join(_HERE, "csrc")
+    if force:
+        subprocess.run(["make", "-C", csrc, "clean"], check=True, stdout=subprocess.DEVNULL)
+    subprocess.run(["make", "-C", csrc, "-j8"], check=True)
+    return LIB_PATH
+
+
+class GemmNtArgs(C.Structure):
+    _fields_ = [
+        ("dtype", C.c_int), ("nseg", C.c_int),
+        ("A", C.c_void_p * 3), ("Bt", C.c_void_p * 3),
+        ("K", C.c_int * 3), ("lda", C.c_int * 3), ("ldb", C.c_int * 3),
+        ("sA", C.c_int64 * 3), ("sB", C.c_int64 * 3),
+        ("C", C.c_void_p), ("ldc", C.c_int), ("sC", C.c_int64),
+        ("c_f32", C.c_int),
+        ("M", C.c_int), ("N", C.c_int), ("n_valid", C.c_int), ("batch", C.c_int),
+        ("bias", C.c_void_p),
+        ("sbias", C.c_void_p), ("ld_sbias", C.c_int),
+        ("pbias", C.c_void_p), ("ld_pbias", C.c_int),
+        ("rows_per_sample", C.c_int),
+        ("act", C.c_int), ("alpha", C.c_float), ("accumulate", C.c_int),
+    ]
+
+
+class GemmTnArgs(C.Structure):
+    _fields_ = [
+        ("dtype", C.c_int),
+        ("A", C.c_void_p), ("lda", C.c_int), ("Ka", C.c_int),
+        ("D", C.c_void_p), ("ldd", C.c_int), ("Nd", C.c_int),
+        ("out", C.c_void_p), ("ldo", C.c_int),
+        ("R", C.c_int), ("Kv", C.c_int), ("Nv", C.c_int),
+        ("nb", C.c_int), ("a_off", C.c_int64 * 8), ("d_off", C.c_int64 * 8), ("o_off", C.c_int64 * 8),
+        ("nb2", C.c_int), ("a_bs", C.c_int64), ("d_bs", C.c_int64), ("o_bs", C.c_int64),
+        ("rsplit", C.c_int), ("alpha", C.c_float),
+    ]
+
+
+class ConvLstmLn(C.Structure):
+    _fields_ = [("beta", C.c_void_p * 5), ("gamma", C.c_void_p * 5)]
+
+
+class ConvLstmDln(C.Structure):
+    _fields_ = [("dbeta", C.c_void_p * 5), ("dgamma", C.c_void_p * 5)]
+
+
+class PackDesc(C.Structure):
+    _fields_ = [
+        ("src_off", C.c_int64), ("ld_src", C.c_int),
+        ("dst_off", C.c_int64), ("dst_dt", C.c_int), ("transpose", C.c_int),
+        ("rows", C.c_int), ("cols", C.c_int), ("ld_dst", C.c_int),
+        ("nks", C.c_int), ("ks_src", C.c_int * 4), ("ks_len", C.c_int * 4), ("ks_dst", C.c_int * 4),
+        ("nns", C.c_int), ("ns_src", C.c_int * 5), ("ns_len", C.c_int * 5), ("ns_dst", C.c_int * 5),
+    ]
+
+
+class AdamSeg(C.Structure):
+    _fields_ = [("off", C.c_int64), ("count", C.c_int), ("wd", C.c_float), ("gmult", C.c_float)]
+
+
+_P, _I, _F, _L = C.c_void_p, C.c_int, C.c_float, C.c_int64
+
+# name -> argtypes (return type is always int).  Must list every symbol include/cmpc.h declares.
+SIGNATURES = {
+    "cmpc_gemm_nt": [C.POINTER(GemmNtArgs), _P],
+    "cmpc_gemm_tn": [C.POINTER(GemmTnArgs), _P],
+    "cmpc_cast": [_I, _P, _I, _P, _L, _P],
+    "cmpc_act_bwd": [_I, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _I, _I, _P],
+    "cmpc_wcolsum": [_I, _P, _P, _P, _I, _I, _I, _I, _I, _F, _P],
+    "cmpc_rowdot1": [_I, _P, _P, _I, _P, _I, _I, _I, _I, _F, _P],
+    "cmpc_rank1_update": [_I, _P, _P, _P, _P, _P, _I, _F, _F, _I, _I, _I, _I, _P],
+    "cmpc_axpy": [_I, _P, _P, _F, _L, _P],
+    "cmpc_l2norm_rows_fwd": [_I, _P, _P, _P, _P, _I, _I, _I, _P],
+    "cmpc_l2norm_rows_bwd": [_I, _P, _P, _P, _P, _I, _I, _I, _I, _P],
+    "cmpc_sample_stats": [_I, _P, _P, _I, _I, _I, _I, _P],
+    "cmpc_mutan_fwd": [_I, _P, _P, _P, _P, _I, _I, _I, _I, _P],
+    "cmpc_mutan_bwd": [_I, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
+    "cmpc_graph_softmax_fwd": [_I, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
+    "cmpc_graph_softmax_bwd": [_I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
+    "cmpc_gconv_pre_fwd": [_I, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
+    "cmpc_gconv_pre_bwd": [_I, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _I, _I, _I, _I, _P],
+    "cmpc_gconv_post_fwd": [_I, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
+    "cmpc_gconv_post_bwd": [_I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
+    "cmpc_softmax_n_fwd": [_P, _P, _I, _I, _P],
+    "cmpc_softmax_n_bwd": [_P, _P, _P, _I, _I, _P],
+    "cmpc_l2norm_all_fwd": [_P, _P, _P, _I, _P],
+    "cmpc_l2norm_all_bwd": [_P, _P, _P, _P, _I, _P],
+    "cmpc_exchange_combine_fwd": [_I, _P, _P, _P, _P, _P, _I, _P, _P, _I, _I, _I, _I, _P],
+    "cmpc_exchange_combine_bwd": [_I, _P, _P, _P, _P, _P, _P, _P, _I, _P, _I, _P, _P, _P, _P, _I, _I, _I, _I, _P],
+    "cmpc_convlstm_a": [_I, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
+    "cmpc_convlstm_b": [_I, _P, _P, _P, C.POINTER(ConvLstmLn), _P, _P, _I, _I, _I, _I, _P],
+    "cmpc_convlstm_c": [_I, _P, _P, C.POINTER(ConvLstmLn), _P, _P, _P, _I, _I, _I, _I, _P],
+    "cmpc_convlstm_bwd": [_I, _P, _P, _P, _P, _P, _P, _P, _P, C.POINTER(ConvLstmLn), _P, _P, _P,
+                          _P, _P, _P, C.POINTER(ConvLstmDln), _P, _P, _I, _I, _I, _I, _P],
+    "cmpc_score_conv_fwd": [_I, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
+    "cmpc_score_conv_bwd": [_I, _P, _P, _P, _P, _I, _P, _P, _I, _I, _I, _I, _I, _P],
+    "cmpc_upsample_fwd": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
+    "cmpc_upsample_loss_bwd": [_P, _P, _P, _F, _I, _I, _I, _I, _I, _P],
+    "cmpc_embed_gather": [_P, _P, _P, _I, _I, _I, _I, _P],
+    "cmpc_embed_scatter": [_P, _I, _P, _P, _I, _I, _I, _P],
+    "cmpc_lstm_cell_fwd": [_P, _P, _P, _P, _I, _P, _P, _P, _I, _I, _I, _I, _P],
+    "cmpc_lstm_cell_bwd": [_P, _P, _P, _P, _I, _P, _I, _P, _P, _P, _I, _I, _I, _P],
+    "cmpc_parse_softmax_fwd": [_P, _I, _P, _P, _I, _P],
+    "cmpc_parse_softmax_bwd": [_P, _P, _P, _P, _I, _I, _P],
+    "cmpc_lang_pool_fwd": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
+    "cmpc_lang_pool_bwd": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
+    "cmpc_pack_weights": [_P, _P, _P, _I, _I, _P],
+    "cmpc_adam_step": [_P, _P, _P, _P, _P, _I, _F, _F, _F, _F, _F, _P],
+}
+
+_lib = None
+
+
+def load():
+    """Load the shared library (once) and attach prototypes; raises if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise CmpcError(
+            f"{LIB_PATH} not found: the CMPC head has no fallback path. Build it with "
+            f"`python -c 'import __graft_entry__ as g; g.build()'` or `make -C cmpc-refseg_amd/csrc`.")
+    lib = C.CDLL(LIB_PATH)
+    lib.cmpc_last_error.restype = C.c_char_p
+    lib.cmpc_last_error.argtypes = []
+    lib.cmpc_abi_version.restype = C.c_int
+    lib.cmpc_abi_version.argtypes = []
+    for name, argtypes in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError if a declared symbol is not exported
+        fn.restype = C.c_int
+        fn.argtypes = argtypes
+    _lib = lib
+    return lib
+
+
+def call(name: str, *args):
+    lib = load()
+    rc = getattr(lib, name)(*args)
+    if rc != 0:
+        raise CmpcError(f"{name} failed ({rc}): {lib.cmpc_last_error().decode()}")

@@ -1,0 +1,136 @@
+// Shared device helpers for the CMPC gfx950 kernels (wave64, CDNA4).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define CMPC_OK 0
+#define CMPC_EINVAL (-1)
+#define CMPC_EHIP (-2)
+
+typedef __attribute__((ext_vector_type(4))) float f4;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf8v;
+typedef __attribute__((ext_vector_type(4))) short s4;
+typedef __attribute__((ext_vector_type(8))) short s8;
+
+typedef uint16_t bf16_t;   // storage type of a bf16 element
+
+enum { DT_F32 = 0, DT_BF16 = 1 };
+enum { ACT_NONE = 0, ACT_RELU = 1, ACT_TANH = 2, ACT_SIGMOID = 3 };
+
+void cmpc_set_error(const char* fmt, ...);
+int cmpc_check_launch(const char* what);
+
+__device__ __forceinline__ float bf2f(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
+__device__ __forceinline__ bf16_t f2bf(float f) {
+    __bf16 b = (__bf16)f;                       // v_cvt_pk_bf16_f32: RNE, NaN-preserving
+    return __builtin_bit_cast(bf16_t, b);
+}
+
+template <typename T> struct Elem;
+template <> struct Elem<float> {
+    static __device__ __forceinline__ float ld(const float* p) { return *p; }
+    static __device__ __forceinline__ void st(float* p, float v) { *p = v; }
+};
+template <> struct Elem<bf16_t> {
+    static __device__ __forceinline__ float ld(const bf16_t* p) { return bf2f(*p); }
+    static __device__ __forceinline__ void st(bf16_t* p, float v) { *p = f2bf(v); }
+};
+
+// 8 consecutive elements <-> float[8] (16-byte vector accesses; p must be 16-B aligned for
+// bf16 and 32-B aligned for f32).
+template <typename T> __device__ __forceinline__ void ld8(const T* p, float (&v)[8]);
+template <> __device__ __forceinline__ void ld8<float>(const float* p, float (&v)[8]) {
+    const float4 a = *reinterpret_cast<const float4*>(p);
+    const float4 b = *reinterpret_cast<const float4*>(p + 4);
+    v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+}
+template <> __device__ __forceinline__ void ld8<bf16_t>(const bf16_t* p, float (&v)[8]) {
+    const uint4 a = *reinterpret_cast<const uint4*>(p);
+    v[0] = __uint_as_float(a.x << 16); v[1] = __uint_as_float(a.x & 0xffff0000u);
+    v[2] = __uint_as_float(a.y << 16); v[3] = __uint_as_float(a.y & 0xffff0000u);
+    v[4] = __uint_as_float(a.z << 16); v[5] = __uint_as_float(a.z & 0xffff0000u);
+    v[6] = __uint_as_float(a.w << 16); v[7] = __uint_as_float(a.w & 0xffff0000u);
+}
+template <typename T> __device__ __forceinline__ void st8(T* p, const float (&v)[8]);
+template <> __device__ __forceinline__ void st8<float>(float* p, const float (&v)[8]) {
+    *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
+    *reinterpret_cast<float4*>(p + 4) = make_float4(v[4], v[5], v[6], v[7]);
+}
+template <> __device__ __forceinline__ void st8<bf16_t>(bf16_t* p, const float (&v)[8]) {
+    uint4 a;
+    a.x = (uint32_t)f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16);
+    a.y = (uint32_t)f2bf(v[2]) | ((uint32_t)f2bf(v[3]) << 16);
+    a.z = (uint32_t)f2bf(v[4]) | ((uint32_t)f2bf(v[5]) << 16);
+    a.w = (uint32_t)f2bf(v[6]) | ((uint32_t)f2bf(v[7]) << 16);
+    *reinterpret_cast<uint4*>(p) = a;
+}
+
+// wave64 reductions via cross-lane shuffles
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// block reductions for 256-thread blocks (4 waves); red must hold >= 4 floats per value
+__device__ __forceinline__ float block_sum_256(float v, float* red) {
+    v = wave_sum(v);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) red[w] = v;
+    __syncthreads();
+    return red[0] + red[1] + red[2] + red[3];
+}
+__device__ __forceinline__ float block_max_256(float v, float* red) {
+    v = wave_max(v);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) red[w] = v;
+    __syncthreads();
+    return fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+}
+
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + __expf(-x)); }
+__device__ __forceinline__ float act_apply(float v, int act) {
+    switch (act) {
+        case ACT_RELU: return fmaxf(v, 0.0f);
+        case ACT_TANH: return tanhf(v);
+        case ACT_SIGMOID: return 1.0f / (1.0f + expf(-v));
+        default: return v;
+    }
+}
+// derivative of the activation expressed through its OUTPUT y
+__device__ __forceinline__ float act_grad_from_out(float y, int act) {
+    switch (act) {
+        case ACT_RELU: return y > 0.0f ? 1.0f : 0.0f;
+        case ACT_TANH: return 1.0f - y * y;
+        case ACT_SIGMOID: return y * (1.0f - y);
+        default: return 1.0f;
+    }
+}
+
+// whole-sample LayerNorm statistics from double sums (tf.contrib.layers.layer_norm, eps 1e-12)
+__device__ __forceinline__ void ln_stats(const double* sums, double count, float& mean, float& rstd) {
+    const double m = sums[0] / count;
+    double var = sums[1] / count - m * m;
+    if (var < 0.0) var = 0.0;
+    mean = (float)m;
+    rstd = (float)(1.0 / sqrt(var + 1e-12));
+}
+
+#define CMPC_DISPATCH_DT(dt, ...)                                  \
+    do {                                                           \
+        if ((dt) == DT_F32) { typedef float T; __VA_ARGS__; }      \
+        else if ((dt) == DT_BF16) { typedef bf16_t T; __VA_ARGS__; } \
+        else { cmpc_set_error("bad dtype %d", (int)(dt)); return CMPC_EINVAL; } \
+    } while (0)

@@ -1,0 +1,399 @@
+// MFMA GEMMs for the CMPC head (gfx950 / CDNA4, wave64).
+//
+//  gemm_nt : C[M,N] = act(alpha * sum_s A_s[M,K_s] . Bt_s[N,K_s]^T + bias + sbias + pbias) (+C)
+//            every 1x1 convolution of the reference (_conv, CMPC_model.py:412-417) in forward,
+//            and the dX = dY . W^T products in backward.  Up to 3 K-segments share one
+//            accumulator (the reference's channel concats at CMPC_model.py:339,238 and
+//            util/cell.py:39 are never materialised).
+//  gemm_tn : out[K,N] += sum_r A[r,K]^T . D[r,N]   (weight gradients, fp32 atomics, split over r)
+//
+// Operands are T = bf16 (v_mfma_f32_16x16x32_bf16) or T = f32 (v_mfma_f32_16x16x4_f32, exact
+// fp32 - the parity mode).  Both use the same byte-level LDS image: a lane's 16-byte chunk is
+// one bf16 fragment (8 k-values) or four f32 k-values consumed by four MFMA steps.
+#include "cmpc_common.h"
+#include "../../include/cmpc.h"
+
+namespace {
+
+constexpr int BM = 128;       // rows of C per workgroup
+constexpr int BKB = 128;      // bytes of K per row per LDS stage (64 bf16 / 32 f32)
+
+// LDS image of a [rows][128 B] tile: 16-B chunk c of row r lives at slot c ^ ((r>>1)&7).
+// With 128-B rows two rows share a 256-B bank line, so 16 distinct rows reading the same
+// logical chunk touch 16 distinct 16-B slots: conflict-free for ds_read_b128.
+__device__ __forceinline__ int nt_lds_off(int row, int c) { return row * BKB + ((c ^ ((row >> 1) & 7)) << 4); }
+
+template <typename T> struct Mma;
+template <> struct Mma<bf16_t> {
+    static __device__ __forceinline__ f4 run(const uint4& a, const uint4& b, f4 acc) {
+        return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf8v, a), __builtin_bit_cast(bf8v, b), acc, 0, 0, 0);
+    }
+};
+template <> struct Mma<float> {
+    static __device__ __forceinline__ f4 run(const uint4& a, const uint4& b, f4 acc) {
+        // lane (r, q) holds k = 4*(chunk)+e, e = 0..3: MFMA step e pairs element e of both operands.
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.x), __uint_as_float(b.x), acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.y), __uint_as_float(b.y), acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.z), __uint_as_float(b.z), acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.w), __uint_as_float(b.w), acc, 0, 0, 0);
+        return acc;
+    }
+};
+
+// ------------------------------------------------------------------------------------------
+// gemm_nt
+// ------------------------------------------------------------------------------------------
+template <typename T, int BN>
+__global__ __launch_bounds__(256) void gemm_nt_kernel(const cmpc_gemm_nt_args p) {
+    constexpr int EPC = 16 / (int)sizeof(T);       // elements per 16-B chunk
+    constexpr int BK = BKB / (int)sizeof(T);       // elements of K per stage
+    constexpr int WAVES_N = (BN == 128) ? 2 : 1;
+    constexpr int WAVES_M = 4 / WAVES_N;
+    constexpr int TM = BM / WAVES_M / 16;          // 16x16 tiles per wave along M
+    constexpr int TN = BN / WAVES_N / 16;
+    constexpr int NA = BM * 8 / 256;               // A chunks per thread per stage
+    constexpr int NB = BN * 8 / 256;
+    constexpr int STAGE = (BM + BN) * BKB;
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wm = wid / WAVES_N, wn = wid % WAVES_N;
+    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    const long bz = blockIdx.z;
+
+    int ntile[3], ntot = 0;
+#pragma unroll
+    for (int s = 0; s < 3; ++s) { ntile[s] = (s < p.nseg) ? p.K[s] / BK : 0; ntot += ntile[s]; }
+
+    f4 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = f4{0.f, 0.f, 0.f, 0.f};
+
+    uint4 ra[NA], rb[NB];
+
+    auto gload = [&](int tile) {
+        int s = 0, t = tile;
+        if (t >= ntile[0]) { t -= ntile[0]; s = 1; if (t >= ntile[1]) { t -= ntile[1]; s = 2; } }
+        const T* Ap = reinterpret_cast<const T*>(p.A[s]) + bz * p.sA[s];
+        const T* Bp = reinterpret_cast<const T*>(p.Bt[s]) + bz * p.sB[s];
+        const long lda = p.lda[s], ldb = p.ldb[s];
+        const int k0 = t * BK;
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            const int id = tid + 256 * i, row = id >> 3, c = id & 7, gm = m0 + row;
+            ra[i] = (gm < p.M) ? *reinterpret_cast<const uint4*>(Ap + gm * lda + k0 + c * EPC) : uint4{0u, 0u, 0u, 0u};
+        }
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+            const int id = tid + 256 * i, row = id >> 3, c = id & 7, gn = n0 + row;
+            rb[i] = (gn < p.N) ? *reinterpret_cast<const uint4*>(Bp + gn * ldb + k0 + c * EPC) : uint4{0u, 0u, 0u, 0u};
+        }
+    };
+    auto lstore = [&](int buf) {
+        char* sA = smem + buf * STAGE;
+        char* sB = sA + BM * BKB;
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            const int id = tid + 256 * i;
+            *reinterpret_cast<uint4*>(sA + nt_lds_off(id >> 3, id & 7)) = ra[i];
+        }
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+            const int id = tid + 256 * i;
+            *reinterpret_cast<uint4*>(sB + nt_lds_off(id >> 3, id & 7)) = rb[i];
+        }
+    };
+
+    if (ntot > 0) { gload(0); lstore(0); }
+    __syncthreads();
+
+    const int fr = lane & 15, fq = lane >> 4;
+    for (int kt = 0; kt < ntot; ++kt) {
+        const int cur = kt & 1;
+        if (kt + 1 < ntot) gload(kt + 1);
+        const char* sA = smem + cur * STAGE;
+        const char* sB = sA + BM * BKB;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            uint4 a[TM], b[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+                a[i] = *reinterpret_cast<const uint4*>(sA + nt_lds_off(wm * TM * 16 + i * 16 + fr, 4 * s + fq));
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+                b[j] = *reinterpret_cast<const uint4*>(sB + nt_lds_off(wn * TN * 16 + j * 16 + fr, 4 * s + fq));
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) acc[i][j] = Mma<T>::run(a[i], b[j], acc[i][j]);
+        }
+        if (kt + 1 < ntot) lstore(cur ^ 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue: accumulators -> wave-private LDS slab -> row-contiguous vector stores ----
+    constexpr int WR = TM * 16, WC = TN * 16;      // wave sub-tile
+    float* slab = reinterpret_cast<float*>(smem) + wid * (WR * WC);
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = i * 16 + fq * 4 + r, col = j * 16 + fr;
+                slab[row * WC + (col ^ (((row >> 2) & 3) << 4))] = acc[i][j][r];
+            }
+    __builtin_amdgcn_s_waitcnt(0xC07F);            // lgkmcnt(0): own wave's LDS writes landed
+    __builtin_amdgcn_wave_barrier();
+
+    constexpr int LPR = WC / 4;                    // lanes per row (4 floats each)
+    constexpr int RPP = 64 / LPR;                  // rows per pass
+    T* Ct = reinterpret_cast<T*>(p.C) + bz * p.sC;
+    float* Cf = reinterpret_cast<float*>(p.C) + bz * p.sC;
+    const int rps = p.rows_per_sample > 0 ? p.rows_per_sample : 1;
+    for (int pass = 0; pass < WR / RPP; ++pass) {
+        const int row = pass * RPP + lane / LPR, c4 = (lane % LPR) * 4;
+        const int gm = m0 + wm * WR + row, gn = n0 + wn * WC + c4;
+        if (gm >= p.M || gn >= p.N) continue;
+        const int sc = c4 ^ (((row >> 2) & 3) << 4);
+        const float4 v4 = *reinterpret_cast<const float4*>(slab + row * WC + sc);
+        float v[4] = {v4.x, v4.y, v4.z, v4.w};
+        const long bm = bz * (long)p.M + gm;       // row index across the batch
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float x = v[e] * p.alpha;
+            if (gn + e < p.n_valid) {
+                if (p.bias) x += p.bias[gn + e];
+                if (p.sbias) x += p.sbias[(bm / rps) * (long)p.ld_sbias + gn + e];
+                if (p.pbias) x += p.pbias[(bm % rps) * (long)p.ld_pbias + gn + e];
+                x = act_apply(x, p.act);
+            } else {
+                x = 0.0f;                          // keep pad columns exactly zero
+            }
+            v[e] = x;
+        }
+        const long off = (long)gm * p.ldc + gn;
+        if (p.c_f32) {
+            if (p.accumulate) {
+                const float4 o = *reinterpret_cast<const float4*>(Cf + off);
+                v[0] += o.x; v[1] += o.y; v[2] += o.z; v[3] += o.w;
+            }
+            *reinterpret_cast<float4*>(Cf + off) = make_float4(v[0], v[1], v[2], v[3]);
+        } else {
+            if (p.accumulate) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] += Elem<T>::ld(Ct + off + e);
+            }
+            if constexpr (sizeof(T) == 4) {
+                *reinterpret_cast<float4*>(Ct + off) = make_float4(v[0], v[1], v[2], v[3]);
+            } else {
+                uint2 o;
+                o.x = (uint32_t)f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16);
+                o.y = (uint32_t)f2bf(v[2]) | ((uint32_t)f2bf(v[3]) << 16);
+                *reinterpret_cast<uint2*>(Ct + off) = o;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// gemm_tn: out[k,n] += alpha * sum_r A[r,k] * D[r,n]
+// LDS image [BR][128 elems] per operand, 32-B segments XOR-swizzled so that the transposing
+// reads (ds_read_b64_tr_b16 for bf16, ds_read_b32 for f32) of 8 rows x 32 B are conflict-free.
+// ------------------------------------------------------------------------------------------
+template <typename T> struct TnCfg;
+template <> struct TnCfg<bf16_t> { static constexpr int BR = 64; };
+template <> struct TnCfg<float> { static constexpr int BR = 32; };
+
+__device__ __forceinline__ int tn_swz(int r, int byte, int rowb) {
+    const int f = (r & 3) | (((r >> 3) & 1) << 2);
+    return r * rowb + ((((byte >> 5) ^ f) << 5) | (byte & 31));
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void gemm_tn_kernel(const cmpc_gemm_tn_args p) {
+    constexpr int BR = TnCfg<T>::BR;
+    constexpr int ROWB = 128 * (int)sizeof(T);     // bytes per LDS row
+    constexpr int EPC = 16 / (int)sizeof(T);
+    constexpr int CPR = ROWB / 16;                 // 16-B chunks per row
+    constexpr int NCH = BR * CPR / 256;            // chunks per thread per operand
+    constexpr int TILE = BR * ROWB;
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wm = wid >> 1, wn = wid & 1;
+    const int ntn = (p.Nv + 127) / 128;
+    const int k0 = (blockIdx.x / ntn) * 128, n0 = (blockIdx.x % ntn) * 128;
+    const int b1 = blockIdx.z % p.nb, b2 = blockIdx.z / p.nb;
+    const T* A = reinterpret_cast<const T*>(p.A) + p.a_off[b1] + (long)b2 * p.a_bs;
+    const T* D = reinterpret_cast<const T*>(p.D) + p.d_off[b1] + (long)b2 * p.d_bs;
+    float* out = p.out + p.o_off[b1] + (long)b2 * p.o_bs;
+
+    // rows of this split
+    const int per = (p.R + p.rsplit - 1) / p.rsplit;
+    const int rbeg = blockIdx.y * per;
+    const int rend = min(p.R, rbeg + per);
+    const int nt = (rend > rbeg) ? (rend - rbeg + BR - 1) / BR : 0;
+
+    f4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f4{0.f, 0.f, 0.f, 0.f};
+
+    uint4 ra[NCH], rd[NCH];
+    auto gload = [&](int t) {
+        const int r0 = rbeg + t * BR;
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            const int id = tid + 256 * i, row = id / CPR, c = id % CPR, gr = r0 + row;
+            const int ka = k0 + c * EPC, nd = n0 + c * EPC;
+            const bool rv = gr < rend;
+            ra[i] = (rv && ka < p.Ka) ? *reinterpret_cast<const uint4*>(A + (long)gr * p.lda + ka) : uint4{0u, 0u, 0u, 0u};
+            rd[i] = (rv && nd < p.Nd) ? *reinterpret_cast<const uint4*>(D + (long)gr * p.ldd + nd) : uint4{0u, 0u, 0u, 0u};
+        }
+    };
+    auto lstore = [&](int buf) {
+        char* sA = smem + buf * 2 * TILE;
+        char* sD = sA + TILE;
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            const int id = tid + 256 * i, row = id / CPR, c = id % CPR;
+            *reinterpret_cast<uint4*>(sA + tn_swz(row, c * 16, ROWB)) = ra[i];
+            *reinterpret_cast<uint4*>(sD + tn_swz(row, c * 16, ROWB)) = rd[i];
+        }
+    };
+
+    if (nt > 0) { gload(0); lstore(0); }
+    __syncthreads();
+    const int fr = lane & 15, fq = lane >> 4;
+    for (int t = 0; t < nt; ++t) {
+        const int cur = t & 1;
+        if (t + 1 < nt) gload(t + 1);
+        const char* sA = smem + cur * 2 * TILE;
+        const char* sD = sA + TILE;
+        if constexpr (sizeof(T) == 2) {
+            // lane li = lane&15 of 16-lane group q supplies the address of block row (li>>2),
+            // columns 4*(li&3)..+3, and receives column li of the block's 4 rows.
+            const int q4 = fr >> 2, p4 = fr & 3;
+#pragma unroll
+            for (int rs = 0; rs < BR / 32; ++rs) {
+                uint4 a[4], b[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int col = wm * 64 + i * 16 + 4 * p4;
+                    const int r_lo = rs * 32 + 8 * fq + q4;
+                    const s4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                        (__attribute__((address_space(3))) s4*)(sA + tn_swz(r_lo, col * 2, ROWB)));
+                    const s4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                        (__attribute__((address_space(3))) s4*)(sA + tn_swz(r_lo + 4, col * 2, ROWB)));
+                    const s8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                    a[i] = __builtin_bit_cast(uint4, v);
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int col = wn * 64 + j * 16 + 4 * p4;
+                    const int r_lo = rs * 32 + 8 * fq + q4;
+                    const s4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                        (__attribute__((address_space(3))) s4*)(sD + tn_swz(r_lo, col * 2, ROWB)));
+                    const s4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                        (__attribute__((address_space(3))) s4*)(sD + tn_swz(r_lo + 4, col * 2, ROWB)));
+                    const s8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                    b[j] = __builtin_bit_cast(uint4, v);
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                            __builtin_bit_cast(bf8v, a[i]), __builtin_bit_cast(bf8v, b[j]), acc[i][j], 0, 0, 0);
+            }
+        } else {
+#pragma unroll 2
+            for (int rs = 0; rs < BR / 4; ++rs) {
+                float a[4], b[4];
+                const int r = rs * 4 + fq;
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    a[i] = *reinterpret_cast<const float*>(sA + tn_swz(r, (wm * 64 + i * 16 + fr) * 4, ROWB));
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    b[j] = *reinterpret_cast<const float*>(sD + tn_swz(r, (wn * 64 + j * 16 + fr) * 4, ROWB));
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[j], acc[i][j], 0, 0, 0);
+            }
+        }
+        if (t + 1 < nt) lstore(cur ^ 1);
+        __syncthreads();
+    }
+    if (nt == 0) return;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int k = k0 + wm * 64 + i * 16 + fq * 4 + r;
+                const int n = n0 + wn * 64 + j * 16 + fr;
+                if (k < p.Kv && n < p.Nv) atomicAdd(out + (long)k * p.ldo + n, acc[i][j][r] * p.alpha);
+            }
+}
+
+}  // namespace
+
+extern "C" int cmpc_gemm_nt(const cmpc_gemm_nt_args* a, void* stream) {
+    if (!a || a->nseg < 1 || a->nseg > 3 || a->M <= 0 || a->N <= 0 || a->batch <= 0) {
+        cmpc_set_error("gemm_nt: bad args"); return CMPC_EINVAL;
+    }
+    const int esz = a->dtype == DT_F32 ? 4 : 2;
+    const int bk = BKB / esz;
+    for (int s = 0; s < a->nseg; ++s) {
+        if (a->K[s] <= 0 || a->K[s] % bk || (a->lda[s] * esz) % 16 || (a->ldb[s] * esz) % 16 || !a->A[s] || !a->Bt[s]) {
+            cmpc_set_error("gemm_nt: segment %d: K=%d must be a multiple of %d and rows 16-B aligned", s, a->K[s], bk);
+            return CMPC_EINVAL;
+        }
+    }
+    if (a->N % 4 || a->ldc % 4 || !a->C) { cmpc_set_error("gemm_nt: N/ldc must be multiples of 4"); return CMPC_EINVAL; }
+    const int bn = (a->N % 128 == 0 || a->N > 64) ? 128 : 64;
+    dim3 grid((a->N + bn - 1) / bn, (a->M + BM - 1) / BM, a->batch);
+    const size_t lds = 2 * (BM + bn) * BKB;
+    hipStream_t st = (hipStream_t)stream;
+    if (a->dtype == DT_F32) {
+        if (bn == 128) hipLaunchKernelGGL((gemm_nt_kernel<float, 128>), grid, dim3(256), lds, st, *a);
+        else hipLaunchKernelGGL((gemm_nt_kernel<float, 64>), grid, dim3(256), lds, st, *a);
+    } else if (a->dtype == DT_BF16) {
+        if (bn == 128) hipLaunchKernelGGL((gemm_nt_kernel<bf16_t, 128>), grid, dim3(256), lds, st, *a);
+        else hipLaunchKernelGGL((gemm_nt_kernel<bf16_t, 64>), grid, dim3(256), lds, st, *a);
+    } else { cmpc_set_error("gemm_nt: bad dtype"); return CMPC_EINVAL; }
+    return cmpc_check_launch("gemm_nt");
+}
+
+extern "C" int cmpc_gemm_tn(const cmpc_gemm_tn_args* a, void* stream) {
+    if (!a || a->R < 0 || a->Kv <= 0 || a->Nv <= 0 || a->nb < 1 || a->nb > 8 || a->nb2 < 1 || a->rsplit < 1 || !a->A || !a->D || !a->out) {
+        cmpc_set_error("gemm_tn: bad args"); return CMPC_EINVAL;
+    }
+    const int esz = a->dtype == DT_F32 ? 4 : 2;
+    if ((a->lda * esz) % 16 || (a->ldd * esz) % 16 || (a->Ka * esz) % 16 || (a->Nd * esz) % 16) {
+        cmpc_set_error("gemm_tn: rows must be 16-B aligned"); return CMPC_EINVAL;
+    }
+    for (int i = 0; i < a->nb; ++i)
+        if ((a->a_off[i] * esz) % 16 || (a->d_off[i] * esz) % 16) { cmpc_set_error("gemm_tn: offsets must be 16-B aligned"); return CMPC_EINVAL; }
+    if ((a->a_bs * esz) % 16 || (a->d_bs * esz) % 16) { cmpc_set_error("gemm_tn: batch strides must be 16-B aligned"); return CMPC_EINVAL; }
+    if (a->R == 0) return CMPC_OK;
+    dim3 grid(((a->Kv + 127) / 128) * ((a->Nv + 127) / 128), a->rsplit, a->nb * a->nb2);
+    hipStream_t st = (hipStream_t)stream;
+    if (a->dtype == DT_F32) {
+        const size_t lds = 2 * 2 * TnCfg<float>::BR * 128 * 4;
+        hipLaunchKernelGGL((gemm_tn_kernel<float>), grid, dim3(256), lds, st, *a);
+    } else if (a->dtype == DT_BF16) {
+        const size_t lds = 2 * 2 * TnCfg<bf16_t>::BR * 128 * 2;
+        hipLaunchKernelGGL((gemm_tn_kernel<bf16_t>), grid, dim3(256), lds, st, *a);
+    } else { cmpc_set_error("gemm_tn: bad dtype"); return CMPC_EINVAL; }
+    return cmpc_check_launch("gemm_tn");
+}

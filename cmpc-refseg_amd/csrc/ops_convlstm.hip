@@ -1,0 +1,393 @@
+// ConvLSTMCell.call (reference util/cell.py:36-79) around its 1x1-convolution GEMM, one step.
+// Gate pre-activations Yg [R, 4*ld] (blocks j,i,f,o), peepholes [N, M] fp32, five whole-sample
+// LayerNorms (j,i,f,o,c).  Wave per spatial row; fp32 math; float64 per-sample sums.
+#include "cmpc_common.h"
+#include "../../include/cmpc.h"
+
+namespace {
+
+constexpr int WPB = 4;
+constexpr int MB = 2;     // ld <= 1024
+__host__ inline int rows_grid(int N, int cap) { int g = (N + WPB - 1) / WPB; return g < 1 ? 1 : (g > cap ? cap : g); }
+
+struct Sum2 { double a, b; };
+
+__device__ __forceinline__ void flush_sums(double s1, double s2, double* dst, double (*red)[WPB], int slot) {
+    s1 = wave_sum_d(s1); s2 = wave_sum_d(s2);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    if (lane == 0) { red[2 * slot][w] = s1; red[2 * slot + 1][w] = s2; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        atomicAdd(dst, red[2 * slot][0] + red[2 * slot][1] + red[2 * slot][2] + red[2 * slot][3]);
+        atomicAdd(dst + 1, red[2 * slot + 1][0] + red[2 * slot + 1][1] + red[2 * slot + 1][2] + red[2 * slot + 1][3]);
+    }
+    __syncthreads();
+}
+
+__device__ __forceinline__ void colflush(const float (&acc)[MB][8], float* out, int ld, int C, float* lds) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < MB; ++k) {
+        const int c0 = k * 512 + lane * 8;
+        if (c0 < ld) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) lds[w * ld + c0 + e] = acc[k][e];
+        }
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += 256) {
+        const float s = lds[c] + lds[ld + c] + lds[2 * ld + c] + lds[3 * ld + c];
+        if (s != 0.f) atomicAdd(out + c, s);
+    }
+}
+
+// ---- forward A: peepholes on i,f (in place) + stats j,i,f -----------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void clstm_a_kernel(T* __restrict__ Yg, const T* __restrict__ c_prev, const float* __restrict__ W_ci,
+                                                     const float* __restrict__ W_cf, double* sums, int B, int N, int ld, int M) {
+    __shared__ double red[6][WPB];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, b = blockIdx.y;
+    double sj1 = 0, sj2 = 0, si1 = 0, si2 = 0, sf1 = 0, sf2 = 0;
+    for (int n = blockIdx.x * WPB + w; n < N; n += gridDim.x * WPB) {
+        const long r = (long)b * N + n;
+        T* y = Yg + r * 4 * ld;
+        float aj1 = 0, aj2 = 0, ai1 = 0, ai2 = 0, af1 = 0, af2 = 0;
+        for (int c0 = lane * 8; c0 < ld; c0 += 512) {
+            float j[8], i[8], f[8];
+            ld8<T>(y + c0, j); ld8<T>(y + ld + c0, i); ld8<T>(y + 2 * ld + c0, f);
+            if (c_prev) {
+                float c[8];
+                ld8<T>(c_prev + r * ld + c0, c);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const int m = c0 + e;
+                    if (m < M) { i[e] += W_ci[(long)n * M + m] * c[e]; f[e] += W_cf[(long)n * M + m] * c[e]; }
+                }
+                st8<T>(y + ld + c0, i); st8<T>(y + 2 * ld + c0, f);
+                // statistics must see the values as stored (bf16 rounding included)
+                ld8<T>(y + ld + c0, i); ld8<T>(y + 2 * ld + c0, f);
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                if (c0 + e < M) {
+                    aj1 += j[e]; aj2 += j[e] * j[e]; ai1 += i[e]; ai2 += i[e] * i[e]; af1 += f[e]; af2 += f[e] * f[e];
+                }
+            }
+        }
+        sj1 += aj1; sj2 += aj2; si1 += ai1; si2 += ai2; sf1 += af1; sf2 += af2;
+    }
+    flush_sums(sj1, sj2, sums + (0 * B + b) * 2, red, 0);
+    flush_sums(si1, si2, sums + (1 * B + b) * 2, red, 1);
+    flush_sums(sf1, sf2, sums + (2 * B + b) * 2, red, 2);
+}
+
+struct LnP { const float* beta[5]; const float* gamma[5]; };
+struct LnG { float* dbeta[5]; float* dgamma[5]; };
+
+// ---- forward B ---------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void clstm_b_kernel(T* __restrict__ Yg, const T* __restrict__ c_prev, const float* __restrict__ W_co,
+                                                     LnP ln, double* sums, T* __restrict__ c_pre, int B, int N, int ld, int M) {
+    __shared__ double red[4][WPB];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, b = blockIdx.y;
+    const double cnt = (double)N * M;
+    float mj, rj, mi, ri, mf, rf;
+    ln_stats(sums + (0 * B + b) * 2, cnt, mj, rj);
+    ln_stats(sums + (1 * B + b) * 2, cnt, mi, ri);
+    ln_stats(sums + (2 * B + b) * 2, cnt, mf, rf);
+    double so1 = 0, so2 = 0, sc1 = 0, sc2 = 0;
+    for (int n = blockIdx.x * WPB + w; n < N; n += gridDim.x * WPB) {
+        const long r = (long)b * N + n;
+        T* y = Yg + r * 4 * ld;
+        float ao1 = 0, ao2 = 0, ac1 = 0, ac2 = 0;
+        for (int c0 = lane * 8; c0 < ld; c0 += 512) {
+            float j[8], i[8], f[8], o[8], c[8], cp[8];
+            ld8<T>(y + c0, j); ld8<T>(y + ld + c0, i); ld8<T>(y + 2 * ld + c0, f); ld8<T>(y + 3 * ld + c0, o);
+            if (c_prev) ld8<T>(c_prev + r * ld + c0, c);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int m = c0 + e;
+                if (m < M) {
+                    const float jn = (j[e] - mj) * rj * ln.gamma[0][m] + ln.beta[0][m];
+                    const float in = (i[e] - mi) * ri * ln.gamma[1][m] + ln.beta[1][m];
+                    const float fn = (f[e] - mf) * rf * ln.gamma[2][m] + ln.beta[2][m];
+                    const float fg = sigmoidf_(fn + 1.0f), ig = sigmoidf_(in), jt = tanhf(jn);
+                    cp[e] = (c_prev ? c[e] * fg : 0.f) + ig * jt;
+                    o[e] += W_co[(long)n * M + m] * cp[e];
+                } else { cp[e] = 0.f; o[e] = 0.f; }
+            }
+            st8<T>(c_pre + r * ld + c0, cp); st8<T>(y + 3 * ld + c0, o);
+            ld8<T>(c_pre + r * ld + c0, cp); ld8<T>(y + 3 * ld + c0, o);
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+                if (c0 + e < M) { ao1 += o[e]; ao2 += o[e] * o[e]; ac1 += cp[e]; ac2 += cp[e] * cp[e]; }
+        }
+        so1 += ao1; so2 += ao2; sc1 += ac1; sc2 += ac2;
+    }
+    flush_sums(so1, so2, sums + (3 * B + b) * 2, red, 0);
+    flush_sums(sc1, sc2, sums + (4 * B + b) * 2, red, 1);
+}
+
+// ---- forward C ---------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void clstm_c_kernel(const T* __restrict__ Yg, const T* __restrict__ c_pre, LnP ln, const double* sums,
+                                                     T* __restrict__ c_new, T* __restrict__ h, int B, int N, int ld, int M) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, b = blockIdx.y;
+    const double cnt = (double)N * M;
+    float mo, ro, mc, rc;
+    ln_stats(sums + (3 * B + b) * 2, cnt, mo, ro);
+    ln_stats(sums + (4 * B + b) * 2, cnt, mc, rc);
+    for (int n = blockIdx.x * WPB + w; n < N; n += gridDim.x * WPB) {
+        const long r = (long)b * N + n;
+        for (int c0 = lane * 8; c0 < ld; c0 += 512) {
+            float o[8], cp[8], cn[8], hh[8];
+            ld8<T>(Yg + r * 4 * ld + 3 * ld + c0, o); ld8<T>(c_pre + r * ld + c0, cp);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int m = c0 + e;
+                if (m < M) {
+                    const float on = (o[e] - mo) * ro * ln.gamma[3][m] + ln.beta[3][m];
+                    cn[e] = (cp[e] - mc) * rc * ln.gamma[4][m] + ln.beta[4][m];
+                    hh[e] = sigmoidf_(on) * tanhf(cn[e]);
+                } else { cn[e] = 0.f; hh[e] = 0.f; }
+            }
+            st8<T>(c_new + r * ld + c0, cn); st8<T>(h + r * ld + c0, hh);
+        }
+    }
+}
+
+// ---- backward pass 1: through h = sig(LN o) * tanh(LN c) up to the LN inputs' dxhat ------------
+template <typename T>
+__global__ __launch_bounds__(256) void clstm_bwd1_kernel(const T* __restrict__ dh, const T* __restrict__ dc_new, const T* __restrict__ Yg,
+                                                        const T* __restrict__ c_pre, LnP ln, const double* sums, T* __restrict__ dYg,
+                                                        T* __restrict__ scr, LnG dl, double* bsums, int B, int N, int ld, int M) {
+    extern __shared__ float lds[];
+    __shared__ double red[4][WPB];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, b = blockIdx.y;
+    const double cnt = (double)N * M;
+    float mo, ro, mc, rc;
+    ln_stats(sums + (3 * B + b) * 2, cnt, mo, ro);
+    ln_stats(sums + (4 * B + b) * 2, cnt, mc, rc);
+    float ago[MB][8], abo[MB][8], agc[MB][8], abc[MB][8];
+#pragma unroll
+    for (int k = 0; k < MB; ++k)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { ago[k][e] = abo[k][e] = agc[k][e] = abc[k][e] = 0.f; }
+    double so1 = 0, so2 = 0, sc1 = 0, sc2 = 0;
+    for (int n = blockIdx.x * WPB + w; n < N; n += gridDim.x * WPB) {
+        const long r = (long)b * N + n;
+        float ao1 = 0, ao2 = 0, ac1 = 0, ac2 = 0;
+#pragma unroll
+        for (int k = 0; k < MB; ++k) {
+            const int c0 = k * 512 + lane * 8;
+            if (c0 < ld) {
+                float g[8], dcn[8], o[8], cp[8], xo[8], xc[8];
+                ld8<T>(dh + r * ld + c0, g); ld8<T>(Yg + r * 4 * ld + 3 * ld + c0, o); ld8<T>(c_pre + r * ld + c0, cp);
+                if (dc_new) ld8<T>(dc_new + r * ld + c0, dcn);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const int m = c0 + e;
+                    if (m < M) {
+                        const float xho = (o[e] - mo) * ro, xhc = (cp[e] - mc) * rc;
+                        const float on = xho * ln.gamma[3][m] + ln.beta[3][m];
+                        const float cn = xhc * ln.gamma[4][m] + ln.beta[4][m];
+                        const float so = sigmoidf_(on), tc = tanhf(cn);
+                        const float don = g[e] * tc * so * (1.f - so);
+                        const float dcc = g[e] * so * (1.f - tc * tc) + (dc_new ? dcn[e] : 0.f);
+                        ago[k][e] += don * xho; abo[k][e] += don; agc[k][e] += dcc * xhc; abc[k][e] += dcc;
+                        xo[e] = don * ln.gamma[3][m]; xc[e] = dcc * ln.gamma[4][m];
+                        ao1 += xo[e]; ao2 += xo[e] * xho; ac1 += xc[e]; ac2 += xc[e] * xhc;
+                    } else { xo[e] = 0.f; xc[e] = 0.f; }
+                }
+                st8<T>(dYg + r * 4 * ld + 3 * ld + c0, xo); st8<T>(scr + r * ld + c0, xc);
+            }
+        }
+        so1 += ao1; so2 += ao2; sc1 += ac1; sc2 += ac2;
+    }
+    flush_sums(so1, so2, bsums + (3 * B + b) * 2, red, 0);
+    flush_sums(sc1, sc2, bsums + (4 * B + b) * 2, red, 1);
+    colflush(ago, dl.dgamma[3], ld, M, lds); colflush(abo, dl.dbeta[3], ld, M, lds);
+    colflush(agc, dl.dgamma[4], ld, M, lds); colflush(abc, dl.dbeta[4], ld, M, lds);
+}
+
+// ---- backward pass 2: finish LN(o), LN(c); through the cell update to dxhat of j,i,f -----------
+template <typename T>
+__global__ __launch_bounds__(256) void clstm_bwd2_kernel(const T* __restrict__ Yg, const T* __restrict__ c_prev, const T* __restrict__ c_pre,
+                                                        const float* __restrict__ W_co, LnP ln, const double* sums, const double* bsums_in,
+                                                        T* __restrict__ dYg, const T* __restrict__ scr, T* __restrict__ dc_prev,
+                                                        float* dW_co, LnG dl, double* bsums, int B, int N, int ld, int M) {
+    extern __shared__ float lds[];
+    __shared__ double red[6][WPB];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, b = blockIdx.y;
+    const double cnt = (double)N * M;
+    float mj, rj, mi, ri, mf, rf, mo, ro, mc, rc;
+    ln_stats(sums + (0 * B + b) * 2, cnt, mj, rj);
+    ln_stats(sums + (1 * B + b) * 2, cnt, mi, ri);
+    ln_stats(sums + (2 * B + b) * 2, cnt, mf, rf);
+    ln_stats(sums + (3 * B + b) * 2, cnt, mo, ro);
+    ln_stats(sums + (4 * B + b) * 2, cnt, mc, rc);
+    const float o_m1 = (float)(bsums_in[(3 * B + b) * 2] / cnt), o_m2 = (float)(bsums_in[(3 * B + b) * 2 + 1] / cnt);
+    const float c_m1 = (float)(bsums_in[(4 * B + b) * 2] / cnt), c_m2 = (float)(bsums_in[(4 * B + b) * 2 + 1] / cnt);
+    float ag[3][MB][8], ab[3][MB][8];
+#pragma unroll
+    for (int q = 0; q < 3; ++q)
+#pragma unroll
+        for (int k = 0; k < MB; ++k)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { ag[q][k][e] = 0.f; ab[q][k][e] = 0.f; }
+    double s[6] = {0, 0, 0, 0, 0, 0};
+    for (int n = blockIdx.x * WPB + w; n < N; n += gridDim.x * WPB) {
+        const long r = (long)b * N + n;
+        float a[6] = {0, 0, 0, 0, 0, 0};
+#pragma unroll
+        for (int k = 0; k < MB; ++k) {
+            const int c0 = k * 512 + lane * 8;
+            if (c0 < ld) {
+                float j[8], i[8], f[8], o[8], cp[8], c[8], dxo[8], dxc[8], oj[8], oi[8], of[8], dcp[8];
+                const T* y = Yg + r * 4 * ld;
+                ld8<T>(y + c0, j); ld8<T>(y + ld + c0, i); ld8<T>(y + 2 * ld + c0, f); ld8<T>(y + 3 * ld + c0, o);
+                ld8<T>(c_pre + r * ld + c0, cp);
+                if (c_prev) ld8<T>(c_prev + r * ld + c0, c);
+                ld8<T>(dYg + r * 4 * ld + 3 * ld + c0, dxo); ld8<T>(scr + r * ld + c0, dxc);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const int m = c0 + e;
+                    if (m < M) {
+                        const float xho = (o[e] - mo) * ro, xhc = (cp[e] - mc) * rc;
+                        const float dop = ro * (dxo[e] - o_m1 - xho * o_m2);
+                        float dc = rc * (dxc[e] - c_m1 - xhc * c_m2);
+                        const float wco = W_co[(long)n * M + m];
+                        dc += dop * wco;
+                        atomicAdd(dW_co + (long)n * M + m, dop * cp[e]);
+                        dxo[e] = dop;
+                        const float xhj = (j[e] - mj) * rj, xhi = (i[e] - mi) * ri, xhf = (f[e] - mf) * rf;
+                        const float jn = xhj * ln.gamma[0][m] + ln.beta[0][m];
+                        const float in = xhi * ln.gamma[1][m] + ln.beta[1][m];
+                        const float fn = xhf * ln.gamma[2][m] + ln.beta[2][m];
+                        const float fg = sigmoidf_(fn + 1.0f), ig = sigmoidf_(in), jt = tanhf(jn);
+                        const float cpv = c_prev ? c[e] : 0.f;
+                        const float dfn = dc * cpv * fg * (1.f - fg);
+                        const float din = dc * jt * ig * (1.f - ig);
+                        const float djn = dc * ig * (1.f - jt * jt);
+                        dcp[e] = dc * fg;
+                        ag[0][k][e] += djn * xhj; ab[0][k][e] += djn;
+                        ag[1][k][e] += din * xhi; ab[1][k][e] += din;
+                        ag[2][k][e] += dfn * xhf; ab[2][k][e] += dfn;
+                        oj[e] = djn * ln.gamma[0][m]; oi[e] = din * ln.gamma[1][m]; of[e] = dfn * ln.gamma[2][m];
+                        a[0] += oj[e]; a[1] += oj[e] * xhj; a[2] += oi[e]; a[3] += oi[e] * xhi; a[4] += of[e]; a[5] += of[e] * xhf;
+                    } else { dxo[e] = 0.f; oj[e] = oi[e] = of[e] = 0.f; dcp[e] = 0.f; }
+                }
+                T* dy = dYg + r * 4 * ld;
+                st8<T>(dy + c0, oj); st8<T>(dy + ld + c0, oi); st8<T>(dy + 2 * ld + c0, of); st8<T>(dy + 3 * ld + c0, dxo);
+                if (c_prev) st8<T>(dc_prev + r * ld + c0, dcp);
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < 6; ++q) s[q] += a[q];
+    }
+    flush_sums(s[0], s[1], bsums + (0 * B + b) * 2, red, 0);
+    flush_sums(s[2], s[3], bsums + (1 * B + b) * 2, red, 1);
+    flush_sums(s[4], s[5], bsums + (2 * B + b) * 2, red, 2);
+#pragma unroll
+    for (int q = 0; q < 3; ++q) { colflush(ag[q], dl.dgamma[q], ld, M, lds); colflush(ab[q], dl.dbeta[q], ld, M, lds); }
+}
+
+// ---- backward pass 3: finish LN(j), LN(i), LN(f); peepholes on i,f ----------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void clstm_bwd3_kernel(const T* __restrict__ Yg, const T* __restrict__ c_prev, const float* __restrict__ W_ci,
+                                                        const float* __restrict__ W_cf, const double* sums, const double* bsums,
+                                                        T* __restrict__ dYg, T* __restrict__ dc_prev, float* dW_ci, float* dW_cf,
+                                                        int B, int N, int ld, int M) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, b = blockIdx.y;
+    const double cnt = (double)N * M;
+    float mean[3], rstd[3], m1[3], m2[3];
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+        ln_stats(sums + (q * B + b) * 2, cnt, mean[q], rstd[q]);
+        m1[q] = (float)(bsums[(q * B + b) * 2] / cnt); m2[q] = (float)(bsums[(q * B + b) * 2 + 1] / cnt);
+    }
+    for (int n = blockIdx.x * WPB + w; n < N; n += gridDim.x * WPB) {
+        const long r = (long)b * N + n;
+        for (int c0 = lane * 8; c0 < ld; c0 += 512) {
+            float x[3][8], d[3][8], c[8], dcp[8];
+#pragma unroll
+            for (int q = 0; q < 3; ++q) { ld8<T>(Yg + r * 4 * ld + q * ld + c0, x[q]); ld8<T>(dYg + r * 4 * ld + q * ld + c0, d[q]); }
+            if (c_prev) { ld8<T>(c_prev + r * ld + c0, c); ld8<T>(dc_prev + r * ld + c0, dcp); }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int m = c0 + e;
+#pragma unroll
+                for (int q = 0; q < 3; ++q) {
+                    const float xh = (x[q][e] - mean[q]) * rstd[q];
+                    d[q][e] = (m < M) ? rstd[q] * (d[q][e] - m1[q] - xh * m2[q]) : 0.f;
+                }
+                if (c_prev && m < M) {
+                    atomicAdd(dW_ci + (long)n * M + m, d[1][e] * c[e]);
+                    atomicAdd(dW_cf + (long)n * M + m, d[2][e] * c[e]);
+                    dcp[e] += d[1][e] * W_ci[(long)n * M + m] + d[2][e] * W_cf[(long)n * M + m];
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < 3; ++q) st8<T>(dYg + r * 4 * ld + q * ld + c0, d[q]);
+            if (c_prev) st8<T>(dc_prev + r * ld + c0, dcp);
+        }
+    }
+}
+
+bool ok(const char* what, int dt, int ld, int M) {
+    if (ld <= 0 || M <= 0 || M > ld || ld % 8 || ld > MB * 512) { cmpc_set_error("%s: need 0 < M <= ld <= %d, ld %% 8 == 0", what, MB * 512); return false; }
+    if (dt != DT_F32 && dt != DT_BF16) { cmpc_set_error("%s: bad dtype", what); return false; }
+    return true;
+}
+LnP to_lnp(const cmpc_convlstm_ln* l) { LnP p; for (int i = 0; i < 5; ++i) { p.beta[i] = l->beta[i]; p.gamma[i] = l->gamma[i]; } return p; }
+LnG to_lng(const cmpc_convlstm_dln* l) { LnG p; for (int i = 0; i < 5; ++i) { p.dbeta[i] = l->dbeta[i]; p.dgamma[i] = l->dgamma[i]; } return p; }
+
+}  // namespace
+
+#define ST ((hipStream_t)stream)
+
+extern "C" int cmpc_convlstm_a(int dt, void* Yg, const void* c_prev, const float* W_ci, const float* W_cf, double* sums,
+                               int B, int N, int ld, int M, void* stream) {
+    if (!ok("convlstm_a", dt, ld, M)) return CMPC_EINVAL;
+    if (hipMemsetAsync(sums, 0, sizeof(double) * 5 * B * 2, ST) != hipSuccess) { cmpc_set_error("convlstm_a: memset"); return CMPC_EHIP; }
+    CMPC_DISPATCH_DT(dt, hipLaunchKernelGGL((clstm_a_kernel<T>), dim3(rows_grid(N, 64), B), dim3(256), 0, ST,
+                                             (T*)Yg, (const T*)c_prev, W_ci, W_cf, sums, B, N, ld, M));
+    return cmpc_check_launch("convlstm_a");
+}
+
+extern "C" int cmpc_convlstm_b(int dt, void* Yg, const void* c_prev, const float* W_co, const cmpc_convlstm_ln* ln,
+                               double* sums, void* c_pre, int B, int N, int ld, int M, void* stream) {
+    if (!ok("convlstm_b", dt, ld, M)) return CMPC_EINVAL;
+    CMPC_DISPATCH_DT(dt, hipLaunchKernelGGL((clstm_b_kernel<T>), dim3(rows_grid(N, 64), B), dim3(256), 0, ST,
+                                             (T*)Yg, (const T*)c_prev, W_co, to_lnp(ln), sums, (T*)c_pre, B, N, ld, M));
+    return cmpc_check_launch("convlstm_b");
+}
+
+extern "C" int cmpc_convlstm_c(int dt, const void* Yg, const void* c_pre, const cmpc_convlstm_ln* ln, const double* sums,
+                               void* c_new, void* h, int B, int N, int ld, int M, void* stream) {
+    if (!ok("convlstm_c", dt, ld, M)) return CMPC_EINVAL;
+    CMPC_DISPATCH_DT(dt, hipLaunchKernelGGL((clstm_c_kernel<T>), dim3(rows_grid(N, 64), B), dim3(256), 0, ST,
+                                             (const T*)Yg, (const T*)c_pre, to_lnp(ln), sums, (T*)c_new, (T*)h, B, N, ld, M));
+    return cmpc_check_launch("convlstm_c");
+}
+
+extern "C" int cmpc_convlstm_bwd(int dt, const void* dh, const void* dc_new, const void* Yg, const void* c_prev, const void* c_pre,
+                                 const float* W_ci, const float* W_cf, const float* W_co,
+                                 const cmpc_convlstm_ln* ln, const double* sums, void* dYg, void* dc_prev,
+                                 float* dW_ci, float* dW_cf, float* dW_co, const cmpc_convlstm_dln* dln, void* scr, double* bsums,
+                                 int B, int N, int ld, int M, void* stream) {
+    if (!ok("convlstm_bwd", dt, ld, M)) return CMPC_EINVAL;
+    if (hipMemsetAsync(bsums, 0, sizeof(double) * 5 * B * 2, ST) != hipSuccess) { cmpc_set_error("convlstm_bwd: memset"); return CMPC_EHIP; }
+    const size_t lds = WPB * ld * sizeof(float);
+    CMPC_DISPATCH_DT(dt, {
+        hipLaunchKernelGGL((clstm_bwd1_kernel<T>), dim3(rows_grid(N, 32), B), dim3(256), lds, ST,
+                           (const T*)dh, (const T*)dc_new, (const T*)Yg, (const T*)c_pre, to_lnp(ln), sums, (T*)dYg, (T*)scr, to_lng(dln), bsums, B, N, ld, M);
+        hipLaunchKernelGGL((clstm_bwd2_kernel<T>), dim3(rows_grid(N, 32), B), dim3(256), lds, ST,
+                           (const T*)Yg, (const T*)c_prev, (const T*)c_pre, W_co, to_lnp(ln), sums, bsums, (T*)dYg, (const T*)scr, (T*)dc_prev,
+                           dW_co, to_lng(dln), bsums, B, N, ld, M);
+        hipLaunchKernelGGL((clstm_bwd3_kernel<T>), dim3(rows_grid(N, 64), B), dim3(256), 0, ST,
+                           (const T*)Yg, (const T*)c_prev, W_ci, W_cf, sums, bsums, (T*)dYg, (T*)dc_prev, dW_ci, dW_cf, B, N, ld, M);
+    });
+    return cmpc_check_launch("convlstm_bwd");
+}

@@ -1,0 +1,482 @@
+// Mutan fusion, cross-modal graph softmaxes and gated-exchange elementwise kernels.
+#include "cmpc_common.h"
+#include "../../include/cmpc.h"
+
+namespace {
+
+constexpr int WPB = 4;
+constexpr int MB = 2;          // column blocks of 512: ld <= 1024 for the per-head register tiles
+__host__ inline int rows_grid(int N, int cap) { int g = (N + WPB - 1) / WPB; return g < 1 ? 1 : (g > cap ? cap : g); }
+
+// ------------------------------------------------------------------------------------------
+// mutan_fusion (CMPC_model.py:295-328)
+// ------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void mutan_fwd_kernel(T* __restrict__ P, const float* __restrict__ g, T* __restrict__ X1,
+                                                       float* __restrict__ rstd, int N, int ld, int C) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, b = blockIdx.y;
+    const float* gb = g + (long)b * 5 * ld;
+    for (int n = blockIdx.x * WPB + w; n < N; n += gridDim.x * WPB) {
+        const long r = (long)b * N + n;
+        T* Pr = P + r * 5 * ld;
+        float q[MB][8];
+#pragma unroll
+        for (int k = 0; k < MB; ++k)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) q[k][e] = 0.f;
+#pragma unroll
+        for (int h = 0; h < 5; ++h) {
+#pragma unroll
+            for (int k = 0; k < MB; ++k) {
+                const int c0 = k * 512 + lane * 8;
+                if (c0 < ld) {
+                    float pv[8];
+                    ld8<T>(Pr + h * ld + c0, pv);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const float th = (c0 + e < C) ? tanhf(pv[e]) : 0.f;
+                        pv[e] = th;
+                        q[k][e] += th * gb[h * ld + c0 + e];
+                    }
+                    st8<T>(Pr + h * ld + c0, pv);
+                }
+            }
+        }
+        float ss = 0.f;
+#pragma unroll
+        for (int k = 0; k < MB; ++k)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int c = k * 512 + lane * 8 + e;
+                q[k][e] = (c < C) ? tanhf(q[k][e]) : 0.f;
+                ss += q[k][e] * q[k][e];
+            }
+        ss = wave_sum(ss);
+        const bool clamped = ss < 1e-12f;
+        const float rs = rsqrtf(fmaxf(ss, 1e-12f));
+#pragma unroll
+        for (int k = 0; k < MB; ++k) {
+            const int c0 = k * 512 + lane * 8;
+            if (c0 < ld) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) q[k][e] *= rs;
+                st8<T>(X1 + r * ld + c0, q[k]);
+            }
+        }
+        if (lane == 0) rstd[r] = clamped ? -rs : rs;
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void mutan_bwd_kernel(T* __restrict__ Th, const float* __restrict__ g, const T* __restrict__ X1,
+                                                       const float* __restrict__ rstd, const T* __restrict__ dX1, float* dg,
+                                                       int N, int ld, int C) {
+    extern __shared__ float lds[];     // [WPB][ld]
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, b = blockIdx.y;
+    const float* gb = g + (long)b * 5 * ld;
+    float acc[5][MB][8];
+#pragma unroll
+    for (int h = 0; h < 5; ++h)
+#pragma unroll
+        for (int k = 0; k < MB; ++k)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc[h][k][e] = 0.f;
+    for (int n = blockIdx.x * WPB + w; n < N; n += gridDim.x * WPB) {
+        const long r = (long)b * N + n;
+        float d[MB][8], xv[MB][8];
+        float dot = 0.f;
+#pragma unroll
+        for (int k = 0; k < MB; ++k) {
+            const int c0 = k * 512 + lane * 8;
+            if (c0 < ld) {
+                ld8<T>(dX1 + r * ld + c0, d[k]); ld8<T>(X1 + r * ld + c0, xv[k]);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { if (c0 + e >= C) d[k][e] = 0.f; dot += d[k][e] * xv[k][e]; }
+            } else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { d[k][e] = 0.f; xv[k][e] = 0.f; }
+            }
+        }
+        dot = wave_sum(dot);
+        const float rs = rstd[r];
+        const float a = fabsf(rs);
+        if (rs < 0.f) dot = 0.f;
+        // dq = l2norm-bwd * (1 - tq^2), tq = X1 / |rs|
+#pragma unroll
+        for (int k = 0; k < MB; ++k)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float tq = xv[k][e] / a;
+                d[k][e] = a * (d[k][e] - xv[k][e] * dot) * (1.f - tq * tq);
+            }
+        T* Tr = Th + r * 5 * ld;
+#pragma unroll
+        for (int h = 0; h < 5; ++h) {
+#pragma unroll
+            for (int k = 0; k < MB; ++k) {
+                const int c0 = k * 512 + lane * 8;
+                if (c0 < ld) {
+                    float tv[8];
+                    ld8<T>(Tr + h * ld + c0, tv);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const float th = tv[e];
+                        acc[h][k][e] += d[k][e] * th;
+                        tv[e] = (c0 + e < C) ? d[k][e] * gb[h * ld + c0 + e] * (1.f - th * th) : 0.f;
+                    }
+                    st8<T>(Tr + h * ld + c0, tv);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int h = 0; h < 5; ++h) {
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < MB; ++k) {
+            const int c0 = k * 512 + lane * 8;
+            if (c0 < ld) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) lds[w * ld + c0 + e] = acc[h][k][e];
+            }
+        }
+        __syncthreads();
+        for (int c = threadIdx.x; c < C; c += 256) {
+            const float s = lds[c] + lds[ld + c] + lds[2 * ld + c] + lds[3 * ld + c];
+            if (s != 0.f) atomicAdd(dg + (long)b * 5 * ld + h * ld + c, s);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// build_spa_graph softmaxes: one 1024-thread workgroup per sample; lane = word index t.
+// ------------------------------------------------------------------------------------------
+constexpr float F32_MIN = -3.4028234663852886e38f;     // tf.float32.min
+
+template <typename T>
+__global__ __launch_bounds__(1024) void graph_softmax_fwd_kernel(const float* __restrict__ A0, const float* __restrict__ pr, const float* __restrict__ mask,
+                                                                float* __restrict__ gw_w, float* __restrict__ gw_v, T* __restrict__ gw_w_t, T* __restrict__ gw_v_t,
+                                                                int N, int Tn, int Tp) {
+    __shared__ float cmax[16][64], csum[16][64];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, b = blockIdx.x;
+    const bool tv = lane < Tn;
+    const float prt = tv ? pr[b * Tn + lane] : 0.f;
+    const float mk = tv ? mask[b * Tn + lane] : 0.f;
+    const long sb = (long)b * N * Tp;
+    float m_run = -INFINITY, s_run = 0.f;
+    for (int n = w; n < N; n += 16) {
+        const float a = tv ? prt * A0[sb + (long)n * Tp + lane] : 0.f;
+        // row softmax over t (masked)
+        const float lg = tv ? (mk * a + (1.f - mk) * F32_MIN) : -INFINITY;
+        const float mx = wave_max(lg);
+        const float ex = tv ? expf(lg - mx) : 0.f;
+        const float sm = wave_sum(ex);
+        const float p = ex / sm;
+        if (lane < Tp) {
+            gw_w[sb + (long)n * Tp + lane] = p;
+            Elem<T>::st(gw_w_t + sb + (long)n * Tp + lane, p);
+        }
+        // online column statistics over n
+        if (tv) {
+            const float mn = fmaxf(m_run, a);
+            s_run = s_run * expf(m_run - mn) + expf(a - mn);
+            m_run = mn;
+        }
+    }
+    cmax[w][lane] = m_run; csum[w][lane] = s_run;
+    __syncthreads();
+    float M = -INFINITY;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) M = fmaxf(M, cmax[i][lane]);
+    float S = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) S += (cmax[i][lane] == -INFINITY) ? 0.f : csum[i][lane] * expf(cmax[i][lane] - M);
+    for (int n = w; n < N; n += 16) {
+        float v = 0.f;
+        if (tv) v = expf(prt * A0[sb + (long)n * Tp + lane] - M) / S * mk;
+        if (lane < Tp) {
+            gw_v[sb + (long)n * Tp + lane] = v;
+            Elem<T>::st(gw_v_t + sb + (long)n * Tp + lane, v);
+        }
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(1024) void graph_softmax_bwd_kernel(const float* __restrict__ dgw_w, const float* __restrict__ dgw_v,
+                                                                const float* __restrict__ gw_w, const float* __restrict__ gw_v,
+                                                                const float* __restrict__ A0, const float* __restrict__ pr, const float* __restrict__ mask,
+                                                                float* __restrict__ dA0, T* __restrict__ dA0_t, float* __restrict__ dpr,
+                                                                int N, int Tn, int Tp) {
+    __shared__ float red[16][64];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, b = blockIdx.x;
+    const bool tv = lane < Tn;
+    const float prt = tv ? pr[b * Tn + lane] : 0.f;
+    const float mk = tv ? mask[b * Tn + lane] : 0.f;
+    const long sb = (long)b * N * Tp;
+    // column dots  sum_n sv * dsv   (sv = gw_v where mask = 1; masked columns contribute 0)
+    float cd = 0.f;
+    for (int n = w; n < N; n += 16)
+        if (tv) cd += gw_v[sb + (long)n * Tp + lane] * dgw_v[sb + (long)n * Tp + lane] * mk;
+    red[w][lane] = cd;
+    __syncthreads();
+    float CD = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) CD += red[i][lane];
+    __syncthreads();
+    float dp = 0.f;
+    for (int n = w; n < N; n += 16) {
+        const long o = sb + (long)n * Tp + lane;
+        const float pw = tv ? gw_w[o] : 0.f, dw = tv ? dgw_w[o] : 0.f;
+        const float rd = wave_sum(pw * dw);
+        float dA = 0.f;
+        if (tv) {
+            dA = mk * pw * (dw - rd);
+            const float sv = gw_v[o];
+            dA += sv * (dgw_v[o] * mk - CD);
+            dp += dA * A0[o];
+        }
+        if (lane < Tp) {
+            const float v = tv ? dA * prt : 0.f;
+            dA0[o] = v;
+            Elem<T>::st(dA0_t + o, v);
+        }
+    }
+    red[w][lane] = dp;
+    __syncthreads();
+    if (w == 0 && tv) {
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) s += red[i][lane];
+        dpr[b * Tn + lane] = s;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// gated exchange helpers
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void softmax_n_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, int N) {
+    __shared__ float red[4];
+    const int b = blockIdx.x;
+    float m = -INFINITY;
+    for (int n = threadIdx.x; n < N; n += 256) m = fmaxf(m, x[(long)b * N + n]);
+    m = block_max_256(m, red);
+    float s = 0.f;
+    for (int n = threadIdx.x; n < N; n += 256) s += expf(x[(long)b * N + n] - m);
+    s = block_sum_256(s, red);
+    for (int n = threadIdx.x; n < N; n += 256) y[(long)b * N + n] = expf(x[(long)b * N + n] - m) / s;
+}
+
+__global__ __launch_bounds__(256) void softmax_n_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ y, float* __restrict__ dx, int N) {
+    __shared__ float red[4];
+    const int b = blockIdx.x;
+    float d = 0.f;
+    for (int n = threadIdx.x; n < N; n += 256) d += dy[(long)b * N + n] * y[(long)b * N + n];
+    d = block_sum_256(d, red);
+    for (int n = threadIdx.x; n < N; n += 256) dx[(long)b * N + n] = y[(long)b * N + n] * (dy[(long)b * N + n] - d);
+}
+
+__global__ __launch_bounds__(256) void l2norm_all_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, float* __restrict__ rstd1, int n) {
+    __shared__ float red[4];
+    float ss = 0.f;
+    for (int i = threadIdx.x; i < n; i += 256) ss += x[i] * x[i];
+    ss = block_sum_256(ss, red);
+    const float rs = rsqrtf(fmaxf(ss, 1e-12f));
+    for (int i = threadIdx.x; i < n; i += 256) y[i] = x[i] * rs;
+    if (threadIdx.x == 0) rstd1[0] = (ss < 1e-12f) ? -rs : rs;
+}
+
+__global__ __launch_bounds__(256) void l2norm_all_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ y, const float* __restrict__ rstd1,
+                                                            float* __restrict__ dx, int n) {
+    __shared__ float red[4];
+    float d = 0.f;
+    for (int i = threadIdx.x; i < n; i += 256) d += dy[i] * y[i];
+    d = block_sum_256(d, red);
+    const float rs = rstd1[0], a = fabsf(rs);
+    if (rs < 0.f) d = 0.f;
+    for (int i = threadIdx.x; i < n; i += 256) dx[i] = a * (dy[i] - y[i] * d);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void exch_combine_fwd_kernel(const T* __restrict__ feat, const T* __restrict__ r1, const T* __restrict__ r2,
+                                                              const float* __restrict__ g1, const float* __restrict__ g2, int ld_g,
+                                                              T* __restrict__ out, float* __restrict__ rstd, int N, int ld, int C) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, b = blockIdx.y;
+    for (int n = blockIdx.x * WPB + w; n < N; n += gridDim.x * WPB) {
+        const long base = ((long)b * N + n) * ld;
+        float v[MB][8];
+        float ss = 0.f;
+#pragma unroll
+        for (int k = 0; k < MB; ++k) {
+            const int c0 = k * 512 + lane * 8;
+            if (c0 < ld) {
+                float f[8], a[8], c[8];
+                ld8<T>(feat + base + c0, f); ld8<T>(r1 + base + c0, a); ld8<T>(r2 + base + c0, c);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const int cc = c0 + e;
+                    v[k][e] = (cc < C) ? f[e] + a[e] * g1[(long)b * ld_g + cc] + c[e] * g2[(long)b * ld_g + cc] : 0.f;
+                    ss += v[k][e] * v[k][e];
+                }
+            }
+        }
+        ss = wave_sum(ss);
+        const bool clamped = ss < 1e-12f;
+        const float rs = rsqrtf(fmaxf(ss, 1e-12f));
+#pragma unroll
+        for (int k = 0; k < MB; ++k) {
+            const int c0 = k * 512 + lane * 8;
+            if (c0 < ld) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[k][e] *= rs;
+                st8<T>(out + base + c0, v[k]);
+            }
+        }
+        if (lane == 0) rstd[(long)b * N + n] = clamped ? -rs : rs;
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void exch_combine_bwd_kernel(const T* __restrict__ dout, const T* __restrict__ out, const float* __restrict__ rstd,
+                                                              const T* __restrict__ r1, const T* __restrict__ r2,
+                                                              const float* __restrict__ g1, const float* __restrict__ g2, int ld_g,
+                                                              T* __restrict__ dfeat, int accumulate, T* __restrict__ dp1, T* __restrict__ dp2,
+                                                              float* dg1, float* dg2, int N, int ld, int C) {
+    extern __shared__ float lds[];     // [WPB][2*ld]
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, b = blockIdx.y;
+    float a1[MB][8], a2[MB][8];
+#pragma unroll
+    for (int k = 0; k < MB; ++k)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { a1[k][e] = 0.f; a2[k][e] = 0.f; }
+    for (int n = blockIdx.x * WPB + w; n < N; n += gridDim.x * WPB) {
+        const long base = ((long)b * N + n) * ld;
+        float d[MB][8], ov[MB][8];
+        float dot = 0.f;
+#pragma unroll
+        for (int k = 0; k < MB; ++k) {
+            const int c0 = k * 512 + lane * 8;
+            if (c0 < ld) {
+                ld8<T>(dout + base + c0, d[k]); ld8<T>(out + base + c0, ov[k]);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { if (c0 + e >= C) d[k][e] = 0.f; dot += d[k][e] * ov[k][e]; }
+            }
+        }
+        dot = wave_sum(dot);
+        const float rs = rstd[(long)b * N + n], a = fabsf(rs);
+        if (rs < 0.f) dot = 0.f;
+#pragma unroll
+        for (int k = 0; k < MB; ++k) {
+            const int c0 = k * 512 + lane * 8;
+            if (c0 < ld) {
+                float x1[8], x2[8], o1[8], o2[8], df[8];
+                ld8<T>(r1 + base + c0, x1); ld8<T>(r2 + base + c0, x2);
+                if (accumulate) ld8<T>(dfeat + base + c0, df);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const int cc = c0 + e;
+                    const float dE = (cc < C) ? a * (d[k][e] - ov[k][e] * dot) : 0.f;
+                    a1[k][e] += dE * x1[e]; a2[k][e] += dE * x2[e];
+                    o1[e] = (cc < C && x1[e] > 0.f) ? dE * g1[(long)b * ld_g + cc] : 0.f;
+                    o2[e] = (cc < C && x2[e] > 0.f) ? dE * g2[(long)b * ld_g + cc] : 0.f;
+                    df[e] = accumulate ? df[e] + dE : dE;
+                }
+                st8<T>(dp1 + base + c0, o1); st8<T>(dp2 + base + c0, o2); st8<T>(dfeat + base + c0, df);
+            }
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < MB; ++k) {
+        const int c0 = k * 512 + lane * 8;
+        if (c0 < ld) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { lds[(w * 2) * ld + c0 + e] = a1[k][e]; lds[(w * 2 + 1) * ld + c0 + e] = a2[k][e]; }
+        }
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += 256) {
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int ww = 0; ww < WPB; ++ww) { s1 += lds[(ww * 2) * ld + c]; s2 += lds[(ww * 2 + 1) * ld + c]; }
+        if (s1 != 0.f) atomicAdd(dg1 + (long)b * ld_g + c, s1);
+        if (s2 != 0.f) atomicAdd(dg2 + (long)b * ld_g + c, s2);
+    }
+}
+
+bool map_ok(const char* what, int ld, int C, int dt) {
+    if (ld <= 0 || C <= 0 || C > ld || ld % 8 || ld > MB * 512) {
+        cmpc_set_error("%s: need 0 < C <= ld <= %d, ld %% 8 == 0 (got C=%d ld=%d)", what, MB * 512, C, ld);
+        return false;
+    }
+    if (dt != DT_F32 && dt != DT_BF16) { cmpc_set_error("%s: bad dtype %d", what, dt); return false; }
+    return true;
+}
+
+}  // namespace
+
+#define ST ((hipStream_t)stream)
+
+extern "C" int cmpc_mutan_fwd(int dt, void* P, const float* g, void* X1, float* rstd, int B, int N, int ld, int C, void* stream) {
+    if (!map_ok("mutan_fwd", ld, C, dt)) return CMPC_EINVAL;
+    CMPC_DISPATCH_DT(dt, hipLaunchKernelGGL((mutan_fwd_kernel<T>), dim3(rows_grid(N, 64), B), dim3(256), 0, ST, (T*)P, g, (T*)X1, rstd, N, ld, C));
+    return cmpc_check_launch("mutan_fwd");
+}
+
+extern "C" int cmpc_mutan_bwd(int dt, void* Th, const float* g, const void* X1, const float* rstd, const void* dX1,
+                              float* dg, int B, int N, int ld, int C, void* stream) {
+    if (!map_ok("mutan_bwd", ld, C, dt)) return CMPC_EINVAL;
+    CMPC_DISPATCH_DT(dt, hipLaunchKernelGGL((mutan_bwd_kernel<T>), dim3(rows_grid(N, 32), B), dim3(256), WPB * ld * sizeof(float), ST,
+                                             (T*)Th, g, (const T*)X1, rstd, (const T*)dX1, dg, N, ld, C));
+    return cmpc_check_launch("mutan_bwd");
+}
+
+extern "C" int cmpc_graph_softmax_fwd(int dt, const float* A0, const float* pr, const float* mask, float* gw_w, float* gw_v,
+                                      void* gw_w_t, void* gw_v_t, int B, int N, int T_, int Tp, void* stream) {
+    if (T_ <= 0 || T_ > 64 || Tp < T_ || Tp > 64) { cmpc_set_error("graph_softmax: need 0 < T <= Tp <= 64"); return CMPC_EINVAL; }
+    CMPC_DISPATCH_DT(dt, hipLaunchKernelGGL((graph_softmax_fwd_kernel<T>), dim3(B), dim3(1024), 0, ST, A0, pr, mask, gw_w, gw_v, (T*)gw_w_t, (T*)gw_v_t, N, T_, Tp));
+    return cmpc_check_launch("graph_softmax_fwd");
+}
+
+extern "C" int cmpc_graph_softmax_bwd(int dt, const float* dgw_w, const float* dgw_v, const float* gw_w, const float* gw_v,
+                                      const float* A0, const float* pr, const float* mask, float* dA0, void* dA0_t, float* dpr,
+                                      int B, int N, int T_, int Tp, void* stream) {
+    if (T_ <= 0 || T_ > 64 || Tp < T_ || Tp > 64) { cmpc_set_error("graph_softmax: need 0 < T <= Tp <= 64"); return CMPC_EINVAL; }
+    CMPC_DISPATCH_DT(dt, hipLaunchKernelGGL((graph_softmax_bwd_kernel<T>), dim3(B), dim3(1024), 0, ST, dgw_w, dgw_v, gw_w, gw_v, A0, pr, mask,
+                                             dA0, (T*)dA0_t, dpr, N, T_, Tp));
+    return cmpc_check_launch("graph_softmax_bwd");
+}
+
+extern "C" int cmpc_softmax_n_fwd(const float* logits, float* attn, int B, int N, void* stream) {
+    hipLaunchKernelGGL(softmax_n_fwd_kernel, dim3(B), dim3(256), 0, ST, logits, attn, N);
+    return cmpc_check_launch("softmax_n_fwd");
+}
+extern "C" int cmpc_softmax_n_bwd(const float* dattn, const float* attn, float* dlogits, int B, int N, void* stream) {
+    hipLaunchKernelGGL(softmax_n_bwd_kernel, dim3(B), dim3(256), 0, ST, dattn, attn, dlogits, N);
+    return cmpc_check_launch("softmax_n_bwd");
+}
+extern "C" int cmpc_l2norm_all_fwd(const float* x, float* y, float* rstd1, int n, void* stream) {
+    hipLaunchKernelGGL(l2norm_all_fwd_kernel, dim3(1), dim3(256), 0, ST, x, y, rstd1, n);
+    return cmpc_check_launch("l2norm_all_fwd");
+}
+extern "C" int cmpc_l2norm_all_bwd(const float* dy, const float* y, const float* rstd1, float* dx, int n, void* stream) {
+    hipLaunchKernelGGL(l2norm_all_bwd_kernel, dim3(1), dim3(256), 0, ST, dy, y, rstd1, dx, n);
+    return cmpc_check_launch("l2norm_all_bwd");
+}
+
+extern "C" int cmpc_exchange_combine_fwd(int dt, const void* feat, const void* r1, const void* r2, const float* g1, const float* g2,
+                                         int ld_g, void* out, float* rstd, int B, int N, int ld, int C, void* stream) {
+    if (!map_ok("exchange_combine_fwd", ld, C, dt)) return CMPC_EINVAL;
+    CMPC_DISPATCH_DT(dt, hipLaunchKernelGGL((exch_combine_fwd_kernel<T>), dim3(rows_grid(N, 64), B), dim3(256), 0, ST,
+                                             (const T*)feat, (const T*)r1, (const T*)r2, g1, g2, ld_g, (T*)out, rstd, N, ld, C));
+    return cmpc_check_launch("exchange_combine_fwd");
+}
+
+extern "C" int cmpc_exchange_combine_bwd(int dt, const void* dout, const void* out, const float* rstd, const void* r1, const void* r2,
+                                         const float* g1, const float* g2, int ld_g, void* dfeat, int accumulate_dfeat,
+                                         void* dp1, void* dp2, float* dg1, float* dg2, int B, int N, int ld, int C, void* stream) {
+    if (!map_ok("exchange_combine_bwd", ld, C, dt)) return CMPC_EINVAL;
+    CMPC_DISPATCH_DT(dt, hipLaunchKernelGGL((exch_combine_bwd_kernel<T>), dim3(rows_grid(N, 32), B), dim3(256), WPB * 2 * ld * sizeof(float), ST,
+                                             (const T*)dout, (const T*)out, rstd, (const T*)r1, (const T*)r2, g1, g2, ld_g,
+                                             (T*)dfeat, accumulate_dfeat, (T*)dp1, (T*)dp2, dg1, dg2, N, ld, C));
+    return cmpc_check_launch("exchange_combine_bwd");
+}

@@ -1,0 +1,260 @@
+// Language-side kernels (reference CMPC_model.py:144-192,347-357) and parameter maintenance
+// (packing fp32 masters into padded GEMM operands; TF-Adam, CMPC_model.py:450-478).
+// The language tensors are tiny ([B*T, .]); they stay fp32 end to end.
+#include "cmpc_common.h"
+#include "../../include/cmpc.h"
+
+namespace {
+
+__global__ void embed_gather_kernel(const float* __restrict__ table, const int* __restrict__ words, float* __restrict__ out,
+                                    int G, int ld_out, int vocab) {
+    const int r = blockIdx.x;
+    int wd = words[r];
+    wd = wd < 0 ? 0 : (wd >= vocab ? vocab - 1 : wd);
+    for (int c = threadIdx.x; c < ld_out; c += blockDim.x) out[(long)r * ld_out + c] = (c < G) ? table[(long)wd * G + c] : 0.f;
+}
+
+__global__ void embed_scatter_kernel(const float* __restrict__ dout, int ld, const int* __restrict__ words, float* dtable, int G, int vocab) {
+    const int r = blockIdx.x;
+    int wd = words[r];
+    wd = wd < 0 ? 0 : (wd >= vocab ? vocab - 1 : wd);
+    for (int c = threadIdx.x; c < G; c += blockDim.x) {
+        const float g = dout[(long)r * ld + c];
+        if (g != 0.f) atomicAdd(dtable + (long)wd * G + c, g);
+    }
+}
+
+// tf LSTMCell: i, j, f, o = split(gates); c' = sig(f + 1) c + sig(i) tanh(j); h' = sig(o) tanh(c')
+__global__ void lstm_cell_fwd_kernel(float* __restrict__ gates, const float* __restrict__ c_prev, const float* __restrict__ h_prev,
+                                     const int* __restrict__ seq_len, int t, float* __restrict__ c_out, float* __restrict__ h_out,
+                                     float* __restrict__ out_t, int ld_out, int ld, int R) {
+    const int b = blockIdx.y;
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= ld) return;
+    float* g = gates + (long)b * 4 * ld;
+    const bool live = t < seq_len[b];
+    float cn = 0.f, hn = 0.f;
+    if (c < R) {
+        const float is = sigmoidf_(g[c]), jt = tanhf(g[ld + c]), fs = sigmoidf_(g[2 * ld + c] + 1.0f), os = sigmoidf_(g[3 * ld + c]);
+        g[c] = is; g[ld + c] = jt; g[2 * ld + c] = fs; g[3 * ld + c] = os;
+        cn = fs * c_prev[(long)b * ld + c] + is * jt;
+        hn = os * tanhf(cn);
+    } else { g[c] = 0.f; g[ld + c] = 0.f; g[2 * ld + c] = 0.f; g[3 * ld + c] = 0.f; }
+    const long o = (long)b * ld + c;
+    c_out[o] = live ? cn : c_prev[o];
+    h_out[o] = live ? hn : h_prev[o];
+    out_t[(long)b * ld_out + c] = live ? hn : 0.f;
+}
+
+__global__ void lstm_cell_bwd_kernel(const float* __restrict__ ga, const float* __restrict__ c_prev, const float* __restrict__ c_out,
+                                     const int* __restrict__ seq_len, int t, const float* __restrict__ dout_t, int ld_dout,
+                                     float* __restrict__ dh, float* __restrict__ dc, float* __restrict__ dgates, int ld, int R) {
+    const int b = blockIdx.y;
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= ld) return;
+    const bool live = t < seq_len[b];
+    const long o = (long)b * ld + c;
+    float* dg = dgates + (long)b * 4 * ld;
+    if (!live || c >= R) {
+        dg[c] = 0.f; dg[ld + c] = 0.f; dg[2 * ld + c] = 0.f; dg[3 * ld + c] = 0.f;
+        if (c >= R) { dh[o] = 0.f; dc[o] = 0.f; }
+        return;   // state gradients pass through unchanged for finished sequences
+    }
+    const float* g = ga + (long)b * 4 * ld;
+    const float is = g[c], jt = g[ld + c], fs = g[2 * ld + c], os = g[3 * ld + c];
+    const float cn = c_out[o], tc = tanhf(cn);
+    const float dhn = dout_t[(long)b * ld_dout + c] + dh[o];
+    const float dcn = dc[o] + dhn * os * (1.f - tc * tc);
+    dg[c] = dcn * jt * is * (1.f - is);
+    dg[ld + c] = dcn * is * (1.f - jt * jt);
+    dg[2 * ld + c] = dcn * c_prev[o] * fs * (1.f - fs);
+    dg[3 * ld + c] = dhn * tc * os * (1.f - os);
+    dc[o] = dcn * fs;
+    dh[o] = 0.f;          // the caller adds dgates . W_h^T
+}
+
+__global__ void parse_softmax_fwd_kernel(const float* __restrict__ logits, int ld, const float* __restrict__ mask, float* __restrict__ parse, int n) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n) return;
+    const float* l = logits + (long)r * ld;
+    const float m = fmaxf(fmaxf(l[0], l[1]), fmaxf(l[2], l[3]));
+    const float e0 = expf(l[0] - m), e1 = expf(l[1] - m), e2 = expf(l[2] - m), e3 = expf(l[3] - m);
+    const float s = e0 + e1 + e2 + e3, mk = mask[r];
+    parse[r * 4 + 0] = e0 / s * mk; parse[r * 4 + 1] = e1 / s * mk; parse[r * 4 + 2] = e2 / s * mk; parse[r * 4 + 3] = e3 / s * mk;
+}
+
+__global__ void parse_softmax_bwd_kernel(const float* __restrict__ dparse, const float* __restrict__ parse, const float* __restrict__ mask,
+                                         float* __restrict__ dlogits, int ld, int n) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n) return;
+    const float mk = mask[r];
+    float p[4], d[4], dot = 0.f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { p[k] = parse[r * 4 + k]; d[k] = dparse[r * 4 + k] * mk; dot += p[k] * d[k]; }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) dlogits[(long)r * ld + k] = (mk != 0.f) ? p[k] * (d[k] - dot) : 0.f;
+    for (int k = 4; k < ld; ++k) dlogits[(long)r * ld + k] = 0.f;
+}
+
+__global__ __launch_bounds__(256) void lang_pool_fwd_kernel(const float* __restrict__ parse, const float* __restrict__ wf, float* __restrict__ v,
+                                                           float* __restrict__ rstd, int T, int ld, int R, int ncls) {
+    __shared__ float red[4];
+    const int b = blockIdx.x;
+    float ss = 0.f;
+    for (int c = threadIdx.x; c < ld; c += 256) {
+        float acc = 0.f;
+        if (c < R) {
+            for (int t = 0; t < T; ++t) {
+                float wgt = 0.f;
+                for (int k = 0; k < ncls; ++k) wgt += parse[((long)b * T + t) * 4 + k];
+                acc += wgt * wf[((long)b * T + t) * ld + c];
+            }
+        }
+        v[(long)b * ld + c] = acc;
+        ss += acc * acc;
+    }
+    ss = block_sum_256(ss, red);
+    const float rs = rsqrtf(fmaxf(ss, 1e-12f));
+    for (int c = threadIdx.x; c < ld; c += 256) v[(long)b * ld + c] *= rs;
+    if (threadIdx.x == 0) rstd[b] = (ss < 1e-12f) ? -rs : rs;
+}
+
+__global__ __launch_bounds__(256) void lang_pool_bwd_kernel(const float* __restrict__ dv, const float* __restrict__ v, const float* __restrict__ rstd,
+                                                           const float* __restrict__ parse, const float* __restrict__ wf,
+                                                           float* __restrict__ dparse, float* __restrict__ dwf, int T, int ld, int R, int ncls) {
+    __shared__ float red[4];
+    const int b = blockIdx.x;
+    float dot = 0.f;
+    for (int c = threadIdx.x; c < R; c += 256) dot += dv[(long)b * ld + c] * v[(long)b * ld + c];
+    dot = block_sum_256(dot, red);
+    const float rs = rstd[b], a = fabsf(rs);
+    if (rs < 0.f) dot = 0.f;
+    for (int t = 0; t < T; ++t) {
+        float wgt = 0.f;
+        for (int k = 0; k < ncls; ++k) wgt += parse[((long)b * T + t) * 4 + k];
+        float dw = 0.f;
+        for (int c = threadIdx.x; c < R; c += 256) {
+            const float draw = a * (dv[(long)b * ld + c] - v[(long)b * ld + c] * dot);
+            const long o = ((long)b * T + t) * ld + c;
+            dw += draw * wf[o];
+            dwf[o] += wgt * draw;
+        }
+        dw = block_sum_256(dw, red);
+        if (threadIdx.x == 0)
+            for (int k = 0; k < ncls; ++k) dparse[((long)b * T + t) * 4 + k] += dw;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// pack: padded operand (k, n) <- master[src_row(k), src_col(n)] through a 32x32 LDS tile so that
+// both the read (n contiguous) and the transposed write (k contiguous) are coalesced.
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ int seg_map(int x, int ns, const int* src, const int* len, const int* dst) {
+    for (int s = 0; s < ns; ++s) if (x >= dst[s] && x < dst[s] + len[s]) return src[s] + (x - dst[s]);
+    return -1;
+}
+
+__global__ __launch_bounds__(256) void pack_kernel(const float* __restrict__ master, char* __restrict__ arena, const cmpc_pack_desc* __restrict__ descs) {
+    __shared__ float tile[32][33];
+    const cmpc_pack_desc d = descs[blockIdx.y];
+    const int Kp = d.transpose ? d.cols : d.rows, Np = d.transpose ? d.rows : d.cols;
+    const int tk = (Kp + 31) / 32, tn = (Np + 31) / 32;
+    if ((int)blockIdx.x >= tk * tn) return;
+    const int k0 = (blockIdx.x / tn) * 32, n0 = (blockIdx.x % tn) * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int i = ty; i < 32; i += 8) {
+        const int k = k0 + i, n = n0 + tx;
+        float v = 0.f;
+        if (k < Kp && n < Np) {
+            const int sr = seg_map(k, d.nks, d.ks_src, d.ks_len, d.ks_dst);
+            const int sc = seg_map(n, d.nns, d.ns_src, d.ns_len, d.ns_dst);
+            if (sr >= 0 && sc >= 0) v = master[d.src_off + (long)sr * d.ld_src + sc];
+        }
+        tile[i][tx] = v;
+    }
+    __syncthreads();
+    char* dst = arena + d.dst_off;
+    for (int i = ty; i < 32; i += 8) {
+        float v; long o; bool okk;
+        if (d.transpose) { const int n = n0 + i, k = k0 + tx; v = tile[tx][i]; o = (long)n * d.ld_dst + k; okk = n < Np && k < Kp; }
+        else { const int k = k0 + i, n = n0 + tx; v = tile[i][tx]; o = (long)k * d.ld_dst + n; okk = n < Np && k < Kp; }
+        if (okk) {
+            if (d.dst_dt == DT_F32) reinterpret_cast<float*>(dst)[o] = v;
+            else reinterpret_cast<bf16_t*>(dst)[o] = f2bf(v);
+        }
+    }
+}
+
+// tf.train.AdamOptimizer:  m = b1 m + (1-b1) g;  v = b2 v + (1-b2) g^2;  p -= lr_t m / (sqrt(v) + eps)
+__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+                                                  const cmpc_adam_seg* __restrict__ segs, float lr_t, float b1, float b2, float eps, float gscale) {
+    const cmpc_adam_seg s = segs[blockIdx.x];
+    for (int i = threadIdx.x; i < s.count; i += 256) {
+        const long o = s.off + i;
+        const float pv = p[o];
+        const float gr = g[o] * gscale * s.gmult + s.wd * pv;
+        const float mn = b1 * m[o] + (1.f - b1) * gr;
+        const float vn = b2 * v[o] + (1.f - b2) * gr * gr;
+        m[o] = mn; v[o] = vn;
+        p[o] = pv - lr_t * mn / (sqrtf(vn) + eps);
+    }
+}
+
+}  // namespace
+
+#define ST ((hipStream_t)stream)
+
+extern "C" int cmpc_embed_gather(const float* table, const int* words, float* out, int n_words, int G, int ld_out, int vocab, void* stream) {
+    if (n_words <= 0) return CMPC_OK;
+    hipLaunchKernelGGL(embed_gather_kernel, dim3(n_words), dim3(128), 0, ST, table, words, out, G, ld_out, vocab);
+    return cmpc_check_launch("embed_gather");
+}
+extern "C" int cmpc_embed_scatter(const float* dout, int ld, const int* words, float* dtable, int n_words, int G, int vocab, void* stream) {
+    if (n_words <= 0) return CMPC_OK;
+    hipLaunchKernelGGL(embed_scatter_kernel, dim3(n_words), dim3(128), 0, ST, dout, ld, words, dtable, G, vocab);
+    return cmpc_check_launch("embed_scatter");
+}
+extern "C" int cmpc_lstm_cell_fwd(float* gates, const float* c_prev, const float* h_prev, const int* seq_len, int t,
+                                  float* c_out, float* h_out, float* out_t, int ld_out, int B, int ld, int R, void* stream) {
+    hipLaunchKernelGGL(lstm_cell_fwd_kernel, dim3((ld + 255) / 256, B), dim3(256), 0, ST, gates, c_prev, h_prev, seq_len, t, c_out, h_out, out_t, ld_out, ld, R);
+    return cmpc_check_launch("lstm_cell_fwd");
+}
+extern "C" int cmpc_lstm_cell_bwd(const float* gates_act, const float* c_prev, const float* c_out, const int* seq_len, int t,
+                                  const float* dout_t, int ld_dout, float* dh, float* dc, float* dgates,
+                                  int B, int ld, int R, void* stream) {
+    hipLaunchKernelGGL(lstm_cell_bwd_kernel, dim3((ld + 255) / 256, B), dim3(256), 0, ST, gates_act, c_prev, c_out, seq_len, t, dout_t, ld_dout, dh, dc, dgates, ld, R);
+    return cmpc_check_launch("lstm_cell_bwd");
+}
+extern "C" int cmpc_parse_softmax_fwd(const float* logits, int ld, const float* mask, float* parse, int n, void* stream) {
+    hipLaunchKernelGGL(parse_softmax_fwd_kernel, dim3((n + 63) / 64), dim3(64), 0, ST, logits, ld, mask, parse, n);
+    return cmpc_check_launch("parse_softmax_fwd");
+}
+extern "C" int cmpc_parse_softmax_bwd(const float* dparse, const float* parse, const float* mask, float* dlogits, int ld, int n, void* stream) {
+    hipLaunchKernelGGL(parse_softmax_bwd_kernel, dim3((n + 63) / 64), dim3(64), 0, ST, dparse, parse, mask, dlogits, ld, n);
+    return cmpc_check_launch("parse_softmax_bwd");
+}
+extern "C" int cmpc_lang_pool_fwd(const float* parse, const float* wf, float* v, float* rstd, int B, int T, int ld, int R, int ncls, void* stream) {
+    if (ncls < 1 || ncls > 4) { cmpc_set_error("lang_pool: ncls must be 1..4"); return CMPC_EINVAL; }
+    hipLaunchKernelGGL(lang_pool_fwd_kernel, dim3(B), dim3(256), 0, ST, parse, wf, v, rstd, T, ld, R, ncls);
+    return cmpc_check_launch("lang_pool_fwd");
+}
+extern "C" int cmpc_lang_pool_bwd(const float* dv, const float* v, const float* rstd, const float* parse, const float* wf,
+                                  float* dparse, float* dwf, int B, int T, int ld, int R, int ncls, void* stream) {
+    if (ncls < 1 || ncls > 4) { cmpc_set_error("lang_pool: ncls must be 1..4"); return CMPC_EINVAL; }
+    hipLaunchKernelGGL(lang_pool_bwd_kernel, dim3(B), dim3(256), 0, ST, dv, v, rstd, parse, wf, dparse, dwf, T, ld, R, ncls);
+    return cmpc_check_launch("lang_pool_bwd");
+}
+
+extern "C" int cmpc_pack_weights(const float* master, void* arena, const cmpc_pack_desc* descs_dev, int ndesc, int max_tiles, void* stream) {
+    if (ndesc <= 0) return CMPC_OK;
+    if (max_tiles <= 0) { cmpc_set_error("pack_weights: max_tiles must be > 0"); return CMPC_EINVAL; }
+    hipLaunchKernelGGL(pack_kernel, dim3(max_tiles, ndesc), dim3(256), 0, ST, master, (char*)arena, descs_dev);
+    return cmpc_check_launch("pack_weights");
+}
+
+extern "C" int cmpc_adam_step(float* params, const float* grads, float* m, float* v, const cmpc_adam_seg* segs_dev, int nseg,
+                              float lr_t, float beta1, float beta2, float eps, float gscale, void* stream) {
+    if (nseg <= 0) return CMPC_OK;
+    hipLaunchKernelGGL(adam_kernel, dim3(nseg), dim3(256), 0, ST, params, grads, m, v, segs_dev, lr_t, beta1, beta2, eps, gscale);
+    return cmpc_check_launch("adam_step");
+}

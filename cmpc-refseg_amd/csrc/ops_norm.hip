@@ -1,0 +1,624 @@
+// Row / whole-sample normalisation kernels and small map utilities (HBM-bound, wave-per-row).
+// Layout: map [B*N, ld] of T (bf16 or f32), C valid channels, 16-byte vector accesses, fp32 math,
+// wave64 shuffle reductions; per-sample sums in float64 atomics, per-column sums reduced through
+// LDS then one fp32 atomic per column per workgroup.
+#include "cmpc_common.h"
+#include "../../include/cmpc.h"
+#include <stdarg.h>
+#include <stdio.h>
+
+// ------------------------------------------------------------------------------------------
+// error plumbing shared by all translation units
+// ------------------------------------------------------------------------------------------
+static thread_local char g_err[512] = "";
+void cmpc_set_error(const char* fmt, ...) {
+    va_list ap; va_start(ap, fmt); vsnprintf(g_err, sizeof(g_err), fmt, ap); va_end(ap);
+}
+int cmpc_check_launch(const char* what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { cmpc_set_error("%s: %s", what, hipGetErrorString(e)); return CMPC_EHIP; }
+    return CMPC_OK;
+}
+extern "C" const char* cmpc_last_error(void) { return g_err; }
+extern "C" int cmpc_abi_version(void) { return 1; }
+
+namespace {
+
+constexpr int MAXBLK = 4;      // ld <= 2048 for kernels that keep per-column registers
+constexpr int WPB = 4;         // waves per 256-thread block
+
+__host__ inline int rows_grid(int N) { int g = (N + WPB - 1) / WPB; return g < 1 ? 1 : (g > 64 ? 64 : g); }
+
+// flush per-lane column accumulators (lane owns columns blk*512 + lane*8 + e) into out[c] (atomics)
+__device__ __forceinline__ void colsum_flush(const float (&acc)[MAXBLK][8], float* out, int ld, int C, float* lds) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < MAXBLK; ++k) {
+        const int c0 = k * 512 + lane * 8;
+        if (c0 < ld) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) lds[w * ld + c0 + e] = acc[k][e];
+        }
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += 256) {
+        const float s = lds[c] + lds[ld + c] + lds[2 * ld + c] + lds[3 * ld + c];
+        if (s != 0.0f) atomicAdd(out + c, s);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+template <typename TS, typename TD>
+__global__ void cast_kernel(const TS* __restrict__ s, TD* __restrict__ d, long n) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+        Elem<TD>::st(d + i, Elem<TS>::ld(s + i));
+}
+
+template <typename T>
+__global__ void axpy_kernel(const T* __restrict__ x, T* __restrict__ y, float a, long n8) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (long)gridDim.x * blockDim.x) {
+        float xv[8], yv[8];
+        ld8<T>(x + i * 8, xv); ld8<T>(y + i * 8, yv);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) yv[e] += a * xv[e];
+        st8<T>(y + i * 8, yv);
+    }
+}
+
+// dpre = dy * act'(y); db[c] += sum; dsb[b][c] += per-sample sums
+template <typename T>
+__global__ __launch_bounds__(256) void act_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ y, T* __restrict__ dpre,
+                                                     int act, int N, int stride, int ld, int C, float* db, float* dsb, int ld_dsb) {
+    extern __shared__ float lds[];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, b = blockIdx.y;
+    float acc[MAXBLK][8];
+#pragma unroll
+    for (int k = 0; k < MAXBLK; ++k)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[k][e] = 0.f;
+    for (int n = blockIdx.x * WPB + w; n < N; n += gridDim.x * WPB) {
+        const long base = ((long)b * N + n) * stride;
+#pragma unroll
+        for (int k = 0; k < MAXBLK; ++k) {
+            const int c0 = k * 512 + lane * 8;
+            if (c0 < ld) {
+                float g[8], yv[8];
+                ld8<T>(dy + base + c0, g);
+                if (act != ACT_NONE) {
+                    ld8<T>(y + base + c0, yv);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) g[e] *= act_grad_from_out(yv[e], act);
+                }
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { if (c0 + e >= C) g[e] = 0.f; acc[k][e] += g[e]; }
+                if (dpre) st8<T>(dpre + base + c0, g);
+            }
+        }
+    }
+    if (db) colsum_flush(acc, db, ld, C, lds);
+    if (dsb) colsum_flush(acc, dsb + (long)b * ld_dsb, ld, C, lds);
+}
+
+// out[b,c] += sum_n w[b,n] * x[b,n,c]
+template <typename T>
+__global__ __launch_bounds__(256) void wcolsum_kernel(const T* __restrict__ x, const float* __restrict__ wgt, float* out, int ld_out,
+                                                     int N, int ld, int C, float scale) {
+    extern __shared__ float lds[];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, b = blockIdx.y;
+    float acc[MAXBLK][8];
+#pragma unroll
+    for (int k = 0; k < MAXBLK; ++k)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[k][e] = 0.f;
+    for (int n = blockIdx.x * WPB + w; n < N; n += gridDim.x * WPB) {
+        const float wv = wgt[(long)b * N + n] * scale;
+        const long base = ((long)b * N + n) * ld;
+#pragma unroll
+        for (int k = 0; k < MAXBLK; ++k) {
+            const int c0 = k * 512 + lane * 8;
+            if (c0 < ld) {
+                float xv[8];
+                ld8<T>(x + base + c0, xv);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) acc[k][e] += wv * xv[e];
+            }
+        }
+    }
+    colsum_flush(acc, out + (long)b * ld_out, ld, C, lds);
+}
+
+// s[b,n] = scale * x[b,n,:] . v[b,:]
+template <typename T>
+__global__ __launch_bounds__(256) void rowdot1_kernel(const T* __restrict__ x, const float* __restrict__ v, int ld_v, float* __restrict__ s,
+                                                     int N, int ld, int C, float scale) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, b = blockIdx.y;
+    for (int n = blockIdx.x * WPB + w; n < N; n += gridDim.x * WPB) {
+        const long base = ((long)b * N + n) * ld;
+        float acc = 0.f;
+        for (int c0 = lane * 8; c0 < ld; c0 += 512) {
+            float xv[8];
+            ld8<T>(x + base + c0, xv);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) if (c0 + e < C) acc += xv[e] * v[(long)b * ld_v + c0 + e];
+        }
+        acc = wave_sum(acc);
+        if (lane == 0) s[(long)b * N + n] = acc * scale;
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void rank1_kernel(T* __restrict__ x, const float* __restrict__ w1, const float* __restrict__ v1,
+                                                   const float* __restrict__ w2, const float* __restrict__ v2, int ld_v,
+                                                   float s1, float s2, int N, int ld, int C) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, b = blockIdx.y;
+    for (int n = blockIdx.x * WPB + w; n < N; n += gridDim.x * WPB) {
+        const long base = ((long)b * N + n) * ld;
+        const float a1 = s1 * w1[(long)b * N + n];
+        const float a2 = w2 ? s2 * w2[(long)b * N + n] : 0.f;
+        for (int c0 = lane * 8; c0 < ld; c0 += 512) {
+            float xv[8];
+            ld8<T>(x + base + c0, xv);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                if (c0 + e < C) {
+                    xv[e] += a1 * v1[(long)b * ld_v + c0 + e];
+                    if (w2) xv[e] += a2 * v2[(long)b * ld_v + c0 + e];
+                }
+            }
+            st8<T>(x + base + c0, xv);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// l2_normalize over channels.  rstd is stored NEGATIVE when sum(x^2) < eps (clamped branch:
+// y = x / sqrt(eps) and d y / d x is the constant 1/sqrt(eps)).
+// ------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void l2norm_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, float* __restrict__ rstd,
+                                                        float* __restrict__ nz, int R, int ld, int C) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    for (int r = blockIdx.x * WPB + w; r < R; r += gridDim.x * WPB) {
+        const long base = (long)r * ld;
+        float xv[MAXBLK][8];
+        float ss = 0.f;
+#pragma unroll
+        for (int k = 0; k < MAXBLK; ++k) {
+            const int c0 = k * 512 + lane * 8;
+            if (c0 < ld) {
+                ld8<T>(x + base + c0, xv[k]);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { if (c0 + e >= C) xv[k][e] = 0.f; ss += xv[k][e] * xv[k][e]; }
+            }
+        }
+        ss = wave_sum(ss);
+        const bool clamped = ss < 1e-12f;
+        const float rs = rsqrtf(fmaxf(ss, 1e-12f));
+        float sa = 0.f;
+#pragma unroll
+        for (int k = 0; k < MAXBLK; ++k) {
+            const int c0 = k * 512 + lane * 8;
+            if (c0 < ld) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { xv[k][e] *= rs; sa += fabsf(xv[k][e]); }
+                st8<T>(y + base + c0, xv[k]);
+            }
+        }
+        if (nz) sa = wave_sum(sa);
+        if (lane == 0) {
+            rstd[r] = clamped ? -rs : rs;
+            if (nz) nz[r] = (sa != 0.f) ? 1.f : 0.f;
+        }
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void l2norm_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ y, const float* __restrict__ rstd,
+                                                        T* __restrict__ dx, int R, int ld, int C, int accumulate) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    for (int r = blockIdx.x * WPB + w; r < R; r += gridDim.x * WPB) {
+        const long base = (long)r * ld;
+        float g[MAXBLK][8], yv[MAXBLK][8];
+        float dot = 0.f;
+#pragma unroll
+        for (int k = 0; k < MAXBLK; ++k) {
+            const int c0 = k * 512 + lane * 8;
+            if (c0 < ld) {
+                ld8<T>(dy + base + c0, g[k]); ld8<T>(y + base + c0, yv[k]);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { if (c0 + e >= C) g[k][e] = 0.f; dot += g[k][e] * yv[k][e]; }
+            }
+        }
+        dot = wave_sum(dot);
+        const float rs = rstd[r];
+        const float a = fabsf(rs);
+        if (rs < 0.f) dot = 0.f;
+#pragma unroll
+        for (int k = 0; k < MAXBLK; ++k) {
+            const int c0 = k * 512 + lane * 8;
+            if (c0 < ld) {
+                float o[8];
+                if (accumulate) ld8<T>(dx + base + c0, o);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float v = a * (g[k][e] - yv[k][e] * dot);
+                    o[e] = accumulate ? o[e] + v : v;
+                }
+                st8<T>(dx + base + c0, o);
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// per-sample {sum x, sum x^2} over (n, c < C)
+// ------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void sample_stats_kernel(const T* __restrict__ x, double* __restrict__ sums, int N, int ld, int C) {
+    __shared__ double red[2][WPB];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, b = blockIdx.y;
+    double s1 = 0.0, s2 = 0.0;
+    for (int n = blockIdx.x * WPB + w; n < N; n += gridDim.x * WPB) {
+        const long base = ((long)b * N + n) * ld;
+        float a1 = 0.f, a2 = 0.f;
+        for (int c0 = lane * 8; c0 < ld; c0 += 512) {
+            float xv[8];
+            ld8<T>(x + base + c0, xv);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) if (c0 + e < C) { a1 += xv[e]; a2 += xv[e] * xv[e]; }
+        }
+        s1 += (double)a1; s2 += (double)a2;
+    }
+    s1 = wave_sum_d(s1); s2 = wave_sum_d(s2);
+    if (lane == 0) { red[0][w] = s1; red[1][w] = s2; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        atomicAdd(sums + 2 * b, red[0][0] + red[0][1] + red[0][2] + red[0][3]);
+        atomicAdd(sums + 2 * b + 1, red[1][0] + red[1][1] + red[1][2] + red[1][3]);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// graph_conv elementwise parts
+// ------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void gconv_pre_fwd_kernel(const T* __restrict__ Y, const T* __restrict__ X, const double* __restrict__ sums,
+                                                           const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                           T* __restrict__ G, int N, int ld, int C) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, b = blockIdx.y;
+    float mean, rstd;
+    ln_stats(sums + 2 * b, (double)N * C, mean, rstd);
+    for (int n = blockIdx.x * WPB + w; n < N; n += gridDim.x * WPB) {
+        const long base = ((long)b * N + n) * ld;
+        for (int c0 = lane * 8; c0 < ld; c0 += 512) {
+            float yv[8], xv[8], o[8];
+            ld8<T>(Y + base + c0, yv); ld8<T>(X + base + c0, xv);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int c = c0 + e;
+                o[e] = (c < C) ? fmaxf(xv[e] + (yv[e] - mean) * rstd * gamma[c] + beta[c], 0.f) : 0.f;
+            }
+            st8<T>(G + base + c0, o);
+        }
+    }
+}
+
+// pass 1 of the LN backward: dxh = dG*[G>0]*gamma (written to dY), sample sums of dxh and dxh*xhat,
+// dgamma += dZ*xhat, dbeta += dZ; dX (+)= dZ
+template <typename T>
+__global__ __launch_bounds__(256) void gconv_pre_bwd1_kernel(const T* __restrict__ dG, const T* __restrict__ G, const T* __restrict__ Y,
+                                                            const double* __restrict__ sums, const float* __restrict__ gamma,
+                                                            T* __restrict__ dX, int accumulate_dX, T* __restrict__ dY,
+                                                            float* dgamma, float* dbeta, double* bsums, int N, int ld, int C) {
+    extern __shared__ float lds[];
+    __shared__ double red[2][WPB];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, b = blockIdx.y;
+    float mean, rstd;
+    ln_stats(sums + 2 * b, (double)N * C, mean, rstd);
+    float ag[MAXBLK][8], ab[MAXBLK][8];
+#pragma unroll
+    for (int k = 0; k < MAXBLK; ++k)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { ag[k][e] = 0.f; ab[k][e] = 0.f; }
+    double s1 = 0.0, s2 = 0.0;
+    for (int n = blockIdx.x * WPB + w; n < N; n += gridDim.x * WPB) {
+        const long base = ((long)b * N + n) * ld;
+        float a1 = 0.f, a2 = 0.f;
+#pragma unroll
+        for (int k = 0; k < MAXBLK; ++k) {
+            const int c0 = k * 512 + lane * 8;
+            if (c0 < ld) {
+                float g[8], gv[8], yv[8], o[8], dxo[8];
+                ld8<T>(dG + base + c0, g); ld8<T>(G + base + c0, gv); ld8<T>(Y + base + c0, yv);
+                if (accumulate_dX) ld8<T>(dX + base + c0, dxo);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const int c = c0 + e;
+                    const float dz = (c < C && gv[e] > 0.f) ? g[e] : 0.f;
+                    const float xh = (yv[e] - mean) * rstd;
+                    const float dxh = (c < C) ? dz * gamma[c] : 0.f;
+                    ag[k][e] += dz * xh; ab[k][e] += dz;
+                    a1 += dxh; a2 += dxh * xh;
+                    o[e] = dxh;
+                    dxo[e] = accumulate_dX ? dxo[e] + dz : dz;
+                }
+                st8<T>(dY + base + c0, o);
+                st8<T>(dX + base + c0, dxo);
+            }
+        }
+        s1 += (double)a1; s2 += (double)a2;
+    }
+    s1 = wave_sum_d(s1); s2 = wave_sum_d(s2);
+    if (lane == 0) { red[0][w] = s1; red[1][w] = s2; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        atomicAdd(bsums + 2 * b, red[0][0] + red[0][1] + red[0][2] + red[0][3]);
+        atomicAdd(bsums + 2 * b + 1, red[1][0] + red[1][1] + red[1][2] + red[1][3]);
+    }
+    colsum_flush(ag, dgamma, ld, C, lds);
+    colsum_flush(ab, dbeta, ld, C, lds);
+}
+
+// pass 2: dY = rstd * (dxh - mean(dxh) - xhat * mean(dxh*xhat))   (in place on dY; xsrc = pre-LN input)
+template <typename T>
+__global__ __launch_bounds__(256) void ln_bwd2_kernel(T* __restrict__ dY, const T* __restrict__ xsrc, const double* __restrict__ sums,
+                                                     const double* __restrict__ bsums, int N, int ld, int C) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, b = blockIdx.y;
+    float mean, rstd;
+    const double cnt = (double)N * C;
+    ln_stats(sums + 2 * b, cnt, mean, rstd);
+    const float m1 = (float)(bsums[2 * b] / cnt), m2 = (float)(bsums[2 * b + 1] / cnt);
+    for (int n = blockIdx.x * WPB + w; n < N; n += gridDim.x * WPB) {
+        const long base = ((long)b * N + n) * ld;
+        for (int c0 = lane * 8; c0 < ld; c0 += 512) {
+            float d[8], xv[8];
+            ld8<T>(dY + base + c0, d); ld8<T>(xsrc + base + c0, xv);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float xh = (xv[e] - mean) * rstd;
+                d[e] = (c0 + e < C) ? rstd * (d[e] - m1 - xh * m2) : 0.f;
+            }
+            st8<T>(dY + base + c0, d);
+        }
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void gconv_post_fwd_kernel(const T* __restrict__ U, const double* __restrict__ sums,
+                                                            const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                            T* __restrict__ out, float* __restrict__ rstd_row, int N, int ld, int C) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, b = blockIdx.y;
+    float mean, rstd;
+    ln_stats(sums + 2 * b, (double)N * C, mean, rstd);
+    for (int n = blockIdx.x * WPB + w; n < N; n += gridDim.x * WPB) {
+        const long base = ((long)b * N + n) * ld;
+        float hv[MAXBLK][8];
+        float ss = 0.f;
+#pragma unroll
+        for (int k = 0; k < MAXBLK; ++k) {
+            const int c0 = k * 512 + lane * 8;
+            if (c0 < ld) {
+                float uv[8];
+                ld8<T>(U + base + c0, uv);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const int c = c0 + e;
+                    const float h = (c < C) ? fmaxf((uv[e] - mean) * rstd * gamma[c] + beta[c], 0.f) : 0.f;
+                    hv[k][e] = h; ss += h * h;
+                }
+            }
+        }
+        ss = wave_sum(ss);
+        const bool clamped = ss < 1e-12f;
+        const float rs = rsqrtf(fmaxf(ss, 1e-12f));
+#pragma unroll
+        for (int k = 0; k < MAXBLK; ++k) {
+            const int c0 = k * 512 + lane * 8;
+            if (c0 < ld) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) hv[k][e] *= rs;
+                st8<T>(out + base + c0, hv[k]);
+            }
+        }
+        if (lane == 0) rstd_row[(long)b * N + n] = clamped ? -rs : rs;
+    }
+}
+
+// pass 1: dH = l2norm-bwd(dout), dUn = dH*[out>0], dxh = dUn*gamma -> dU; sums; dgamma/dbeta
+template <typename T>
+__global__ __launch_bounds__(256) void gconv_post_bwd1_kernel(const T* __restrict__ dout, const T* __restrict__ out, const float* __restrict__ rstd_row,
+                                                             const T* __restrict__ U, const double* __restrict__ sums, const float* __restrict__ gamma,
+                                                             T* __restrict__ dU, float* dgamma, float* dbeta, double* bsums, int N, int ld, int C) {
+    extern __shared__ float lds[];
+    __shared__ double red[2][WPB];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, b = blockIdx.y;
+    float mean, rstd;
+    ln_stats(sums + 2 * b, (double)N * C, mean, rstd);
+    float ag[MAXBLK][8], ab[MAXBLK][8];
+#pragma unroll
+    for (int k = 0; k < MAXBLK; ++k)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { ag[k][e] = 0.f; ab[k][e] = 0.f; }
+    double s1 = 0.0, s2 = 0.0;
+    for (int n = blockIdx.x * WPB + w; n < N; n += gridDim.x * WPB) {
+        const long base = ((long)b * N + n) * ld;
+        float g[MAXBLK][8], ov[MAXBLK][8];
+        float dot = 0.f;
+#pragma unroll
+        for (int k = 0; k < MAXBLK; ++k) {
+            const int c0 = k * 512 + lane * 8;
+            if (c0 < ld) {
+                ld8<T>(dout + base + c0, g[k]); ld8<T>(out + base + c0, ov[k]);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { if (c0 + e >= C) g[k][e] = 0.f; dot += g[k][e] * ov[k][e]; }
+            }
+        }
+        dot = wave_sum(dot);
+        const float rs = rstd_row[(long)b * N + n];
+        const float a = fabsf(rs);
+        if (rs < 0.f) dot = 0.f;
+        float a1 = 0.f, a2 = 0.f;
+#pragma unroll
+        for (int k = 0; k < MAXBLK; ++k) {
+            const int c0 = k * 512 + lane * 8;
+            if (c0 < ld) {
+                float uv[8], o[8];
+                ld8<T>(U + base + c0, uv);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const int c = c0 + e;
+                    const float dh = a * (g[k][e] - ov[k][e] * dot);
+                    const float dz = (c < C && ov[k][e] > 0.f) ? dh : 0.f;
+                    const float xh = (uv[e] - mean) * rstd;
+                    const float dxh = (c < C) ? dz * gamma[c] : 0.f;
+                    ag[k][e] += dz * xh; ab[k][e] += dz;
+                    a1 += dxh; a2 += dxh * xh;
+                    o[e] = dxh;
+                }
+                st8<T>(dU + base + c0, o);
+            }
+        }
+        s1 += (double)a1; s2 += (double)a2;
+    }
+    s1 = wave_sum_d(s1); s2 = wave_sum_d(s2);
+    if (lane == 0) { red[0][w] = s1; red[1][w] = s2; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        atomicAdd(bsums + 2 * b, red[0][0] + red[0][1] + red[0][2] + red[0][3]);
+        atomicAdd(bsums + 2 * b + 1, red[1][0] + red[1][1] + red[1][2] + red[1][3]);
+    }
+    colsum_flush(ag, dgamma, ld, C, lds);
+    colsum_flush(ab, dbeta, ld, C, lds);
+}
+
+bool map_ok(const char* what, int ld, int C, int dt) {
+    if (ld <= 0 || C <= 0 || C > ld || ld % 8 || ld > MAXBLK * 512) {
+        cmpc_set_error("%s: need 0 < C <= ld <= %d, ld %% 8 == 0 (got C=%d ld=%d)", what, MAXBLK * 512, C, ld);
+        return false;
+    }
+    if (dt != DT_F32 && dt != DT_BF16) { cmpc_set_error("%s: bad dtype %d", what, dt); return false; }
+    return true;
+}
+
+}  // namespace
+
+#define ST ((hipStream_t)stream)
+
+extern "C" int cmpc_cast(int src_dt, const void* src, int dst_dt, void* dst, int64_t n, void* stream) {
+    if (n <= 0) return CMPC_OK;
+    const int g = (int)((n + 255) / 256 > 4096 ? 4096 : (n + 255) / 256);
+    if (src_dt == DT_F32 && dst_dt == DT_BF16) hipLaunchKernelGGL((cast_kernel<float, bf16_t>), dim3(g), dim3(256), 0, ST, (const float*)src, (bf16_t*)dst, (long)n);
+    else if (src_dt == DT_BF16 && dst_dt == DT_F32) hipLaunchKernelGGL((cast_kernel<bf16_t, float>), dim3(g), dim3(256), 0, ST, (const bf16_t*)src, (float*)dst, (long)n);
+    else if (src_dt == DT_F32 && dst_dt == DT_F32) hipLaunchKernelGGL((cast_kernel<float, float>), dim3(g), dim3(256), 0, ST, (const float*)src, (float*)dst, (long)n);
+    else if (src_dt == DT_BF16 && dst_dt == DT_BF16) hipLaunchKernelGGL((cast_kernel<bf16_t, bf16_t>), dim3(g), dim3(256), 0, ST, (const bf16_t*)src, (bf16_t*)dst, (long)n);
+    else { cmpc_set_error("cast: bad dtypes"); return CMPC_EINVAL; }
+    return cmpc_check_launch("cast");
+}
+
+extern "C" int cmpc_axpy(int dt, const void* x, void* y, float a, int64_t n, void* stream) {
+    if (n % 8) { cmpc_set_error("axpy: n must be a multiple of 8"); return CMPC_EINVAL; }
+    if (n == 0) return CMPC_OK;
+    const long n8 = n / 8;
+    const int g = (int)((n8 + 255) / 256 > 4096 ? 4096 : (n8 + 255) / 256);
+    CMPC_DISPATCH_DT(dt, hipLaunchKernelGGL((axpy_kernel<T>), dim3(g), dim3(256), 0, ST, (const T*)x, (T*)y, a, n8));
+    return cmpc_check_launch("axpy");
+}
+
+extern "C" int cmpc_act_bwd(int dt, const void* dy, const void* y, void* dpre, int act, int R, int stride, int ld, int C,
+                            float* db, float* dsb, int ld_dsb, int rows_per_sample, void* stream) {
+    if (!map_ok("act_bwd", ld, C, dt)) return CMPC_EINVAL;
+    if (stride < ld || stride % 8) { cmpc_set_error("act_bwd: stride must be >= ld and a multiple of 8"); return CMPC_EINVAL; }
+    int N = R, B = 1;
+    if (dsb) { if (rows_per_sample <= 0 || R % rows_per_sample) { cmpc_set_error("act_bwd: bad rows_per_sample"); return CMPC_EINVAL; } N = rows_per_sample; B = R / N; }
+    if (R == 0) return CMPC_OK;
+    const int gx = dsb ? rows_grid(N) : ((R + 3) / 4 > 256 ? 256 : (R + 3) / 4);
+    CMPC_DISPATCH_DT(dt, hipLaunchKernelGGL((act_bwd_kernel<T>), dim3(gx, B), dim3(256), WPB * ld * sizeof(float), ST,
+                                             (const T*)dy, (const T*)y, (T*)dpre, act, N, stride, ld, C, db, dsb, ld_dsb));
+    return cmpc_check_launch("act_bwd");
+}
+
+extern "C" int cmpc_wcolsum(int dt, const void* x, const float* w, float* out, int ld_out, int B, int N, int ld, int C, float scale, void* stream) {
+    if (!map_ok("wcolsum", ld, C, dt)) return CMPC_EINVAL;
+    CMPC_DISPATCH_DT(dt, hipLaunchKernelGGL((wcolsum_kernel<T>), dim3(rows_grid(N) > 32 ? 32 : rows_grid(N), B), dim3(256), WPB * ld * sizeof(float), ST,
+                                             (const T*)x, w, out, ld_out, N, ld, C, scale));
+    return cmpc_check_launch("wcolsum");
+}
+
+extern "C" int cmpc_rowdot1(int dt, const void* x, const float* v, int ld_v, float* s, int B, int N, int ld, int C, float scale, void* stream) {
+    if (!map_ok("rowdot1", ld, C, dt)) return CMPC_EINVAL;
+    CMPC_DISPATCH_DT(dt, hipLaunchKernelGGL((rowdot1_kernel<T>), dim3(rows_grid(N), B), dim3(256), 0, ST, (const T*)x, v, ld_v, s, N, ld, C, scale));
+    return cmpc_check_launch("rowdot1");
+}
+
+extern "C" int cmpc_rank1_update(int dt, void* x, const float* w1, const float* v1, const float* w2, const float* v2,
+                                 int ld_v, float s1, float s2, int B, int N, int ld, int C, void* stream) {
+    if (!map_ok("rank1_update", ld, C, dt)) return CMPC_EINVAL;
+    CMPC_DISPATCH_DT(dt, hipLaunchKernelGGL((rank1_kernel<T>), dim3(rows_grid(N), B), dim3(256), 0, ST, (T*)x, w1, v1, w2, v2, ld_v, s1, s2, N, ld, C));
+    return cmpc_check_launch("rank1_update");
+}
+
+extern "C" int cmpc_l2norm_rows_fwd(int dt, const void* x, void* y, float* rstd, float* nz_mask, int R, int ld, int C, void* stream) {
+    if (!map_ok("l2norm_rows_fwd", ld, C, dt)) return CMPC_EINVAL;
+    if (R == 0) return CMPC_OK;
+    const int g = (R + 3) / 4 > 2048 ? 2048 : (R + 3) / 4;
+    CMPC_DISPATCH_DT(dt, hipLaunchKernelGGL((l2norm_fwd_kernel<T>), dim3(g), dim3(256), 0, ST, (const T*)x, (T*)y, rstd, nz_mask, R, ld, C));
+    return cmpc_check_launch("l2norm_rows_fwd");
+}
+
+extern "C" int cmpc_l2norm_rows_bwd(int dt, const void* dy, const void* y, const float* rstd, void* dx, int R, int ld, int C, int accumulate, void* stream) {
+    if (!map_ok("l2norm_rows_bwd", ld, C, dt)) return CMPC_EINVAL;
+    if (R == 0) return CMPC_OK;
+    const int g = (R + 3) / 4 > 2048 ? 2048 : (R + 3) / 4;
+    CMPC_DISPATCH_DT(dt, hipLaunchKernelGGL((l2norm_bwd_kernel<T>), dim3(g), dim3(256), 0, ST, (const T*)dy, (const T*)y, rstd, (T*)dx, R, ld, C, accumulate));
+    return cmpc_check_launch("l2norm_rows_bwd");
+}
+
+extern "C" int cmpc_sample_stats(int dt, const void* x, double* sums, int B, int N, int ld, int C, void* stream) {
+    if (ld <= 0 || C > ld || ld % 8) { cmpc_set_error("sample_stats: bad ld/C"); return CMPC_EINVAL; }
+    if (hipMemsetAsync(sums, 0, sizeof(double) * 2 * B, ST) != hipSuccess) { cmpc_set_error("sample_stats: memset failed"); return CMPC_EHIP; }
+    CMPC_DISPATCH_DT(dt, hipLaunchKernelGGL((sample_stats_kernel<T>), dim3(rows_grid(N), B), dim3(256), 0, ST, (const T*)x, sums, N, ld, C));
+    return cmpc_check_launch("sample_stats");
+}
+
+extern "C" int cmpc_gconv_pre_fwd(int dt, const void* Y, const void* X, const double* sums, const float* gamma, const float* beta,
+                                  void* G, int B, int N, int ld, int C, void* stream) {
+    if (!map_ok("gconv_pre_fwd", ld, C, dt)) return CMPC_EINVAL;
+    CMPC_DISPATCH_DT(dt, hipLaunchKernelGGL((gconv_pre_fwd_kernel<T>), dim3(rows_grid(N), B), dim3(256), 0, ST,
+                                             (const T*)Y, (const T*)X, sums, gamma, beta, (T*)G, N, ld, C));
+    return cmpc_check_launch("gconv_pre_fwd");
+}
+
+extern "C" int cmpc_gconv_pre_bwd(int dt, const void* dG, const void* G, const void* Y, const double* sums, const float* gamma,
+                                  void* dX, int accumulate_dX, void* dY, float* dgamma, float* dbeta, double* bsums,
+                                  int B, int N, int ld, int C, void* stream) {
+    if (!map_ok("gconv_pre_bwd", ld, C, dt)) return CMPC_EINVAL;
+    if (hipMemsetAsync(bsums, 0, sizeof(double) * 2 * B, ST) != hipSuccess) { cmpc_set_error("gconv_pre_bwd: memset failed"); return CMPC_EHIP; }
+    CMPC_DISPATCH_DT(dt, {
+        hipLaunchKernelGGL((gconv_pre_bwd1_kernel<T>), dim3(rows_grid(N) > 32 ? 32 : rows_grid(N), B), dim3(256), WPB * ld * sizeof(float), ST,
+                           (const T*)dG, (const T*)G, (const T*)Y, sums, gamma, (T*)dX, accumulate_dX, (T*)dY, dgamma, dbeta, bsums, N, ld, C);
+        hipLaunchKernelGGL((ln_bwd2_kernel<T>), dim3(rows_grid(N), B), dim3(256), 0, ST, (T*)dY, (const T*)Y, sums, bsums, N, ld, C);
+    });
+    return cmpc_check_launch("gconv_pre_bwd");
+}
+
+extern "C" int cmpc_gconv_post_fwd(int dt, const void* U, const double* sums, const float* gamma, const float* beta,
+                                   void* out, float* rstd_row, int B, int N, int ld, int C, void* stream) {
+    if (!map_ok("gconv_post_fwd", ld, C, dt)) return CMPC_EINVAL;
+    CMPC_DISPATCH_DT(dt, hipLaunchKernelGGL((gconv_post_fwd_kernel<T>), dim3(rows_grid(N), B), dim3(256), 0, ST,
+                                             (const T*)U, sums, gamma, beta, (T*)out, rstd_row, N, ld, C));
+    return cmpc_check_launch("gconv_post_fwd");
+}
+
+extern "C" int cmpc_gconv_post_bwd(int dt, const void* dout, const void* out, const float* rstd_row, const void* U,
+                                   const double* sums, const float* gamma, void* dU, float* dgamma, float* dbeta, double* bsums,
+                                   int B, int N, int ld, int C, void* stream) {
+    if (!map_ok("gconv_post_bwd", ld, C, dt)) return CMPC_EINVAL;
+    if (hipMemsetAsync(bsums, 0, sizeof(double) * 2 * B, ST) != hipSuccess) { cmpc_set_error("gconv_post_bwd: memset failed"); return CMPC_EHIP; }
+    CMPC_DISPATCH_DT(dt, {
+        hipLaunchKernelGGL((gconv_post_bwd1_kernel<T>), dim3(rows_grid(N) > 32 ? 32 : rows_grid(N), B), dim3(256), WPB * ld * sizeof(float), ST,
+                           (const T*)dout, (const T*)out, rstd_row, (const T*)U, sums, gamma, (T*)dU, dgamma, dbeta, bsums, N, ld, C);
+        hipLaunchKernelGGL((ln_bwd2_kernel<T>), dim3(rows_grid(N), B), dim3(256), 0, ST, (T*)dU, (const T*)U, sums, bsums, N, ld, C);
+    });
+    return cmpc_check_launch("gconv_post_bwd");
+}

@@ -1,0 +1,239 @@
+// Score heads: 3x3 SAME convolution M->1, legacy tf.image.resize_bilinear, sigmoid, weighed
+// logistic loss and the in-graph mIoU counters (reference CMPC_model.py:128-142,440-447,486-490;
+// util/loss.py:6-16).  Everything here is fp32 (parity-critical) except the feature map read.
+#include "cmpc_common.h"
+#include "../../include/cmpc.h"
+
+namespace {
+
+constexpr int WPB = 4;
+constexpr int MB = 2;
+
+template <typename T>
+__global__ __launch_bounds__(256) void score_conv_fwd_kernel(const T* __restrict__ feat, const float* __restrict__ Wk, const float* __restrict__ bias,
+                                                            float* __restrict__ score, int B, int h, int w, int ld, int M) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int total = B * h * w;
+    for (int p = blockIdx.x * WPB + wv; p < total; p += gridDim.x * WPB) {
+        const int b = p / (h * w), y = (p / w) % h, x = p % w;
+        float acc = 0.f;
+        for (int dy = -1; dy <= 1; ++dy) {
+            const int yy = y + dy;
+            if (yy < 0 || yy >= h) continue;
+            for (int dx = -1; dx <= 1; ++dx) {
+                const int xx = x + dx;
+                if (xx < 0 || xx >= w) continue;
+                const T* f = feat + ((long)(b * h + yy) * w + xx) * ld;
+                const float* wk = Wk + ((dy + 1) * 3 + (dx + 1)) * M;
+                for (int c0 = lane * 8; c0 < ld; c0 += 512) {
+                    float v[8];
+                    ld8<T>(f + c0, v);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) if (c0 + e < M) acc += v[e] * wk[c0 + e];
+                }
+            }
+        }
+        acc = wave_sum(acc);
+        if (lane == 0) score[p] = acc + bias[0];
+    }
+}
+
+// dfeat[b,y,x,:] (+)= sum_taps dscore[b, y-dy, x-dx] * W[tap,:]
+template <typename T>
+__global__ __launch_bounds__(256) void score_conv_bwd_data_kernel(const float* __restrict__ dscore, const float* __restrict__ Wk, T* __restrict__ dfeat,
+                                                                 int accumulate, int B, int h, int w, int ld, int M) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int total = B * h * w;
+    for (int p = blockIdx.x * WPB + wv; p < total; p += gridDim.x * WPB) {
+        const int b = p / (h * w), y = (p / w) % h, x = p % w;
+        float ds[9];
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const int dy = t / 3 - 1, dx = t % 3 - 1, yy = y - dy, xx = x - dx;
+            ds[t] = (yy >= 0 && yy < h && xx >= 0 && xx < w) ? dscore[(b * h + yy) * w + xx] : 0.f;
+        }
+        T* d = dfeat + (long)p * ld;
+        for (int c0 = lane * 8; c0 < ld; c0 += 512) {
+            float o[8];
+            if (accumulate) ld8<T>(d + c0, o);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                float v = 0.f;
+                if (c0 + e < M) {
+#pragma unroll
+                    for (int t = 0; t < 9; ++t) v += ds[t] * Wk[t * M + c0 + e];
+                }
+                o[e] = accumulate ? o[e] + v : v;
+            }
+            st8<T>(d + c0, o);
+        }
+    }
+}
+
+// dW[tap,m] += sum_pixels dscore[b, y-dy, x-dx] * feat[b,y,x,m];  dbias += sum dscore
+template <typename T>
+__global__ __launch_bounds__(256) void score_conv_bwd_w_kernel(const float* __restrict__ dscore, const T* __restrict__ feat, float* dWk, float* dbias,
+                                                              int B, int h, int w, int ld, int M) {
+    extern __shared__ float lds[];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int total = B * h * w;
+    float acc[9][MB][8];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int k = 0; k < MB; ++k)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc[t][k][e] = 0.f;
+    float sb = 0.f;
+    for (int p = blockIdx.x * WPB + wv; p < total; p += gridDim.x * WPB) {
+        const int b = p / (h * w), y = (p / w) % h, x = p % w;
+        float ds[9];
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const int dy = t / 3 - 1, dx = t % 3 - 1, yy = y - dy, xx = x - dx;
+            ds[t] = (yy >= 0 && yy < h && xx >= 0 && xx < w) ? dscore[(b * h + yy) * w + xx] : 0.f;
+        }
+        sb += dscore[p];
+        const T* f = feat + (long)p * ld;
+#pragma unroll
+        for (int k = 0; k < MB; ++k) {
+            const int c0 = k * 512 + lane * 8;
+            if (c0 < ld) {
+                float v[8];
+                ld8<T>(f + c0, v);
+#pragma unroll
+                for (int t = 0; t < 9; ++t)
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) acc[t][k][e] += ds[t] * v[e];
+            }
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < MB; ++k) {
+            const int c0 = k * 512 + lane * 8;
+            if (c0 < ld) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) lds[wv * ld + c0 + e] = acc[t][k][e];
+            }
+        }
+        __syncthreads();
+        for (int c = threadIdx.x; c < M; c += 256) {
+            const float s = lds[c] + lds[ld + c] + lds[2 * ld + c] + lds[3 * ld + c];
+            if (s != 0.f) atomicAdd(dWk + t * M + c, s);
+        }
+    }
+    if (lane == 0 && sb != 0.f) atomicAdd(dbias, sb);
+}
+
+// tf.image.resize_bilinear (align_corners=False, legacy): in = out_idx * (in_size / out_size) in
+// float32; lo = floor(in); hi = min(lo + 1, in_size - 1); lerp = in - lo.
+__device__ __forceinline__ void interp_coef(int o, float scale, int n_in, int& lo, int& hi, float& lerp) {
+    const float in = (float)o * scale;
+    lo = (int)floorf(in);
+    hi = min(lo + 1, n_in - 1);
+    lerp = in - (float)lo;
+}
+
+__global__ __launch_bounds__(256) void upsample_fwd_kernel(const float* __restrict__ score, float* __restrict__ up, float* __restrict__ sigm,
+                                                          const float* __restrict__ target, float* loss, int* inter, int* uni,
+                                                          int h, int w, int H, int W) {
+    __shared__ float red[4];
+    const int b = blockIdx.y;
+    const float sy = (float)h / (float)H, sx = (float)w / (float)W;
+    const float* s = score + (long)b * h * w;
+    float ls = 0.f; int ci = 0, cu = 0;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < H * W; i += gridDim.x * 256) {
+        const int Y = i / W, X = i % W;
+        int y0, y1, x0, x1; float fy, fx;
+        interp_coef(Y, sy, h, y0, y1, fy);
+        interp_coef(X, sx, w, x0, x1, fx);
+        const float tl = s[y0 * w + x0], tr = s[y0 * w + x1], bl = s[y1 * w + x0], br = s[y1 * w + x1];
+        const float top = tl + (tr - tl) * fx;
+        const float bot = bl + (br - bl) * fx;
+        const float u = top + (bot - top) * fy;
+        const long o = (long)b * H * W + i;
+        up[o] = u;
+        if (sigm) sigm[o] = 1.0f / (1.0f + expf(-u));
+        if (target) {
+            const float z = target[o];
+            ls += fmaxf(u, 0.f) - u * z + log1pf(expf(-fabsf(u)));     // sigmoid_cross_entropy_with_logits
+            const bool pr = u > 0.f, gt = z != 0.f;
+            ci += (pr && gt) ? 1 : 0; cu += (pr || gt) ? 1 : 0;
+        }
+    }
+    if (target) {
+        ls = block_sum_256(ls, red);
+        const float fi = block_sum_256((float)ci, red);
+        const float fu = block_sum_256((float)cu, red);
+        if (threadIdx.x == 0) { atomicAdd(loss + b, ls); atomicAdd(inter + b, (int)(fi + 0.5f)); atomicAdd(uni + b, (int)(fu + 0.5f)); }
+    }
+}
+
+__global__ __launch_bounds__(256) void upsample_loss_bwd_kernel(const float* __restrict__ up, const float* __restrict__ target, float* __restrict__ dscore,
+                                                               float wscale, int B, int h, int w, int H, int W) {
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    if (p >= B * h * w) return;
+    const int b = p / (h * w), y = (p / w) % h, x = p % w;
+    const float sy = (float)h / (float)H, sx = (float)w / (float)W;
+    const int Ylo = max(0, (int)floorf((float)(y - 1) / sy) - 1), Yhi = min(H - 1, (int)ceilf((float)(y + 1) / sy) + 1);
+    const int Xlo = max(0, (int)floorf((float)(x - 1) / sx) - 1), Xhi = min(W - 1, (int)ceilf((float)(x + 1) / sx) + 1);
+    float acc = 0.f;
+    for (int Y = Ylo; Y <= Yhi; ++Y) {
+        int y0, y1; float fy;
+        interp_coef(Y, sy, h, y0, y1, fy);
+        const float wy = (y0 == y ? 1.f - fy : 0.f) + (y1 == y ? fy : 0.f);
+        if (wy == 0.f) continue;
+        for (int X = Xlo; X <= Xhi; ++X) {
+            int x0, x1; float fx;
+            interp_coef(X, sx, w, x0, x1, fx);
+            const float wx = (x0 == x ? 1.f - fx : 0.f) + (x1 == x ? fx : 0.f);
+            if (wx == 0.f) continue;
+            const long o = ((long)b * H + Y) * W + X;
+            const float u = up[o];
+            const float d = 1.0f / (1.0f + expf(-u)) - target[o];
+            acc += wy * wx * d;
+        }
+    }
+    dscore[p] = acc * wscale;
+}
+
+}  // namespace
+
+#define ST ((hipStream_t)stream)
+
+extern "C" int cmpc_score_conv_fwd(int dt, const void* feat, const float* Wk, const float* bias, float* score,
+                                   int B, int h, int w, int ld, int M, void* stream) {
+    if (ld % 8 || M > ld || ld > MB * 512) { cmpc_set_error("score_conv_fwd: bad ld/M"); return CMPC_EINVAL; }
+    const int total = B * h * w, g = (total + 3) / 4 > 2048 ? 2048 : (total + 3) / 4;
+    CMPC_DISPATCH_DT(dt, hipLaunchKernelGGL((score_conv_fwd_kernel<T>), dim3(g), dim3(256), 0, ST, (const T*)feat, Wk, bias, score, B, h, w, ld, M));
+    return cmpc_check_launch("score_conv_fwd");
+}
+
+extern "C" int cmpc_score_conv_bwd(int dt, const float* dscore, const void* feat, const float* Wk, void* dfeat, int accumulate,
+                                   float* dWk, float* dbias, int B, int h, int w, int ld, int M, void* stream) {
+    if (ld % 8 || M > ld || ld > MB * 512) { cmpc_set_error("score_conv_bwd: bad ld/M"); return CMPC_EINVAL; }
+    const int total = B * h * w, g = (total + 3) / 4 > 2048 ? 2048 : (total + 3) / 4;
+    CMPC_DISPATCH_DT(dt, {
+        if (dfeat) hipLaunchKernelGGL((score_conv_bwd_data_kernel<T>), dim3(g), dim3(256), 0, ST, dscore, Wk, (T*)dfeat, accumulate, B, h, w, ld, M);
+        if (dWk) hipLaunchKernelGGL((score_conv_bwd_w_kernel<T>), dim3(g > 128 ? 128 : g), dim3(256), WPB * ld * sizeof(float), ST,
+                                    dscore, (const T*)feat, dWk, dbias, B, h, w, ld, M);
+    });
+    return cmpc_check_launch("score_conv_bwd");
+}
+
+extern "C" int cmpc_upsample_fwd(const float* score, float* up, float* sigm, const float* target, float* loss,
+                                 int* inter, int* uni, int B, int h, int w, int H, int W, void* stream) {
+    if (target && (!loss || !inter || !uni)) { cmpc_set_error("upsample_fwd: loss/inter/uni required with target"); return CMPC_EINVAL; }
+    const int gx = (H * W + 255) / 256 > 64 ? 64 : (H * W + 255) / 256;
+    hipLaunchKernelGGL(upsample_fwd_kernel, dim3(gx, B), dim3(256), 0, ST, score, up, sigm, target, loss, inter, uni, h, w, H, W);
+    return cmpc_check_launch("upsample_fwd");
+}
+
+extern "C" int cmpc_upsample_loss_bwd(const float* up, const float* target, float* dscore, float wscale,
+                                      int B, int h, int w, int H, int W, void* stream) {
+    hipLaunchKernelGGL(upsample_loss_bwd_kernel, dim3((B * h * w + 255) / 256), dim3(256), 0, ST, up, target, dscore, wscale, B, h, w, H, W);
+    return cmpc_check_launch("upsample_loss_bwd");
+}

@@ -1,0 +1,205 @@
+"""LSTM_model -- drop-in counterpart of the reference's CMPC_model.LSTM_model (CMPC_model.py:13-492).
+
+Same constructor keywords (CMPC_model.py:15-40), same feeds (words int32[B,T], im f32[B,H,W,3] BGR
+minus mean, target_fine f32[B,H,W,1], seq_len int32[B]; :67-71) and fetches (pred, up, sigm :140-142;
+up_c3/4/5 :129-133; words_parse :354; gw_w/gw_v :395,399; loss scalars and mIoU :481-491), driven as
+    sess.run([train, train_step, merged], feed)   ->  model.train_step(words, im, target_fine, seq_len)
+    sess.run([pred, up, sigm], feed)              ->  model.forward(words, im, seq_len)
+(trainval_model.py:98-107, test.py:286-296).  The head runs on the HIP kernels of libcmpc_hip.so; the
+frozen DeepLab-ResNet-101 backbone runs on PyTorch-ROCm.  There is no CPU fallback.
+"""
+from __future__ import annotations
+
+import os
+from typing import Dict, Optional
+
+import numpy as np
+import torch
+
+from . import _lib, backbone as bb, ops
+from ._lib import DT_BF16, DT_F32
+from .params import EXG, LEVELS, HeadCfg, ParamStore, init_head_params
+
+MU = (104.00698793, 116.66876762, 122.67891434)       # trainval_model.py:371
+
+
+class LSTM_model(object):
+    def __init__(self, batch_size=1, num_steps=20, vf_h=40, vf_w=40, H=320, W=320, vf_dim=2048,
+                 vocab_size=12112, w_emb_dim=1000, v_emb_dim=1000, mlp_dim=500, start_lr=0.00025,
+                 lr_decay_step=800000, lr_decay_rate=1.0, rnn_size=1000, keep_prob_rnn=1.0, keep_prob_emb=1.0,
+                 keep_prob_mlp=1.0, num_rnn_layers=1, optimizer='adam', weight_decay=0.0005, mode='eval',
+                 conv5=False, glove_dim=300, emb_name='Gref', emb_dir='data',
+                 # --- extensions (not in the reference signature) ---
+                 device="cuda:0", dtype="bf16", c4_dim=1024, c3_dim=512, parse_dim=500,
+                 backbone_width=64, backbone_blocks=(3, 4, 23, 3), head_params: Optional[Dict] = None,
+                 backbone_params: Optional[Dict] = None, seed=1234, **ignored):
+        # `ignored` swallows kwargs the reference driver passes but CMPC_model does not accept
+        # (freeze_bn, is_aug: trainval_model.py:40).
+        if optimizer != 'adam':
+            raise ValueError("Unknown optimizer type %s!" % optimizer)          # CMPC_model.py:458
+        if conv5:
+            raise NotImplementedError("conv5=True (backbone fine-tuning, CMPC_model.py:427-430) is out of scope")
+        if keep_prob_rnn != 1.0 or keep_prob_emb != 1.0 or keep_prob_mlp != 1.0 or num_rnn_layers != 1:
+            raise NotImplementedError("dropout / stacked LSTM are unused by the reference graph")
+        if dtype not in ("bf16", "f32"):
+            raise ValueError("dtype must be 'bf16' or 'f32'")
+        if not torch.cuda.is_available():
+            raise RuntimeError("LSTM_model needs an MI355X (gfx950): the CMPC head has no CPU path")
+        _lib.load()
+        self.mode, self.device = mode, torch.device(device)
+        self.dt = DT_BF16 if dtype == "bf16" else DT_F32
+        self.batch_size, self.num_steps, self.H, self.W = batch_size, num_steps, H, W
+        self.cfg = HeadCfg(batch_size=batch_size, num_steps=num_steps, vf_h=vf_h, vf_w=vf_w, H=H, W=W, vf_dim=vf_dim,
+                           c4_dim=c4_dim, c3_dim=c3_dim, vocab_size=vocab_size, v_emb_dim=v_emb_dim, mlp_dim=mlp_dim,
+                           rnn_size=rnn_size, glove_dim=glove_dim, parse_dim=parse_dim, start_lr=start_lr,
+                           lr_decay_step=lr_decay_step, weight_decay=weight_decay)
+        for name, v in (("vf_dim", vf_dim), ("c4_dim", c4_dim), ("c3_dim", c3_dim)):
+            if v % 64:
+                raise ValueError(f"{name}={v} must be a multiple of 64 (MFMA K tile)")
+        self.store = ParamStore(self.cfg, self.device, self.dt)
+        if head_params is None:
+            head_params = init_head_params(self.cfg, seed=seed)
+            path = '{}/{}_emb.npy'.format(emb_dir, emb_name)                     # CMPC_model.py:79
+            if os.path.exists(path):
+                glove = np.load(path)                                             # allow_pickle=False
+                head_params["text_objseg/Variable"] = torch.from_numpy(np.asarray(glove, dtype=np.float32))
+        self.store.load_state(head_params)
+        self.cx = ops.Ctx(self.cfg, self.store, self.dt)
+        self.backbone = bb.DeepLabResNet(backbone_width, backbone_blocks)
+        self.backbone.load_tf(backbone_params if backbone_params is not None else bb.init_params(backbone_width, backbone_blocks))
+        self.backbone = self.backbone.to(self.device).to(ops.tdt(self.dt)).to(memory_format=torch.channels_last).eval()
+        self.world = 1
+        self.last = {}
+
+    # ------------------------------------------------------------------------------------------
+    def _check_feeds(self, words, im, seq_len, target=None):
+        B, T, H, W = self.batch_size, self.num_steps, self.H, self.W
+        if tuple(words.shape) != (B, T):
+            raise ValueError(f"words must be [{B},{T}], got {tuple(words.shape)}")
+        if im is not None and tuple(im.shape) != (B, H, W, 3):
+            raise ValueError(f"im must be [{B},{H},{W},3], got {tuple(im.shape)}")
+        if tuple(seq_len.shape) != (B,):
+            raise ValueError(f"seq_len must be [{B}], got {tuple(seq_len.shape)}")
+        if target is not None and tuple(target.shape) != (B, H, W, 1):
+            raise ValueError(f"target_fine must be [{B},{H},{W},1], got {tuple(target.shape)}")
+
+    def _dev(self, x, dtype):
+        if not torch.is_tensor(x):
+            x = torch.as_tensor(np.asarray(x))
+        return x.to(self.device, dtype=dtype, non_blocking=True).contiguous()
+
+    def features(self, im):
+        """backbone taps (c3, c4, c5), NHWC, head dtype (CMPC_model.py:73-76)."""
+        return self.backbone(self._dev(im, torch.float32))
+
+    def head(self, feats, words, seq_len, target=None):
+        """build_graph() on given backbone taps (CMPC_model.py:89-142).  Returns the fetch dict."""
+        cfg, cx, O = self.cfg, self.cx, ops
+        B, T, N = cfg.batch_size, cfg.num_steps, cfg.N
+        c3, c4, c5 = [f.to(ops.tdt(self.dt)).contiguous() for f in feats]
+        words = self._dev(words, torch.int32).view(-1)
+        seq_len = self._dev(seq_len, torch.int32)
+        tgt = self._dev(target, torch.float32) if target is not None else None
+        a = cx.anchor
+        wf, mask = O.TextEncoder.apply(a, words, seq_len, cx)
+        parse = O.LangParser.apply(wf, mask, cx)
+        vl = O.LangPool.apply(parse, wf, 2, cx)                 # valid_lang: entity + attribute
+        out = {"words_feat": wf, "seq_mask": mask, "words_parse": parse}
+        fus, losses = {}, {}
+        for lv, f in (("c5", c5), ("c4", c4), ("c3", c3)):
+            X0 = O.Lateral.apply(a, f, lv, cx)
+            X1 = O.Mutan.apply(X0, vl, lv, cx)
+            X2, gw_w, gw_v = O.SpaGraph.apply(X1, wf, parse, mask, lv, cx)
+            fus[lv] = O.Fusion.apply(X1, X2, vl, lv, cx)
+            out[f"lat_{lv}"], out[f"vis_la_sp_{lv}"], out[f"spa_graph_{lv}"], out[f"fusion_{lv}"] = X0, X1, X2, fus[lv]
+            out[f"gw_w_{lv}"], out[f"gw_v_{lv}"] = gw_w, gw_v
+        for lv in LEVELS:
+            l, sc, up, _s, _iu = O.ScoreHead.apply(fus[lv], f"score_{lv}", tgt, 0.1, cx)
+            out[f"score_{lv}"], out[f"up_{lv}"], losses[lv] = sc, up, l
+        nec = O.LangPool.apply(parse, wf, 3, cx)                # nec_lang: entity + attribute + relation
+        out["nec_lang"] = nec
+        f3, f4, f5 = fus["c3"], fus["c4"], fus["c5"]
+        e3 = O.Exchange.apply(f3, f4, f5, nec, "c3", cx)
+        e4 = O.Exchange.apply(f4, f3, f5, nec, "c4", cx)
+        e5 = O.Exchange.apply(f5, f3, f4, nec, "c5", cx)
+        e32 = O.Exchange.apply(e3, e4, e5, nec, "c3_2", cx)
+        e42 = O.Exchange.apply(e4, e3, e5, nec, "c4_2", cx)
+        e52 = O.Exchange.apply(e5, e3, e4, nec, "c5_2", cx)
+        out.update(exg_c3=e3, exg_c4=e4, exg_c5=e5, exg_c3_2=e32, exg_c4_2=e42, exg_c5_2=e52)
+        fused = O.ConvLSTM.apply(e32, e42, e52, cx)
+        out["fused"] = fused
+        l, pred, up, sigm, iu = O.ScoreHead.apply(fused, "score", tgt, 0.7, cx)
+        out.update(pred=pred, up=up, sigm=sigm, iu=iu)
+        if tgt is not None:
+            # cls_loss_all = 0.7 L + 0.1 (L_c5 + L_c4 + L_c3), CMPC_model.py:444-445 (scalar bookkeeping only)
+            out["loss_last"], out["loss_c5"], out["loss_c4"], out["loss_c3"] = l.mean(), losses["c5"].mean(), losses["c4"].mean(), losses["c3"].mean()
+            out["loss_all"] = 0.7 * out["loss_last"] + 0.1 * out["loss_c5"] + 0.1 * out["loss_c4"] + 0.1 * out["loss_c3"]
+            out["mIoU"] = (iu[0].double() / iu[1].double()).mean()               # CMPC_model.py:486-490
+        return out
+
+    @torch.no_grad()
+    def forward(self, words, im, seq_len):
+        """sess.run([pred, up, sigm, ...], {words, im, seq_len}) (test.py:286-296)."""
+        self._check_feeds(words, im, seq_len)
+        o = self.head(self.features(im), words, seq_len)
+        B, h, w, H, W, T, N = self.batch_size, self.cfg.vf_h, self.cfg.vf_w, self.H, self.W, self.num_steps, self.cfg.N
+        res = {"pred": o["pred"], "up": o["up"], "sigm": o["sigm"],
+               "up_c3": o["up_c3"], "up_c4": o["up_c4"], "up_c5": o["up_c5"],
+               "words_parse": o["words_parse"].view(B, 1, T, 4),
+               # the reference keeps the attributes of the LAST level built, c3 (CMPC_model.py:395,399)
+               "gw_w": o["gw_w_c3"][:, :, :T], "gw_v": o["gw_v_c3"][:, :, :T]}
+        return res
+
+    def predict(self, images, sentences, sequence_lenghts):
+        """TF-serving signature of export_model_serving.py:57-71: images, sentences, sequence_lenghts -> masks."""
+        return self.forward(sentences, images, sequence_lenghts)["sigm"]
+
+    def loss_and_grads(self, feats, words, target_fine, seq_len):
+        """forward + backward of `cost` (CMPC_model.py:447) into the flat gradient buffer (L2 and the
+        x2 bias multiplier are applied inside the Adam kernel)."""
+        self.store.zero_grads()
+        o = self.head(feats, words, seq_len, target_fine)
+        o["loss_all"].backward()
+        return o
+
+    def train_step(self, words, im, target_fine, seq_len):
+        """sess.run([train, train_step, merged], feed) (trainval_model.py:98-107)."""
+        if self.mode != 'train':
+            raise RuntimeError("model was built with mode='eval' (CMPC_model.py:85-86)")
+        self._check_feeds(words, im, seq_len, target_fine)
+        feats = self.features(im)
+        o = self.loss_and_grads(feats, words, target_fine, seq_len)
+        gscale = 1.0
+        if self.world > 1:
+            torch.distributed.all_reduce(self.store.grads)       # RCCL over xGMI: one flat buffer
+            gscale = 1.0 / self.world
+        lr = self.store.adam_step(gscale)
+        scal = {k: o[k].detach() for k in ("loss_all", "loss_c3", "loss_c4", "loss_c5", "loss_last", "mIoU")}
+        scal["mean_IOU"] = scal.pop("mIoU")
+        scal["learning_rate"] = lr
+        self.last = scal
+        return self.store.step, scal
+
+    # ------------------------------------------------------------------------------------------
+    def state_dict(self):
+        return self.store.state_dict()
+
+    def load_weights(self, named: Dict[str, torch.Tensor]):
+        self.store.load_state(named)
+
+    def enable_data_parallel(self):
+        """One process per GPU; identical weights are assumed (same seed); gradients are summed with
+        one all-reduce of the flat buffer and divided by the world size in the Adam kernel."""
+        import torch.distributed as dist
+        self.world = dist.get_world_size() if dist.is_initialized() else 1
+        if self.world > 1:
+            dist.broadcast(self.store.params, 0)
+            self.store.pack()
+        return self.world
+
+
+def get_segmentation_model(name, **kwargs):
+    """get_model.get_segmentation_model (get_model.py:15-17): name -> <module>.LSTM_model(**kwargs)."""
+    if name not in ("CMPC_model",):
+        raise ValueError("only CMPC_model is built in this round (got %r)" % (name,))
+    return LSTM_model(**kwargs)

@@ -1,0 +1,217 @@
+/* cmpc.h -- C ABI of libcmpc_hip.so: the CMPC head (zigonk/CMPC-Refseg CMPC_model.build_graph /
+ * train_op) as hand-written HIP kernels for gfx950 (MI355X).
+ *
+ * The reference has no FFI: its only device boundary is sess.run(feed_dict) on a TF1 graph
+ * (trainval_model.py:98-107, test.py:286-296).  Each entry point below replaces one stage of
+ * that graph; the comment on each cites the reference lines (file:line under /root/reference)
+ * whose arithmetic it performs.  The Python facade cmpc-refseg_amd/model.py chains them behind
+ * LSTM_model's constructor / feed / fetch contract (CMPC_model.py:15-40,67-71,140-142).
+ *
+ * Conventions
+ *  - every pointer is a DEVICE pointer unless the name ends in _host; the caller owns all buffers
+ *  - `stream` is a hipStream_t passed as void*; all work is enqueued on it, nothing synchronises
+ *  - return value: 0 = ok, <0 = error (CMPC_EINVAL -1, CMPC_EHIP -2); cmpc_last_error() gives
+ *    the message; nothing throws across the ABI
+ *  - dt: 0 = float32, 1 = bfloat16 (storage of feature maps and GEMM operands); statistics,
+ *    accumulators, logits, losses and parameters are always float32 (sample sums: float64)
+ *  - a "map" is a row-major [R = B*N, ld] matrix, rows r = b*N + n (n = y*w + x, NHWC order of the
+ *    reference), C valid channels, ld >= C a multiple of 8; producers write pad columns as 0
+ *  - not re-entrant per stream; one process per GPU for data-parallel runs
+ */
+#ifndef CMPC_H
+#define CMPC_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+const char* cmpc_last_error(void);
+int cmpc_abi_version(void);
+
+/* ---- GEMMs: every _conv 1x1 (CMPC_model.py:412-417), tf.matmul (:173,187,226,235,362,384,400)
+ *      and tf.nn.convolution 1x1 (util/cell.py:43) ---------------------------------------- */
+typedef struct {
+    int dtype;                 /* operand dtype (A, Bt, and C unless c_f32) */
+    int nseg;                  /* 1..3 K-segments summed into one accumulator */
+    const void* A[3];          /* [M, K_s] row-major, lda[s] */
+    const void* Bt[3];         /* [N, K_s] row-major (the weight, output-channel major), ldb[s] */
+    int K[3], lda[3], ldb[3];
+    int64_t sA[3], sB[3];      /* batch strides in elements */
+    void* C; int ldc; int64_t sC;
+    int c_f32;                 /* 1: C is float32 regardless of dtype */
+    int M, N, n_valid, batch;  /* columns >= n_valid are written as 0 */
+    const float* bias;         /* [N] or NULL */
+    const float* sbias; int ld_sbias;   /* per-sample bias  sbias[(row/rows_per_sample)*ld + n] */
+    const float* pbias; int ld_pbias;   /* per-position bias pbias[(row%rows_per_sample)*ld + n] */
+    int rows_per_sample;
+    int act;                   /* 0 none, 1 relu, 2 tanh, 3 sigmoid */
+    float alpha;               /* scales the accumulator before the biases */
+    int accumulate;            /* C += result */
+} cmpc_gemm_nt_args;
+int cmpc_gemm_nt(const cmpc_gemm_nt_args* a, void* stream);
+
+typedef struct {
+    int dtype;
+    const void* A; int lda; int Ka;     /* [R, Ka] */
+    const void* D; int ldd; int Nd;     /* [R, Nd] */
+    float* out; int ldo;                /* out[k, n] += alpha * sum_r A[r,k] D[r,n]  (fp32 atomics) */
+    int R, Kv, Nv;                      /* reduction length, valid output rows / cols */
+    int nb; int64_t a_off[8], d_off[8], o_off[8];  /* inner batch: element offsets */
+    int nb2; int64_t a_bs, d_bs, o_bs;  /* outer batch: strides */
+    int rsplit;                         /* workgroups along the reduction */
+    float alpha;
+} cmpc_gemm_tn_args;
+int cmpc_gemm_tn(const cmpc_gemm_tn_args* a, void* stream);
+
+/* ---- utilities ---------------------------------------------------------------------------- */
+int cmpc_cast(int src_dt, const void* src, int dst_dt, void* dst, int64_t n, void* stream);
+/* act'(y) applied to a gradient, plus column sums:  dpre = dy * act'(y);  db[c] += sum_r dpre
+ * (bias gradients of _conv, CMPC_model.py:416-417); dsb[b][c] += per-sample sums (optional).
+ * dy / y / dpre are [R, ld] windows of matrices with row stride `stride`; y, dpre, db, dsb optional */
+int cmpc_act_bwd(int dt, const void* dy, const void* y, void* dpre, int act, int R, int stride, int ld, int C,
+                 float* db, float* dsb, int ld_dsb, int rows_per_sample, void* stream);
+/* out[b, :] (+)= sum_n w[b,n] * x[b,n,:]   and   s[b,n] = scale * x[b,n,:] . v[b,:] */
+int cmpc_wcolsum(int dt, const void* x, const float* w, float* out, int ld_out, int B, int N, int ld, int C,
+                 float scale, void* stream);
+int cmpc_rowdot1(int dt, const void* x, const float* v, int ld_v, float* s, int B, int N, int ld, int C,
+                 float scale, void* stream);
+/* x[b,n,:] += s1*w1[b,n]*v1[b,:] + s2*w2[b,n]*v2[b,:]  (w2/v2 optional) */
+int cmpc_rank1_update(int dt, void* x, const float* w1, const float* v1, const float* w2, const float* v2,
+                      int ld_v, float s1, float s2, int B, int N, int ld, int C, void* stream);
+/* y (+)= x elementwise on maps */
+int cmpc_axpy(int dt, const void* x, void* y, float a, int64_t n, void* stream);
+
+/* ---- tf.nn.l2_normalize(x, 3) (CMPC_model.py:109,111,113,272-284,324,408; eps 1e-12) ------- */
+int cmpc_l2norm_rows_fwd(int dt, const void* x, void* y, float* rstd, float* nz_mask, int R, int ld, int C, void* stream);
+int cmpc_l2norm_rows_bwd(int dt, const void* dy, const void* y, const float* rstd, void* dx, int R, int ld, int C,
+                         int accumulate, void* stream);
+
+/* ---- whole-sample statistics for tf.contrib.layers.layer_norm (CMPC_model.py:364,370;
+ *      util/cell.py:53-66): sums[b] = {sum x, sum x^2} over (n, c<C), float64 ---------------- */
+int cmpc_sample_stats(int dt, const void* x, double* sums, int B, int N, int ld, int C, void* stream);
+
+/* ---- mutan_fusion (CMPC_model.py:295-328): P [R, 5*ld] holds the five vis_trans pre-activations
+ *      (GEMM incl. spatial channels and bias); g [B, 5*ld] = tanh(lang_trans); on return P holds
+ *      tanh(P_h), X1 = l2norm(tanh(sum_h tanh(P_h) * g_h)) ------------------------------------ */
+int cmpc_mutan_fwd(int dt, void* P, const float* g, void* X1, float* rstd, int B, int N, int ld, int C, void* stream);
+/* in: Th (tanh values), dX1; out: Th overwritten by dP_h, dg[b][5*ld] += column sums */
+int cmpc_mutan_bwd(int dt, void* Th, const float* g, const void* X1, const float* rstd, const void* dX1,
+                   float* dg, int B, int N, int ld, int C, void* stream);
+
+/* ---- build_spa_graph softmaxes (CMPC_model.py:384-399): A0 [B,N,Tp] f32 = affinity/sqrt(C);
+ *      gw_w = softmax_T(mask*pr*A0 + (1-mask)*FLT_MIN), gw_v = softmax_N(pr*A0)*mask.
+ *      f32 copies are kept for backward, dt copies ([B,N,Tp], pad columns 0) feed the GEMMs -- */
+int cmpc_graph_softmax_fwd(int dt, const float* A0, const float* pr, const float* mask, float* gw_w, float* gw_v,
+                           void* gw_w_t, void* gw_v_t, int B, int N, int T, int Tp, void* stream);
+int cmpc_graph_softmax_bwd(int dt, const float* dgw_w, const float* dgw_v, const float* gw_w, const float* gw_v,
+                           const float* A0, const float* pr, const float* mask, float* dA0, void* dA0_t, float* dpr,
+                           int B, int N, int T, int Tp, void* stream);
+
+/* ---- graph_conv (CMPC_model.py:359-374) around the two GEMMs ------------------------------- */
+/* G = relu(X + LN(Y; gamma, beta)) */
+int cmpc_gconv_pre_fwd(int dt, const void* Y, const void* X, const double* sums, const float* gamma, const float* beta,
+                       void* G, int B, int N, int ld, int C, void* stream);
+/* dX (+)= dG*[G>0]; dY = LN-backward; dgamma/dbeta += ; bsums: scratch double[B][2] */
+int cmpc_gconv_pre_bwd(int dt, const void* dG, const void* G, const void* Y, const double* sums, const float* gamma,
+                       void* dX, int accumulate_dX, void* dY, float* dgamma, float* dbeta, double* bsums,
+                       int B, int N, int ld, int C, void* stream);
+/* out = l2norm(relu(LN(U; gamma, beta)))  (CMPC_model.py:370-372,408) */
+int cmpc_gconv_post_fwd(int dt, const void* U, const double* sums, const float* gamma, const float* beta,
+                        void* out, float* rstd_row, int B, int N, int ld, int C, void* stream);
+int cmpc_gconv_post_bwd(int dt, const void* dout, const void* out, const float* rstd_row, const void* U,
+                        const double* sums, const float* gamma, void* dU, float* dgamma, float* dbeta, double* bsums,
+                        int B, int N, int ld, int C, void* stream);
+
+/* ---- gated_exchange_module (CMPC_model.py:245-259) ---------------------------------------- */
+/* softmax over the N nodes of each sample (global_vec, :229) */
+int cmpc_softmax_n_fwd(const float* logits, float* attn, int B, int N, void* stream);
+int cmpc_softmax_n_bwd(const float* dattn, const float* attn, float* dlogits, int B, int N, void* stream);
+/* tf.nn.l2_normalize(gv_lang) with no axis -> over the whole [B, M] tensor (:241) */
+int cmpc_l2norm_all_fwd(const float* x, float* y, float* rstd1, int n, void* stream);
+int cmpc_l2norm_all_bwd(const float* dy, const float* y, const float* rstd1, float* dx, int n, void* stream);
+/* out = l2norm_rows(feat + r1*g1[b] + r2*g2[b])  (:256-258,272) */
+int cmpc_exchange_combine_fwd(int dt, const void* feat, const void* r1, const void* r2, const float* g1, const float* g2,
+                              int ld_g, void* out, float* rstd, int B, int N, int ld, int C, void* stream);
+/* dfeat (+)= dE; dp1 = dE*g1*[r1>0]; dp2 likewise; dg1/dg2 [B][ld_g] += sum_n dE*r  */
+int cmpc_exchange_combine_bwd(int dt, const void* dout, const void* out, const float* rstd, const void* r1, const void* r2,
+                              const float* g1, const float* g2, int ld_g, void* dfeat, int accumulate_dfeat,
+                              void* dp1, void* dp2, float* dg1, float* dg2, int B, int N, int ld, int C, void* stream);
+
+/* ---- ConvLSTMCell.call (util/cell.py:36-79), one time step; Yg [R, 4*ld] = [x|h].kernel with
+ *      gate blocks j,i,f,o; peepholes W_c* are [N, M] fp32 (row stride M); LayerNorm vectors
+ *      in the order j,i,f,o,c; sums / bsums are double[5][B][2] in the same order ------------ */
+typedef struct { const float* beta[5]; const float* gamma[5]; } cmpc_convlstm_ln;
+typedef struct { float* dbeta[5]; float* dgamma[5]; } cmpc_convlstm_dln;
+/* A: i += W_ci*c_prev, f += W_cf*c_prev (skipped when c_prev NULL); sums[j,i,f] <- stats */
+int cmpc_convlstm_a(int dt, void* Yg, const void* c_prev, const float* W_ci, const float* W_cf, double* sums,
+                    int B, int N, int ld, int M, void* stream);
+/* B: c_pre = c_prev*sig(LN f + 1) + sig(LN i)*tanh(LN j); o_pre = o + W_co*c_pre (in place);
+ *    sums[o] <- stats(o_pre), sums[c] <- stats(c_pre) */
+int cmpc_convlstm_b(int dt, void* Yg, const void* c_prev, const float* W_co, const cmpc_convlstm_ln* ln,
+                    double* sums, void* c_pre, int B, int N, int ld, int M, void* stream);
+/* C: c_new = LN(c_pre); h = sig(LN(o_pre)) * tanh(c_new) */
+int cmpc_convlstm_c(int dt, const void* Yg, const void* c_pre, const cmpc_convlstm_ln* ln, const double* sums,
+                    void* c_new, void* h, int B, int N, int ld, int M, void* stream);
+/* backward of C,B,A in three passes.  dYg [R,4*ld] receives d(pre-LN gate inputs = GEMM output);
+ * dc_prev the state gradient (untouched when c_prev NULL); LN / peephole gradients accumulate
+ * (atomics); scr [R, ld] dt scratch; bsums double[5][B][2] scratch */
+int cmpc_convlstm_bwd(int dt, const void* dh, const void* dc_new, const void* Yg, const void* c_prev, const void* c_pre,
+                      const float* W_ci, const float* W_cf, const float* W_co,
+                      const cmpc_convlstm_ln* ln, const double* sums, void* dYg, void* dc_prev,
+                      float* dW_ci, float* dW_cf, float* dW_co, const cmpc_convlstm_dln* dln, void* scr, double* bsums,
+                      int B, int N, int ld, int M, void* stream);
+
+/* ---- score heads, resize_bilinear, sigmoid, weighed_logistic_loss, mIoU
+ *      (CMPC_model.py:128-142,440-447,486-490; util/loss.py:6-16) -------------------------- */
+int cmpc_score_conv_fwd(int dt, const void* feat, const float* Wk, const float* bias, float* score,
+                        int B, int h, int w, int ld, int M, void* stream);
+int cmpc_score_conv_bwd(int dt, const float* dscore, const void* feat, const float* Wk, void* dfeat, int accumulate,
+                        float* dWk, float* dbias, int B, int h, int w, int ld, int M, void* stream);
+/* up = legacy bilinear(score); sigm = sigmoid(up) (optional); when target != NULL also
+ * loss[b] += sum BCE, inter[b]/uni[b] += |pred&gt| / |pred|gt| with pred = up > 0 */
+int cmpc_upsample_fwd(const float* score, float* up, float* sigm, const float* target, float* loss,
+                      int* inter, int* uni, int B, int h, int w, int H, int W, void* stream);
+/* dscore = sum over the bilinear footprint of wscale * (sigmoid(up) - target) */
+int cmpc_upsample_loss_bwd(const float* up, const float* target, float* dscore, float wscale,
+                           int B, int h, int w, int H, int W, void* stream);
+
+/* ---- language side (CMPC_model.py:144-192,347-357) ---------------------------------------- */
+int cmpc_embed_gather(const float* table, const int* words, float* out, int n_words, int G, int ld_out, int vocab, void* stream);
+int cmpc_embed_scatter(const float* dout, int ld, const int* words, float* dtable, int n_words, int G, int vocab, void* stream);
+/* tf LSTMCell step (gates i,j,f,o; forget_bias 1) with dynamic_rnn length masking.
+ * gates [B, 4*ld] f32 pre-activations in, activated gates out; state f32 [B, ld] */
+int cmpc_lstm_cell_fwd(float* gates, const float* c_prev, const float* h_prev, const int* seq_len, int t,
+                       float* c_out, float* h_out, float* out_t, int ld_out, int B, int ld, int R, void* stream);
+int cmpc_lstm_cell_bwd(const float* gates_act, const float* c_prev, const float* c_out, const int* seq_len, int t,
+                       const float* dout_t, int ld_dout, float* dh, float* dc, float* dgates,
+                       int B, int ld, int R, void* stream);
+/* softmax over the 4 parser classes times seq_mask (:352-353) */
+int cmpc_parse_softmax_fwd(const float* logits, int ld, const float* mask, float* parse, int n, void* stream);
+int cmpc_parse_softmax_bwd(const float* dparse, const float* parse, const float* mask, float* dlogits, int ld, int n, void* stream);
+/* valid_lang (ncls=2) / nec_lang (ncls=3): v[b] = l2norm(sum_t (sum_{k<ncls} parse[b,t,k]) wf[b,t,:]) */
+int cmpc_lang_pool_fwd(const float* parse, const float* wf, float* v, float* rstd, int B, int T, int ld, int R, int ncls, void* stream);
+int cmpc_lang_pool_bwd(const float* dv, const float* v, const float* rstd, const float* parse, const float* wf,
+                       float* dparse, float* dwf, int B, int T, int ld, int R, int ncls, void* stream);
+
+/* ---- parameters: packing fp32 masters into padded GEMM operands; TF-Adam (CMPC_model.py:450-478)
+ *      with L2 on 'DW' (:433,446, util/loss.py:28-32) and x2 on 'biases' (:464-465) folded in ---- */
+typedef struct {
+    int64_t src_off;           /* element offset into the fp32 master buffer; matrix [K, N], row stride ld_src */
+    int ld_src;
+    int64_t dst_off;           /* BYTE offset into the operand arena */
+    int dst_dt;                /* dtype of the packed copy */
+    int transpose;             /* 1: dst[n][k] (Bt for forward), 0: dst[k][n] (Bt for dX) */
+    int rows, cols, ld_dst;    /* dst matrix extent (padded) */
+    int nks; int ks_src[4], ks_len[4], ks_dst[4];   /* K segments: src row range -> dst k offset */
+    int nns; int ns_src[5], ns_len[5], ns_dst[5];   /* N blocks:   src col range -> dst n offset */
+} cmpc_pack_desc;
+int cmpc_pack_weights(const float* master, void* arena, const cmpc_pack_desc* descs_dev, int ndesc, int max_tiles, void* stream);
+
+typedef struct { int64_t off; int count; float wd; float gmult; } cmpc_adam_seg;
+int cmpc_adam_step(float* params, const float* grads, float* m, float* v, const cmpc_adam_seg* segs_dev, int nseg,
+                   float lr_t, float beta1, float beta2, float eps, float gscale, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
