@@ -1,0 +1,189 @@
+#!/usr/bin/env python3
+"""bench.py -- images/sec of the CMPC train step (backbone forward + HIP head forward/backward +
+gradient all-reduce + fused Adam) at 320x320, L=20, B=8 per GPU, synthetic data.
+
+  python bench.py --gpus 1 --steps 20 --warmup 5
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+         bench.py --gpus N --steps K --warmup W
+
+Prints ONE JSON line on rank 0 (contract in the project brief): metric/value/unit, ms_per_step,
+`roofline` for the dominant kernel (the bf16 MFMA gemm_nt, timed live with events on the launch
+stream) and `cpu_baseline` (the oracle -- a torch-CPU fp32 restatement of the reference graph,
+since TensorFlow cannot run here -- timed on this box's host cores on a bounded sample).
+"""
+from __future__ import annotations
+
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+MU = np.array((104.00698793, 116.66876762, 122.67891434), dtype=np.float32)
+
+
+def synth_batch(B, T, H, W, vocab, seed):
+    """SURVEY.md 8d synthetic inputs: uint8 image -> BGR minus mean; seq_len ~ U{3..T} (sample 0 = T);
+    words ~ U{4..V-1}, 0-padded at the end; one random rectangle per image as the mask."""
+    rng = np.random.default_rng(seed)
+    im = rng.integers(0, 256, size=(B, H, W, 3), dtype=np.uint8).astype(np.float32)[:, :, :, ::-1] - MU
+    seq_len = rng.integers(3, T + 1, size=(B,)).astype(np.int32)
+    seq_len[0] = T
+    words = np.zeros((B, T), dtype=np.int32)
+    for b in range(B):
+        words[b, :seq_len[b]] = rng.integers(4, vocab, size=(seq_len[b],))
+    target = np.zeros((B, H, W, 1), dtype=np.float32)
+    for b in range(B):
+        hh, ww = rng.integers(40, 201, size=2)
+        y0, x0 = rng.integers(0, H - hh + 1), rng.integers(0, W - ww + 1)
+        target[b, y0:y0 + hh, x0:x0 + ww, 0] = 1.0
+    return words, np.ascontiguousarray(im), seq_len, target
+
+
+class GemmTimer:
+    """Wraps ops.gemm_nt: an event pair on the launch stream around every bf16 launch, plus the
+    algorithmic FLOPs of that launch (2*M*n_valid*K_valid, pad columns/rows not counted)."""
+
+    def __init__(self, ops, cfg):
+        self.ops, self.orig, self.rec, self.on = ops, ops.gemm_nt, [], False
+        # padded extent -> algorithmic extent (collisions with the 512/1024/2048 backbone widths
+        # only ever under-count)
+        C, M, Cp, Mp = cfg.v_emb_dim, cfg.mlp_dim, cfg.Cp, cfg.Mp
+        self.valid = {Cp: C, Mp: M, 64: 8, 5 * Cp: 5 * C, 4 * Mp: 4 * M}
+
+    def install(self):
+        ops, orig, me = self.ops, self.orig, self
+
+        def timed(dt, segs, C, ldc, M, N, n_valid=None, batch=1, **kw):
+            if not me.on or dt != 1:
+                return orig(dt, segs, C, ldc, M, N, n_valid=n_valid, batch=batch, **kw)
+            k_alg = sum(me.valid.get(s[4], s[4]) for s in segs)
+            nv = N if n_valid is None else n_valid
+            nv = me.valid.get(nv, nv) if nv != 64 else nv
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            orig(dt, segs, C, ldc, M, N, n_valid=n_valid, batch=batch, **kw)
+            e1.record()
+            me.rec.append((e0, e1, 2.0 * M * batch * nv * k_alg))
+        ops.gemm_nt = timed
+
+    def summary(self):
+        t = sum(e0.elapsed_time(e1) for e0, e1, _ in self.rec) * 1e-3
+        f = sum(fl for _, _, fl in self.rec)
+        return t, f, len(self.rec)
+
+
+def cpu_baseline(args):
+    """The oracle (test infrastructure) timed as the CPU baseline: one full train step
+    (backbone forward + head forward/backward + TF-Adam) on `cpu_images` synthetic images."""
+    from oracle import cmpc_torch as O
+    nthreads = os.cpu_count() or 1
+    torch.set_num_threads(nthreads)
+    B = args.cpu_images
+    cfg = O.Cfg(batch_size=B)
+    hp, bp = O.init_head_params(cfg), O.init_backbone_params(cfg)
+    w, im, sl, tg = synth_batch(B, cfg.num_steps, cfg.H, cfg.W, cfg.vocab_size, 0)
+    w, im, sl, tg = map(torch.from_numpy, (w, im, sl, tg))
+    opt = O.TFAdam(hp)
+    t0 = time.time()
+    with torch.no_grad():
+        feats = O.backbone_forward(bp, im, cfg)
+    O.train_step(hp, opt, 0, feats, w, sl, tg, cfg)
+    dt = time.time() - t0
+    return {"value": B / dt, "unit": "images/sec", "cores": nthreads, "kind": "port",
+            "sample": f"1 train step (backbone fwd + head fwd/bwd + Adam) on {B} synthetic 320x320 L=20 images, "
+                      f"torch-CPU fp32 restatement of the TF graph (TensorFlow unavailable), {dt:.1f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=8, help="images per GPU")
+    ap.add_argument("--dtype", default="bf16", choices=("bf16", "f32"))
+    ap.add_argument("--cpu-images", type=int, default=2)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-timing", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.distributed.init_process_group("nccl", device_id=torch.device(f"cuda:{local}"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X; there is no CPU path for the product")
+    torch.cuda.set_device(local)
+    dev = torch.device(f"cuda:{local}")
+
+    pkg = importlib.import_module("cmpc-refseg_amd")
+    ops = importlib.import_module("cmpc-refseg_amd.ops")
+    B, T, H, W = args.batch, 20, 320, 320
+    model = pkg.LSTM_model(batch_size=B, num_steps=T, H=H, W=W, mode="train", dtype=args.dtype, device=str(dev))
+    model.enable_data_parallel()
+    w, im, sl, tg = synth_batch(B, T, H, W, model.cfg.vocab_size, seed=rank)
+    words = torch.from_numpy(w).to(dev)
+    im = torch.from_numpy(im).to(dev)
+    seq_len = torch.from_numpy(sl).to(dev)
+    target = torch.from_numpy(tg).to(dev)
+    timer = GemmTimer(ops, model.cfg)
+    if not args.no_kernel_timing:
+        timer.install()
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        model.train_step(words, im, target, seq_len)
+    barrier()
+    timer.on = True
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        _, scal = model.train_step(words, im, target, seq_len)
+    barrier()
+    dt = time.perf_counter() - t0
+    timer.on = False
+    tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
+    if world > 1:
+        torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
+    dt = float(tmax.item())
+    loss = float(scal["loss_all"])
+
+    if rank == 0:
+        out = {
+            "metric": "images/sec at 320x320 L=20 (train step: backbone fwd + CMPC head fwd/bwd + grad all-reduce + Adam)",
+            "value": B * world * args.steps / dt, "unit": "images/sec", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": f"CMPC_model 320x320 B={B}/gpu L=20 {args.dtype}, ResNet-101 backbone (frozen), random-init weights",
+                       "global_batch": B * world, "parallelism": f"dp{world}"},
+            "final_loss": loss,
+        }
+        if not args.no_kernel_timing and timer.rec:
+            t, f, n = timer.summary()
+            peak = 2500.0 if args.dtype == "bf16" else 157.3
+            out["roofline"] = {"bound": "mfma", "achieved": f / t / 1e12, "peak": peak, "unit": "TFLOP/s",
+                               "frac": f / t / 1e12 / peak, "traffic": None,
+                               "kernel": "gemm_nt_kernel<bf16> (all 1x1-conv / dX products of the head)",
+                               "launches_per_step": n / args.steps, "ms_per_step_in_kernel": 1e3 * t / args.steps}
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
