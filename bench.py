@@ -84,7 +84,12 @@ def cpu_baseline(args):
     """The oracle (test infrastructure) timed as the CPU baseline: one full train step
     (backbone forward + head forward/backward + TF-Adam) on `cpu_images` synthetic images."""
     from oracle import cmpc_torch as O
-    nthreads = os.cpu_count() or 1
+    # the GPU box gives one GPU a 16-core CPU share; os.cpu_count() reports the whole host
+    try:
+        nthreads = len(os.sched_getaffinity(0))
+    except AttributeError:
+        nthreads = os.cpu_count() or 1
+    nthreads = max(1, min(nthreads, 16))
     torch.set_num_threads(nthreads)
     B = args.cpu_images
     cfg = O.Cfg(batch_size=B)
@@ -92,6 +97,7 @@ def cpu_baseline(args):
     w, im, sl, tg = synth_batch(B, cfg.num_steps, cfg.H, cfg.W, cfg.vocab_size, 0)
     w, im, sl, tg = map(torch.from_numpy, (w, im, sl, tg))
     opt = O.TFAdam(hp)
+    log(f"cpu baseline: {nthreads} threads, {B} image(s)")
     t0 = time.time()
     with torch.no_grad():
         feats = O.backbone_forward(bp, im, cfg)
@@ -102,6 +108,10 @@ def cpu_baseline(args):
                       f"torch-CPU fp32 restatement of the TF graph (TensorFlow unavailable), {dt:.1f} s"}
 
 
+def log(msg):
+    print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -109,7 +119,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=8, help="images per GPU")
     ap.add_argument("--dtype", default="bf16", choices=("bf16", "f32"))
-    ap.add_argument("--cpu-images", type=int, default=2)
+    ap.add_argument("--cpu-images", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     args = ap.parse_args()
@@ -129,6 +139,7 @@ def main():
     pkg = importlib.import_module("cmpc-refseg_amd")
     ops = importlib.import_module("cmpc-refseg_amd.ops")
     B, T, H, W = args.batch, 20, 320, 320
+    log("building model")
     model = pkg.LSTM_model(batch_size=B, num_steps=T, H=H, W=W, mode="train", dtype=args.dtype, device=str(dev))
     model.enable_data_parallel()
     w, im, sl, tg = synth_batch(B, T, H, W, model.cfg.vocab_size, seed=rank)
@@ -145,8 +156,11 @@ def main():
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
+    log("model built; warmup")
+    for i in range(args.warmup):
         model.train_step(words, im, target, seq_len)
+        torch.cuda.synchronize()
+        log(f"warmup step {i} done")
     barrier()
     timer.on = True
     t0 = time.perf_counter()
@@ -160,6 +174,7 @@ def main():
         torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
     dt = float(tmax.item())
     loss = float(scal["loss_all"])
+    log(f"timed {args.steps} steps in {dt:.3f} s")
 
     if rank == 0:
         out = {
@@ -179,6 +194,7 @@ def main():
                                "kernel": "gemm_nt_kernel<bf16> (all 1x1-conv / dX products of the head)",
                                "launches_per_step": n / args.steps, "ms_per_step_in_kernel": 1e3 * t / args.steps}
         if world == 1 and not args.no_cpu_baseline:
+            log("cpu baseline (oracle on host cores)")
             out["cpu_baseline"] = cpu_baseline(args)
         print(json.dumps(out), flush=True)
     if world > 1:

@@ -345,6 +345,67 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const cmpc_gemm_tn_args p)
             }
 }
 
+
+// ------------------------------------------------------------------------------------------
+// gemm_nt for M <= 16 rows (the language side: [B, .] vectors against whole weight matrices).
+// Weight-streaming: one wave per NC output columns, K split over the 64 lanes (float4 loads of
+// the K-contiguous weight rows), the few A rows re-read from L1/L2; wave-shuffle reduction.
+// ------------------------------------------------------------------------------------------
+template <int MMAX>
+__global__ __launch_bounds__(256) void gemm_nt_skinny_f32_kernel(const cmpc_gemm_nt_args p) {
+    constexpr int NC = 2;
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int n0 = (blockIdx.x * 4 + wid) * NC;
+    if (n0 >= p.N) return;
+    float acc[MMAX][NC];
+#pragma unroll
+    for (int m = 0; m < MMAX; ++m)
+#pragma unroll
+        for (int c = 0; c < NC; ++c) acc[m][c] = 0.f;
+    for (int s = 0; s < p.nseg; ++s) {
+        const float* A = reinterpret_cast<const float*>(p.A[s]);
+        const float* Bt = reinterpret_cast<const float*>(p.Bt[s]);
+        const long lda = p.lda[s], ldb = p.ldb[s];
+        const int K = p.K[s];
+        for (int k = lane * 4; k < K; k += 256) {
+            float4 w[NC];
+#pragma unroll
+            for (int c = 0; c < NC; ++c)
+                w[c] = (n0 + c < p.N) ? *reinterpret_cast<const float4*>(Bt + (n0 + c) * ldb + k) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int m = 0; m < MMAX; ++m) {
+                if (m < p.M) {
+                    const float4 a = *reinterpret_cast<const float4*>(A + m * lda + k);
+#pragma unroll
+                    for (int c = 0; c < NC; ++c) acc[m][c] += a.x * w[c].x + a.y * w[c].y + a.z * w[c].z + a.w * w[c].w;
+                }
+            }
+        }
+    }
+    float mine = 0.f;
+#pragma unroll
+    for (int m = 0; m < MMAX; ++m)
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            const float v = wave_sum(acc[m][c]);
+            if (lane == m * NC + c) mine = v;
+        }
+    const int m = lane / NC, c = lane % NC, gn = n0 + c;
+    if (m >= p.M || gn >= p.N) return;
+    float x = 0.f;
+    if (gn < p.n_valid) {
+        x = mine * p.alpha;
+        const int rps = p.rows_per_sample > 0 ? p.rows_per_sample : 1;
+        if (p.bias) x += p.bias[gn];
+        if (p.sbias) x += p.sbias[(m / rps) * (long)p.ld_sbias + gn];
+        if (p.pbias) x += p.pbias[(m % rps) * (long)p.ld_pbias + gn];
+        x = act_apply(x, p.act);
+    }
+    float* C = reinterpret_cast<float*>(p.C) + (long)m * p.ldc + gn;
+    if (p.accumulate) x += *C;
+    *C = x;
+}
+
 }  // namespace
 
 extern "C" int cmpc_gemm_nt(const cmpc_gemm_nt_args* a, void* stream) {
@@ -360,10 +421,16 @@ extern "C" int cmpc_gemm_nt(const cmpc_gemm_nt_args* a, void* stream) {
         }
     }
     if (a->N % 4 || a->ldc % 4 || !a->C) { cmpc_set_error("gemm_nt: N/ldc must be multiples of 4"); return CMPC_EINVAL; }
+    hipStream_t st = (hipStream_t)stream;
+    if (a->dtype == DT_F32 && a->M <= 16 && a->batch == 1) {
+        dim3 grid((a->N + 7) / 8);
+        if (a->M <= 8) hipLaunchKernelGGL((gemm_nt_skinny_f32_kernel<8>), grid, dim3(256), 0, st, *a);
+        else hipLaunchKernelGGL((gemm_nt_skinny_f32_kernel<16>), grid, dim3(256), 0, st, *a);
+        return cmpc_check_launch("gemm_nt(skinny)");
+    }
     const int bn = (a->N % 128 == 0 || a->N > 64) ? 128 : 64;
     dim3 grid((a->N + bn - 1) / bn, (a->M + BM - 1) / BM, a->batch);
     const size_t lds = 2 * (BM + bn) * BKB;
-    hipStream_t st = (hipStream_t)stream;
     if (a->dtype == DT_F32) {
         if (bn == 128) hipLaunchKernelGGL((gemm_nt_kernel<float, 128>), grid, dim3(256), lds, st, *a);
         else hipLaunchKernelGGL((gemm_nt_kernel<float, 64>), grid, dim3(256), lds, st, *a);

@@ -154,13 +154,17 @@ __device__ __forceinline__ int seg_map(int x, int ns, const int* src, const int*
     return -1;
 }
 
-__global__ __launch_bounds__(256) void pack_kernel(const float* __restrict__ master, char* __restrict__ arena, const cmpc_pack_desc* __restrict__ descs) {
+__global__ __launch_bounds__(256) void pack_kernel(const float* __restrict__ master, char* __restrict__ arena, const cmpc_pack_desc* __restrict__ descs,
+                                                  const int* __restrict__ tile_prefix, int ndesc) {
     __shared__ float tile[32][33];
-    const cmpc_pack_desc d = descs[blockIdx.y];
+    // blockIdx.x -> (descriptor, tile) through the exclusive prefix sum of per-descriptor tile counts
+    int lo = 0, hi = ndesc;
+    while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (tile_prefix[mid] <= (int)blockIdx.x) lo = mid; else hi = mid; }
+    const cmpc_pack_desc d = descs[lo];
+    const int t = blockIdx.x - tile_prefix[lo];
     const int Kp = d.transpose ? d.cols : d.rows, Np = d.transpose ? d.rows : d.cols;
-    const int tk = (Kp + 31) / 32, tn = (Np + 31) / 32;
-    if ((int)blockIdx.x >= tk * tn) return;
-    const int k0 = (blockIdx.x / tn) * 32, n0 = (blockIdx.x % tn) * 32;
+    const int tn = (Np + 31) / 32;
+    const int k0 = (t / tn) * 32, n0 = (t % tn) * 32;
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
     for (int i = ty; i < 32; i += 8) {
         const int k = k0 + i, n = n0 + tx;
@@ -245,10 +249,10 @@ extern "C" int cmpc_lang_pool_bwd(const float* dv, const float* v, const float* 
     return cmpc_check_launch("lang_pool_bwd");
 }
 
-extern "C" int cmpc_pack_weights(const float* master, void* arena, const cmpc_pack_desc* descs_dev, int ndesc, int max_tiles, void* stream) {
-    if (ndesc <= 0) return CMPC_OK;
-    if (max_tiles <= 0) { cmpc_set_error("pack_weights: max_tiles must be > 0"); return CMPC_EINVAL; }
-    hipLaunchKernelGGL(pack_kernel, dim3(max_tiles, ndesc), dim3(256), 0, ST, master, (char*)arena, descs_dev);
+extern "C" int cmpc_pack_weights(const float* master, void* arena, const cmpc_pack_desc* descs_dev, const int* tile_prefix_dev,
+                                 int ndesc, int total_tiles, void* stream) {
+    if (ndesc <= 0 || total_tiles <= 0) return CMPC_OK;
+    hipLaunchKernelGGL(pack_kernel, dim3(total_tiles), dim3(256), 0, ST, master, (char*)arena, descs_dev, tile_prefix_dev, ndesc);
     return cmpc_check_launch("pack_weights");
 }
 

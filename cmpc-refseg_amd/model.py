@@ -16,7 +16,7 @@ from typing import Dict, Optional
 import numpy as np
 import torch
 
-from . import _lib, backbone as bb, ops
+from . import _lib, backbone as bb, dist, ops
 from ._lib import DT_BF16, DT_F32
 from .params import EXG, LEVELS, HeadCfg, ParamStore, init_head_params
 
@@ -169,10 +169,7 @@ class LSTM_model(object):
         self._check_feeds(words, im, seq_len, target_fine)
         feats = self.features(im)
         o = self.loss_and_grads(feats, words, target_fine, seq_len)
-        gscale = 1.0
-        if self.world > 1:
-            torch.distributed.all_reduce(self.store.grads)       # RCCL over xGMI: one flat buffer
-            gscale = 1.0 / self.world
+        gscale = dist.allreduce_grads_(self.store.grads)          # RCCL over xGMI: one flat buffer
         lr = self.store.adam_step(gscale)
         scal = {k: o[k].detach() for k in ("loss_all", "loss_c3", "loss_c4", "loss_c5", "loss_last", "mIoU")}
         scal["mean_IOU"] = scal.pop("mIoU")
@@ -190,10 +187,9 @@ class LSTM_model(object):
     def enable_data_parallel(self):
         """One process per GPU; identical weights are assumed (same seed); gradients are summed with
         one all-reduce of the flat buffer and divided by the world size in the Adam kernel."""
-        import torch.distributed as dist
-        self.world = dist.get_world_size() if dist.is_initialized() else 1
+        self.world = dist.world_size()
         if self.world > 1:
-            dist.broadcast(self.store.params, 0)
+            dist.broadcast_params_(self.store.params, 0)
             self.store.pack()
         return self.world
 

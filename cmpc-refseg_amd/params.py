@@ -337,7 +337,11 @@ class ParamStore:
         raw = np.frombuffer(bytes(arr), dtype=np.uint8).copy()
         self.descs_dev = torch.from_numpy(raw).to(self.device)
         self.ndesc = n
-        self.max_tiles = max(((d.rows + 31) // 32) * ((d.cols + 31) // 32) for d in self._descs)
+        pref = np.zeros(n + 1, dtype=np.int32)
+        for i, d in enumerate(self._descs):
+            pref[i + 1] = pref[i] + ((d.rows + 31) // 32) * ((d.cols + 31) // 32)
+        self.tile_prefix = torch.from_numpy(pref).to(self.device)
+        self.total_tiles = int(pref[-1])
         # Adam segments: <= 8192 elements each, inside one parameter
         segs = []
         for name, shape, _, flags in self.specs:
@@ -357,7 +361,7 @@ class ParamStore:
 
     def pack(self):
         _lib.call("cmpc_pack_weights", self.params.data_ptr(), self.arena.data_ptr(), self.descs_dev.data_ptr(),
-                  self.ndesc, self.max_tiles, self._stream())
+                  self.tile_prefix.data_ptr(), self.ndesc, self.total_tiles, self._stream())
 
     def zero_grads(self):
         self.grads.zero_()

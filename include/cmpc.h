@@ -205,7 +205,10 @@ typedef struct {
     int nks; int ks_src[4], ks_len[4], ks_dst[4];   /* K segments: src row range -> dst k offset */
     int nns; int ns_src[5], ns_len[5], ns_dst[5];   /* N blocks:   src col range -> dst n offset */
 } cmpc_pack_desc;
-int cmpc_pack_weights(const float* master, void* arena, const cmpc_pack_desc* descs_dev, int ndesc, int max_tiles, void* stream);
+/* tile_prefix_dev[i] = number of 32x32 tiles of descriptors 0..i-1 (exclusive prefix sum, ndesc+1 entries
+ * with tile count = ceil(K/32)*ceil(N/32) of each padded block); total_tiles = tile_prefix[ndesc] */
+int cmpc_pack_weights(const float* master, void* arena, const cmpc_pack_desc* descs_dev, const int* tile_prefix_dev,
+                      int ndesc, int total_tiles, void* stream);
 
 typedef struct { int64_t off; int count; float wd; float gmult; } cmpc_adam_seg;
 int cmpc_adam_step(float* params, const float* grads, float* m, float* v, const cmpc_adam_seg* segs_dev, int nseg,
