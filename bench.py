@@ -98,14 +98,18 @@ def cpu_baseline(args):
     w, im, sl, tg = map(torch.from_numpy, (w, im, sl, tg))
     opt = O.TFAdam(hp)
     log(f"cpu baseline: {nthreads} threads, {B} image(s)")
-    t0 = time.time()
-    with torch.no_grad():
-        feats = O.backbone_forward(bp, im, cfg)
-    O.train_step(hp, opt, 0, feats, w, sl, tg, cfg)
-    dt = time.time() - t0
-    return {"value": B / dt, "unit": "images/sec", "cores": nthreads, "kind": "port",
-            "sample": f"1 train step (backbone fwd + head fwd/bwd + Adam) on {B} synthetic 320x320 L=20 images, "
-                      f"torch-CPU fp32 restatement of the TF graph (TensorFlow unavailable), {dt:.1f} s"}
+    best = None
+    for step in range(args.cpu_steps):
+        t0 = time.time()
+        with torch.no_grad():
+            feats = O.backbone_forward(bp, im, cfg)
+        O.train_step(hp, opt, step, feats, w, sl, tg, cfg)
+        dt = time.time() - t0
+        log(f"cpu baseline step {step}: {dt:.1f} s")
+        best = dt if best is None else min(best, dt)
+    return {"value": B / best, "unit": "images/sec", "cores": nthreads, "kind": "port",
+            "sample": f"best of {args.cpu_steps} train steps (backbone fwd + head fwd/bwd + Adam) on a batch of {B} synthetic "
+                      f"320x320 L=20 images, torch-CPU fp32 restatement of the TF graph (TensorFlow unavailable), {best:.1f} s/step"}
 
 
 def log(msg):
@@ -119,7 +123,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=8, help="images per GPU")
     ap.add_argument("--dtype", default="bf16", choices=("bf16", "f32"))
-    ap.add_argument("--cpu-images", type=int, default=1)
+    ap.add_argument("--cpu-images", type=int, default=8)
+    ap.add_argument("--cpu-steps", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     args = ap.parse_args()

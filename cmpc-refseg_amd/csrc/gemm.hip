@@ -442,9 +442,11 @@ extern "C" int cmpc_gemm_nt(const cmpc_gemm_nt_args* a, void* stream) {
 }
 
 extern "C" int cmpc_gemm_tn(const cmpc_gemm_tn_args* a, void* stream) {
-    if (!a || a->R < 0 || a->Kv <= 0 || a->Nv <= 0 || a->nb < 1 || a->nb > 8 || a->nb2 < 1 || a->rsplit < 1 || !a->A || !a->D || !a->out) {
+    if (!a || a->R < 0 || a->Kv <= 0 || a->Nv <= 0 || a->nb < 1 || a->nb > 8 || a->nb2 < 1 || a->rsplit < 1) {
         cmpc_set_error("gemm_tn: bad args"); return CMPC_EINVAL;
     }
+    if (a->R == 0) return CMPC_OK;              // empty reduction: out += 0
+    if (!a->A || !a->D || !a->out) { cmpc_set_error("gemm_tn: null operand"); return CMPC_EINVAL; }
     const int esz = a->dtype == DT_F32 ? 4 : 2;
     if ((a->lda * esz) % 16 || (a->ldd * esz) % 16 || (a->Ka * esz) % 16 || (a->Nd * esz) % 16) {
         cmpc_set_error("gemm_tn: rows must be 16-B aligned"); return CMPC_EINVAL;
@@ -452,7 +454,6 @@ extern "C" int cmpc_gemm_tn(const cmpc_gemm_tn_args* a, void* stream) {
     for (int i = 0; i < a->nb; ++i)
         if ((a->a_off[i] * esz) % 16 || (a->d_off[i] * esz) % 16) { cmpc_set_error("gemm_tn: offsets must be 16-B aligned"); return CMPC_EINVAL; }
     if ((a->a_bs * esz) % 16 || (a->d_bs * esz) % 16) { cmpc_set_error("gemm_tn: batch strides must be 16-B aligned"); return CMPC_EINVAL; }
-    if (a->R == 0) return CMPC_OK;
     dim3 grid(((a->Kv + 127) / 128) * ((a->Nv + 127) / 128), a->rsplit, a->nb * a->nb2);
     hipStream_t st = (hipStream_t)stream;
     if (a->dtype == DT_F32) {

@@ -198,7 +198,7 @@ def test_facade_contract_and_errors(case):
     assert U.rel_err(out["up"].float().cpu(), case["taps"]["up"]) < 1e-4
     assert torch.allclose(out["sigm"].cpu(), torch.sigmoid(out["up"].cpu()), atol=1e-6)
     masks = m.predict(case["im"], case["words"], case["sl"])
-    assert torch.equal(masks, out["sigm"])
+    assert torch.allclose(masks, out["sigm"], atol=2e-6)      # fp32 atomics reorder sums between runs
     with pytest.raises(ValueError):
         m.forward(case["words"][:, :3], case["im"], case["sl"])
     with pytest.raises(ValueError):
