@@ -93,6 +93,7 @@ SIGNATURES = {
     "cmpc_rowdot1": [_I, _P, _P, _I, _P, _I, _I, _I, _I, _F, _P],
     "cmpc_rank1_update": [_I, _P, _P, _P, _P, _P, _I, _F, _F, _I, _I, _I, _I, _P],
     "cmpc_axpy": [_I, _P, _P, _F, _L, _P],
+    "cmpc_bias_act_res": [_I, _P, _P, _P, _I, _L, _I, _P],
     "cmpc_l2norm_rows_fwd": [_I, _P, _P, _P, _P, _I, _I, _I, _P],
     "cmpc_l2norm_rows_bwd": [_I, _P, _P, _P, _P, _I, _I, _I, _I, _P],
     "cmpc_sample_stats": [_I, _P, _P, _I, _I, _I, _I, _P],

@@ -9,12 +9,15 @@ TF 'SAME' padding is reproduced explicitly: the 7x7/2 stem pads (2,3), the 3x3/2
 """
 from __future__ import annotations
 
+import ctypes
 import math
 from typing import Dict, List, Tuple
 
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
+
+from . import _lib
 
 
 def _same_pad(size, k, stride, dil):
@@ -83,6 +86,7 @@ class _ConvBN(nn.Module):
         self.k, self.stride, self.dilation, self.relu = k, stride, dilation, relu
         self.weight = nn.Parameter(torch.zeros(cout, cin, k, k), requires_grad=False)
         self.bias = nn.Parameter(torch.zeros(cout), requires_grad=False)
+        self.register_buffer("bias32", torch.zeros(cout, dtype=torch.float32), persistent=False)
 
     def load(self, p, conv, bn):
         sc = p[f"{bn}/gamma"].double() / torch.sqrt(p[f"{bn}/moving_variance"].double() + 1e-3)
@@ -90,16 +94,32 @@ class _ConvBN(nn.Module):
         w = p[f"{conv}/weights"].double().permute(3, 2, 0, 1) * sc.view(-1, 1, 1, 1)      # HWIO -> OIHW
         self.weight.data.copy_(w.to(self.weight.dtype))
         self.bias.data.copy_(sh.to(self.bias.dtype))
+        self.bias32.copy_(sh.float())
 
-    def forward(self, x):
+    def _apply(self, fn, *a, **kw):
+        out = super()._apply(fn, *a, **kw)
+        self.bias32 = self.bias32.float()          # the epilogue kernel always reads an fp32 shift
+        return out
+
+    def forward(self, x, res=None):
+        """conv (MIOpen) then ONE fused HIP epilogue: + folded-BN shift (+ residual) (+ ReLU), in place."""
         k, s, d = self.k, self.stride, self.dilation
         pt, pb = _same_pad(x.shape[2], k, s, d)
         pl, pr = _same_pad(x.shape[3], k, s, d)
         if pt == pb and pl == pr:
-            y = F.conv2d(x, self.weight, self.bias, stride=s, padding=(pt, pl), dilation=d)
+            y = F.conv2d(x, self.weight, None, stride=s, padding=(pt, pl), dilation=d)
         else:
-            y = F.conv2d(F.pad(x, (pl, pr, pt, pb)), self.weight, self.bias, stride=s, dilation=d)
-        return F.relu(y, inplace=True) if self.relu else y
+            y = F.conv2d(F.pad(x, (pl, pr, pt, pb)), self.weight, None, stride=s, dilation=d)
+        B, C, H, W = y.shape
+        if C % 8 or not y.is_contiguous(memory_format=torch.channels_last) or (res is not None and not res.is_contiguous(memory_format=torch.channels_last)):
+            y = y + self.bias32.to(y.dtype).view(1, -1, 1, 1)
+            if res is not None:
+                y = y + res
+            return F.relu(y, inplace=True) if self.relu else y
+        dt = 0 if y.dtype == torch.float32 else 1
+        _lib.call("cmpc_bias_act_res", dt, y.data_ptr(), self.bias32.data_ptr(), res.data_ptr() if res is not None else None,
+                  int(self.relu), B * H * W, C, ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+        return y
 
 
 class _Bottleneck(nn.Module):
@@ -108,11 +128,11 @@ class _Bottleneck(nn.Module):
         self.b1 = _ConvBN(1, cin, cout, stride, relu=False) if has_b1 else None
         self.a = _ConvBN(1, cin, mid, stride)
         self.b = _ConvBN(3, mid, mid, 1, dil)
-        self.c = _ConvBN(1, mid, cout, relu=False)
+        self.c = _ConvBN(1, mid, cout, relu=True)       # ReLU after the residual add, fused with it
 
     def forward(self, x):
         sc = self.b1(x) if self.b1 is not None else x
-        return F.relu(sc + self.c(self.b(self.a(x))), inplace=True)
+        return self.c(self.b(self.a(x)), res=sc)
 
 
 class DeepLabResNet(nn.Module):

@@ -156,35 +156,60 @@ __device__ __forceinline__ int seg_map(int x, int ns, const int* src, const int*
 
 __global__ __launch_bounds__(256) void pack_kernel(const float* __restrict__ master, char* __restrict__ arena, const cmpc_pack_desc* __restrict__ descs,
                                                   const int* __restrict__ tile_prefix, int ndesc) {
-    __shared__ float tile[32][33];
-    // blockIdx.x -> (descriptor, tile) through the exclusive prefix sum of per-descriptor tile counts
+    // tile = 32 (k) x 128 (n): float4 reads along n (every segment boundary is a multiple of 4),
+    // 8/16-byte writes along n (natural) or along k through LDS (transposed).
+    __shared__ float tile[32][132];
     int lo = 0, hi = ndesc;
     while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (tile_prefix[mid] <= (int)blockIdx.x) lo = mid; else hi = mid; }
     const cmpc_pack_desc d = descs[lo];
     const int t = blockIdx.x - tile_prefix[lo];
     const int Kp = d.transpose ? d.cols : d.rows, Np = d.transpose ? d.rows : d.cols;
-    const int tn = (Np + 31) / 32;
-    const int k0 = (t / tn) * 32, n0 = (t % tn) * 32;
+    const int tn = (Np + 127) / 128;
+    const int k0 = (t / tn) * 32, n0 = (t % tn) * 128;
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
-    for (int i = ty; i < 32; i += 8) {
-        const int k = k0 + i, n = n0 + tx;
-        float v = 0.f;
-        if (k < Kp && n < Np) {
-            const int sr = seg_map(k, d.nks, d.ks_src, d.ks_len, d.ks_dst);
-            const int sc = seg_map(n, d.nns, d.ns_src, d.ns_len, d.ns_dst);
-            if (sr >= 0 && sc >= 0) v = master[d.src_off + (long)sr * d.ld_src + sc];
-        }
-        tile[i][tx] = v;
-    }
-    __syncthreads();
     char* dst = arena + d.dst_off;
-    for (int i = ty; i < 32; i += 8) {
-        float v; long o; bool okk;
-        if (d.transpose) { const int n = n0 + i, k = k0 + tx; v = tile[tx][i]; o = (long)n * d.ld_dst + k; okk = n < Np && k < Kp; }
-        else { const int k = k0 + i, n = n0 + tx; v = tile[i][tx]; o = (long)k * d.ld_dst + n; okk = n < Np && k < Kp; }
-        if (okk) {
-            if (d.dst_dt == DT_F32) reinterpret_cast<float*>(dst)[o] = v;
-            else reinterpret_cast<bf16_t*>(dst)[o] = f2bf(v);
+    const int n = n0 + 4 * tx;
+    const int sc = (n < Np) ? seg_map(n, d.nns, d.ns_src, d.ns_len, d.ns_dst) : -1;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int kk = ty + 8 * i, k = k0 + kk;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (k < Kp && sc >= 0) {
+            const int sr = seg_map(k, d.nks, d.ks_src, d.ks_len, d.ks_dst);
+            if (sr >= 0) v = *reinterpret_cast<const float4*>(master + d.src_off + (long)sr * d.ld_src + sc);
+        }
+        if (!d.transpose) {
+            if (k < Kp && n < Np) {
+                const long o = (long)k * d.ld_dst + n;
+                if (d.dst_dt == DT_F32) *reinterpret_cast<float4*>(reinterpret_cast<float*>(dst) + o) = v;
+                else {
+                    uint2 u;
+                    u.x = (uint32_t)f2bf(v.x) | ((uint32_t)f2bf(v.y) << 16);
+                    u.y = (uint32_t)f2bf(v.z) | ((uint32_t)f2bf(v.w) << 16);
+                    *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(dst) + o) = u;
+                }
+            }
+        } else {
+            tile[kk][4 * tx] = v.x; tile[kk][4 * tx + 1] = v.y; tile[kk][4 * tx + 2] = v.z; tile[kk][4 * tx + 3] = v.w;
+        }
+    }
+    if (!d.transpose) return;
+    __syncthreads();
+    // transposed write: row n of the destination holds k contiguous; 8 threads x 4 k-values per row
+    const int kq = (threadIdx.x & 7) * 4;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int nl = (threadIdx.x >> 3) + 32 * j, nn = n0 + nl, k = k0 + kq;
+        if (nn < Np && k < Kp) {
+            const long o = (long)nn * d.ld_dst + k;
+            const float a0 = tile[kq][nl], a1 = tile[kq + 1][nl], a2 = tile[kq + 2][nl], a3 = tile[kq + 3][nl];
+            if (d.dst_dt == DT_F32) *reinterpret_cast<float4*>(reinterpret_cast<float*>(dst) + o) = make_float4(a0, a1, a2, a3);
+            else {
+                uint2 u;
+                u.x = (uint32_t)f2bf(a0) | ((uint32_t)f2bf(a1) << 16);
+                u.y = (uint32_t)f2bf(a2) | ((uint32_t)f2bf(a3) << 16);
+                *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(dst) + o) = u;
+            }
         }
     }
 }

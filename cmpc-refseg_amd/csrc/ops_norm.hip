@@ -171,6 +171,26 @@ __global__ __launch_bounds__(256) void rank1_kernel(T* __restrict__ x, const flo
     }
 }
 
+
+// y = relu?(y + bias[c] (+ res))  on an NHWC map [R, C] (C % 8 == 0): the frozen-BN shift, the
+// residual add and the ReLU of a DeepLab-ResNet bottleneck in one pass over the conv output.
+template <typename T>
+__global__ void bias_act_res_kernel(T* __restrict__ y, const float* __restrict__ bias, const T* __restrict__ res, int relu, long n8, int C) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (long)gridDim.x * blockDim.x) {
+        const int c0 = (int)((i * 8) % C);
+        float v[8], r[8];
+        ld8<T>(y + i * 8, v);
+        if (res) ld8<T>(res + i * 8, r);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            float x = v[e] + bias[c0 + e];
+            if (res) x += r[e];
+            v[e] = relu ? fmaxf(x, 0.f) : x;
+        }
+        st8<T>(y + i * 8, v);
+    }
+}
+
 // ------------------------------------------------------------------------------------------
 // l2_normalize over channels.  rstd is stored NEGATIVE when sum(x^2) < eps (clamped branch:
 // y = x / sqrt(eps) and d y / d x is the constant 1/sqrt(eps)).
@@ -523,6 +543,15 @@ extern "C" int cmpc_axpy(int dt, const void* x, void* y, float a, int64_t n, voi
     const int g = (int)((n8 + 255) / 256 > 4096 ? 4096 : (n8 + 255) / 256);
     CMPC_DISPATCH_DT(dt, hipLaunchKernelGGL((axpy_kernel<T>), dim3(g), dim3(256), 0, ST, (const T*)x, (T*)y, a, n8));
     return cmpc_check_launch("axpy");
+}
+
+extern "C" int cmpc_bias_act_res(int dt, void* y, const float* bias, const void* res, int relu, int64_t R, int C, void* stream) {
+    if (C <= 0 || C % 8 || !y || !bias) { cmpc_set_error("bias_act_res: C must be a positive multiple of 8"); return CMPC_EINVAL; }
+    const long n8 = R * C / 8;
+    if (n8 == 0) return CMPC_OK;
+    const int g = (int)((n8 + 255) / 256 > 8192 ? 8192 : (n8 + 255) / 256);
+    CMPC_DISPATCH_DT(dt, hipLaunchKernelGGL((bias_act_res_kernel<T>), dim3(g), dim3(256), 0, ST, (T*)y, bias, (const T*)res, relu, n8, C));
+    return cmpc_check_launch("bias_act_res");
 }
 
 extern "C" int cmpc_act_bwd(int dt, const void* dy, const void* y, void* dpre, int act, int R, int stride, int ld, int C,

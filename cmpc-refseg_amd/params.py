@@ -339,7 +339,8 @@ class ParamStore:
         self.ndesc = n
         pref = np.zeros(n + 1, dtype=np.int32)
         for i, d in enumerate(self._descs):
-            pref[i + 1] = pref[i] + ((d.rows + 31) // 32) * ((d.cols + 31) // 32)
+            kp, np_ = (d.cols, d.rows) if d.transpose else (d.rows, d.cols)
+            pref[i + 1] = pref[i] + ((kp + 31) // 32) * ((np_ + 127) // 128)
         self.tile_prefix = torch.from_numpy(pref).to(self.device)
         self.total_tiles = int(pref[-1])
         # Adam segments: <= 8192 elements each, inside one parameter

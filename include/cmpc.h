@@ -78,6 +78,9 @@ int cmpc_rowdot1(int dt, const void* x, const float* v, int ld_v, float* s, int 
 /* x[b,n,:] += s1*w1[b,n]*v1[b,:] + s2*w2[b,n]*v2[b,:]  (w2/v2 optional) */
 int cmpc_rank1_update(int dt, void* x, const float* w1, const float* v1, const float* w2, const float* v2,
                       int ld_v, float s1, float s2, int B, int N, int ld, int C, void* stream);
+/* backbone epilogue (deeplab_resnet/model.py bottlenecks; network.py:260-270,194-201,233-235): in place
+ * y = relu?(y + bias[c] (+ res)) on an NHWC conv output [R, C]; bias = the folded frozen batch-norm shift */
+int cmpc_bias_act_res(int dt, void* y, const float* bias, const void* res, int relu, int64_t R, int C, void* stream);
 /* y (+)= x elementwise on maps */
 int cmpc_axpy(int dt, const void* x, void* y, float a, int64_t n, void* stream);
 
@@ -205,8 +208,9 @@ typedef struct {
     int nks; int ks_src[4], ks_len[4], ks_dst[4];   /* K segments: src row range -> dst k offset */
     int nns; int ns_src[5], ns_len[5], ns_dst[5];   /* N blocks:   src col range -> dst n offset */
 } cmpc_pack_desc;
-/* tile_prefix_dev[i] = number of 32x32 tiles of descriptors 0..i-1 (exclusive prefix sum, ndesc+1 entries
- * with tile count = ceil(K/32)*ceil(N/32) of each padded block); total_tiles = tile_prefix[ndesc] */
+/* tile_prefix_dev[i] = number of 32(k) x 128(n) tiles of descriptors 0..i-1 (exclusive prefix sum, ndesc+1
+ * entries; tile count = ceil(K/32)*ceil(N/128) of each padded block); total_tiles = tile_prefix[ndesc].
+ * Every K/N segment boundary, ld_src and src_off must be a multiple of 4 (float4 reads). */
 int cmpc_pack_weights(const float* master, void* arena, const cmpc_pack_desc* descs_dev, const int* tile_prefix_dev,
                       int ndesc, int total_tiles, void* stream);
 
