@@ -59,6 +59,15 @@ class GemmTnArgs(C.Structure):
     ]
 
 
+class ConvArgs(C.Structure):
+    _fields_ = [
+        ("dtype", C.c_int), ("X", C.c_void_p), ("ldx", C.c_int), ("Wt", C.c_void_p), ("ldw", C.c_int),
+        ("bias", C.c_void_p), ("res", C.c_void_p), ("Y", C.c_void_p), ("ldy", C.c_int),
+        ("B", C.c_int), ("H", C.c_int), ("W", C.c_int), ("Cin", C.c_int), ("Cout", C.c_int),
+        ("ksize", C.c_int), ("stride", C.c_int), ("dil", C.c_int), ("relu", C.c_int), ("zeros", C.c_void_p),
+    ]
+
+
 class ConvLstmLn(C.Structure):
     _fields_ = [("beta", C.c_void_p * 5), ("gamma", C.c_void_p * 5)]
 
@@ -87,6 +96,7 @@ _P, _I, _F, _L = C.c_void_p, C.c_int, C.c_float, C.c_int64
 SIGNATURES = {
     "cmpc_gemm_nt": [C.POINTER(GemmNtArgs), _P],
     "cmpc_gemm_tn": [C.POINTER(GemmTnArgs), _P],
+    "cmpc_conv_nhwc": [C.POINTER(ConvArgs), _P],
     "cmpc_cast": [_I, _P, _I, _P, _L, _P],
     "cmpc_act_bwd": [_I, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _I, _I, _P],
     "cmpc_wcolsum": [_I, _P, _P, _P, _I, _I, _I, _I, _I, _F, _P],
@@ -157,8 +167,14 @@ def load():
     return lib
 
 
+_DEBUG_SYNC = bool(os.environ.get("CMPC_DEBUG_SYNC"))
+
+
 def call(name: str, *args):
     lib = load()
     rc = getattr(lib, name)(*args)
     if rc != 0:
         raise CmpcError(f"{name} failed ({rc}): {lib.cmpc_last_error().decode()}")
+    if _DEBUG_SYNC:                      # CMPC_DEBUG_SYNC=1: surface an asynchronous fault at the launch that caused it
+        import torch
+        torch.cuda.synchronize()

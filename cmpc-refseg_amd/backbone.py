@@ -87,6 +87,10 @@ class _ConvBN(nn.Module):
         self.weight = nn.Parameter(torch.zeros(cout, cin, k, k), requires_grad=False)
         self.bias = nn.Parameter(torch.zeros(cout), requires_grad=False)
         self.register_buffer("bias32", torch.zeros(cout, dtype=torch.float32), persistent=False)
+        # [Cout][kh][kw][Cin]: the K-contiguous operand of the implicit-GEMM kernel (cmpc_conv_nhwc)
+        self.register_buffer("w_ohwi", torch.zeros(cout, k * k * cin), persistent=False)   # 2-D: immune to memory_format casts
+        self.register_buffer("zeros", torch.zeros(256, dtype=torch.uint8), persistent=False)
+        self.use_hip = k in (1, 3) and cin % 64 == 0 and cout % 8 == 0
 
     def load(self, p, conv, bn):
         sc = p[f"{bn}/gamma"].double() / torch.sqrt(p[f"{bn}/moving_variance"].double() + 1e-3)
@@ -95,15 +99,33 @@ class _ConvBN(nn.Module):
         self.weight.data.copy_(w.to(self.weight.dtype))
         self.bias.data.copy_(sh.to(self.bias.dtype))
         self.bias32.copy_(sh.float())
+        self.w_ohwi.copy_(w.permute(0, 2, 3, 1).reshape(w.shape[0], -1).to(self.w_ohwi.dtype))
 
     def _apply(self, fn, *a, **kw):
         out = super()._apply(fn, *a, **kw)
         self.bias32 = self.bias32.float()          # the epilogue kernel always reads an fp32 shift
+        self.zeros = self.zeros.to(torch.uint8)
         return out
 
     def forward(self, x, res=None):
-        """conv (MIOpen) then ONE fused HIP epilogue: + folded-BN shift (+ residual) (+ ReLU), in place."""
+        """Implicit-GEMM HIP convolution with the folded-BN shift, residual add and ReLU in its epilogue
+        (1x1 / 3x3 with Cin % 64 == 0); otherwise MIOpen conv + one fused HIP epilogue pass."""
         k, s, d = self.k, self.stride, self.dilation
+        if self.use_hip and x.is_cuda and x.is_contiguous(memory_format=torch.channels_last) and \
+                (res is None or res.is_contiguous(memory_format=torch.channels_last)):
+            B, Cin, H, W = x.shape
+            Ho, Wo, Cout = -(-H // s), -(-W // s), self.weight.shape[0]
+            y = torch.empty((B, Ho, Wo, Cout), dtype=x.dtype, device=x.device)
+            a = _lib.ConvArgs()
+            a.dtype = 0 if x.dtype == torch.float32 else 1
+            a.X, a.ldx = x.data_ptr(), Cin
+            a.Wt, a.ldw = self.w_ohwi.data_ptr(), k * k * Cin
+            a.bias, a.res = self.bias32.data_ptr(), (res.data_ptr() if res is not None else None)
+            a.Y, a.ldy = y.data_ptr(), Cout
+            a.B, a.H, a.W, a.Cin, a.Cout, a.ksize, a.stride, a.dil, a.relu = B, H, W, Cin, Cout, k, s, d, int(self.relu)
+            a.zeros = self.zeros.data_ptr()
+            _lib.call("cmpc_conv_nhwc", ctypes.byref(a), ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+            return y.permute(0, 3, 1, 2)                  # NCHW view of the NHWC buffer (= channels_last)
         pt, pb = _same_pad(x.shape[2], k, s, d)
         pl, pr = _same_pad(x.shape[3], k, s, d)
         if pt == pb and pl == pr:

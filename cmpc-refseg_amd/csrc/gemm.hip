@@ -374,6 +374,152 @@ __global__ __launch_bounds__(512) void gemm_nt_v2_kernel(const cmpc_gemm_nt_args
 }
 
 // ------------------------------------------------------------------------------------------
+// conv_v2: NHWC convolution (1x1 or 3x3, stride 1/2, dilation d, TF 'SAME') as an implicit GEMM on
+// the gemm_nt v2 pipeline: K walks (tap, Cin-slice); the weight side is a plain [Cout][taps*Cin]
+// K-contiguous matrix, the activation side re-addresses each output pixel's row per tap and points
+// out-of-image lanes at a page of zeros (LDS-DMA cannot zero-fill).  Epilogue: + folded-BN shift,
+// + residual, ReLU  (deeplab_resnet/model.py bottlenecks; kaffe/tensorflow/network.py:105-188,260-270).
+// ------------------------------------------------------------------------------------------
+template <typename T, int BM>
+__global__ __launch_bounds__(512) void conv_v2_kernel(const cmpc_conv_args p) {
+    constexpr int BN = 128;
+    constexpr int EPC = 16 / (int)sizeof(T);
+    constexpr int BK = BKB / (int)sizeof(T);
+    constexpr int WAVES_N = 2, WAVES_M = 4;
+    constexpr int TM = BM / WAVES_M / 16, TN = BN / WAVES_N / 16;
+    constexpr int STAGE = (BM + BN) * BKB;
+    constexpr int APW = BM / 8 / 8, BPW = BN / 8 / 8, LPT = APW + BPW;
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wid / WAVES_N, wn = wid % WAVES_N;
+    const int Ho = (p.H + p.stride - 1) / p.stride, Wo = (p.W + p.stride - 1) / p.stride;
+    const int M = p.B * Ho * Wo, N = p.Cout;
+    const int gx = (N + BN - 1) / BN, nwg = gridDim.x;
+    const int xq = nwg >> 3, xr = nwg & 7, xcd = blockIdx.x & 7, xi = blockIdx.x >> 3;
+    const int tix = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + xi;
+    const int m0 = (tix / gx) * BM, n0 = (tix % gx) * BN;
+    const int kpt = p.Cin / BK;                       // K-tiles per tap
+    const int ntot = p.ksize * p.ksize * kpt;
+    // TF SAME: total pad = max((out-1)*stride + (k-1)*dil + 1 - in, 0), before = total / 2
+    const int padh = max((Ho - 1) * p.stride + (p.ksize - 1) * p.dil + 1 - p.H, 0) / 2;
+    const int padw = max((Wo - 1) * p.stride + (p.ksize - 1) * p.dil + 1 - p.W, 0) / 2;
+
+    f4 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = f4{0.f, 0.f, 0.f, 0.f};
+
+    const int r8 = lane >> 3, slot = lane & 7;
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+    // this lane's output pixel for each of the wave's A pieces
+    int pb[APW], py[APW], px[APW], pc[APW];
+#pragma unroll
+    for (int j = 0; j < APW; ++j) {
+        const int blk = wid * APW + j, row = blk * 8 + r8;
+        const int gm = min(m0 + row, M - 1);
+        pb[j] = gm / (Ho * Wo);
+        const int rem = gm - pb[j] * (Ho * Wo);
+        py[j] = (rem / Wo) * p.stride - padh;
+        px[j] = (rem % Wo) * p.stride - padw;
+        pc[j] = (slot ^ ((row >> 1) & 7)) * EPC;
+    }
+    const T* X = reinterpret_cast<const T*>(p.X);
+    const T* Wt = reinterpret_cast<const T*>(p.Wt);
+    const T* Z = reinterpret_cast<const T*>(p.zeros);
+    auto issue = [&](int tile, int buf) {
+        const int tap = tile / kpt, k0 = (tile - tap * kpt) * BK;
+        const int dy = (tap / p.ksize) * p.dil, dx = (tap % p.ksize) * p.dil;
+        const uint32_t base = lds0 + buf * STAGE;
+#pragma unroll
+        for (int j = 0; j < APW; ++j) {
+            const int blk = wid * APW + j;
+            const int yi = py[j] + dy, xi2 = px[j] + dx;
+            const bool ok = yi >= 0 && yi < p.H && xi2 >= 0 && xi2 < p.W;
+            const T* g = ok ? X + ((long)(pb[j] * p.H + yi) * p.W + xi2) * p.ldx + k0 + pc[j] : Z + pc[j];
+            glds16(g, __builtin_amdgcn_readfirstlane(base + blk * 1024));
+        }
+#pragma unroll
+        for (int j = 0; j < BPW; ++j) {
+            const int blk = wid * BPW + j, row = blk * 8 + r8;
+            const int c = slot ^ ((row >> 1) & 7);
+            const int gn = min(n0 + row, N - 1);
+            glds16(Wt + (long)gn * p.ldw + tap * p.Cin + k0 + c * EPC, __builtin_amdgcn_readfirstlane(base + BM * BKB + blk * 1024));
+        }
+    };
+
+    if (ntot > 0) issue(0, 0);
+    if (ntot > 1) issue(1, 1);
+    const int fr = lane & 15, fq = lane >> 4;
+    int cur = 0;
+    for (int kt = 0; kt < ntot; ++kt) {
+        if (kt + 1 < ntot) wait_vmcnt<LPT>(); else wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();
+        if (kt + 2 < ntot) issue(kt + 2, cur == 0 ? 2 : cur - 1);
+        const char* sA = smem + cur * STAGE;
+        const char* sB = sA + BM * BKB;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            uint4 a[TM], b[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+                a[i] = *reinterpret_cast<const uint4*>(sA + nt_lds_off(wm * TM * 16 + i * 16 + fr, 4 * s + fq));
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+                b[j] = *reinterpret_cast<const uint4*>(sB + nt_lds_off(wn * TN * 16 + j * 16 + fr, 4 * s + fq));
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) acc[i][j] = Mma<T>::run(a[i], b[j], acc[i][j]);
+        }
+        cur = (cur == 2) ? 0 : cur + 1;
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+
+    constexpr int WR = TM * 16, WC = TN * 16;
+    float* slab = reinterpret_cast<float*>(smem) + wid * (WR * WC);
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = i * 16 + fq * 4 + r, col = j * 16 + fr;
+                slab[row * WC + (col ^ (((row >> 2) & 3) << 4))] = acc[i][j][r];
+            }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+    constexpr int LPR = WC / 4, RPP = 64 / LPR;
+    T* Y = reinterpret_cast<T*>(p.Y);
+    const T* Rs = reinterpret_cast<const T*>(p.res);
+    for (int pass = 0; pass < WR / RPP; ++pass) {
+        const int row = pass * RPP + lane / LPR, c4 = (lane % LPR) * 4;
+        const int gm = m0 + wm * WR + row, gn = n0 + wn * WC + c4;
+        if (gm >= M || gn >= N) continue;
+        const int sc = c4 ^ (((row >> 2) & 3) << 4);
+        const float4 v4 = *reinterpret_cast<const float4*>(slab + row * WC + sc);
+        float v[4] = {v4.x, v4.y, v4.z, v4.w};
+        const long off = (long)gm * p.ldy + gn;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float x = v[e] + p.bias[gn + e];
+            if (Rs) x += Elem<T>::ld(Rs + off + e);
+            v[e] = p.relu ? fmaxf(x, 0.f) : x;
+        }
+        if constexpr (sizeof(T) == 4) {
+            *reinterpret_cast<float4*>(Y + off) = make_float4(v[0], v[1], v[2], v[3]);
+        } else {
+            uint2 o;
+            o.x = (uint32_t)f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16);
+            o.y = (uint32_t)f2bf(v[2]) | ((uint32_t)f2bf(v[3]) << 16);
+            *reinterpret_cast<uint2*>(Y + off) = o;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // gemm_tn: out[k,n] += alpha * sum_r A[r,k] * D[r,n]
 // LDS image [BR][128 elems] per operand, 32-B segments XOR-swizzled so that the transposing
 // reads (ds_read_b64_tr_b16 for bf16, ds_read_b32 for f32) of 8 rows x 32 B are conflict-free.
@@ -629,6 +775,37 @@ extern "C" int cmpc_gemm_nt(const cmpc_gemm_nt_args* a, void* stream) {
         else hipLaunchKernelGGL((gemm_nt_kernel<bf16_t, 64>), grid, dim3(256), lds, st, *a);
     } else { cmpc_set_error("gemm_nt: bad dtype"); return CMPC_EINVAL; }
     return cmpc_check_launch("gemm_nt");
+}
+
+
+template <typename T>
+static int launch_conv(const cmpc_conv_args* a, hipStream_t st) {
+    const int Ho = (a->H + a->stride - 1) / a->stride, Wo = (a->W + a->stride - 1) / a->stride;
+    const long M = (long)a->B * Ho * Wo;
+    const int gn = (a->Cout + 127) / 128;
+    const bool big = ((M + 255) / 256) * gn >= 384;
+    if (big) {
+        static bool attr = false;
+        if (!attr) { (void)hipFuncSetAttribute((const void*)conv_v2_kernel<T, 256>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * (256 + 128) * BKB); attr = true; }
+        hipLaunchKernelGGL((conv_v2_kernel<T, 256>), dim3((unsigned)(((M + 255) / 256) * gn)), dim3(512), 3 * (256 + 128) * BKB, st, *a);
+    } else {
+        static bool attr = false;
+        if (!attr) { (void)hipFuncSetAttribute((const void*)conv_v2_kernel<T, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * (128 + 128) * BKB); attr = true; }
+        hipLaunchKernelGGL((conv_v2_kernel<T, 128>), dim3((unsigned)(((M + 127) / 128) * gn)), dim3(512), 3 * (128 + 128) * BKB, st, *a);
+    }
+    return cmpc_check_launch("conv_nhwc");
+}
+
+extern "C" int cmpc_conv_nhwc(const cmpc_conv_args* a, void* stream) {
+    if (!a || !a->X || !a->Wt || !a->Y || !a->bias || !a->zeros || a->B <= 0 || a->H <= 0 || a->W <= 0) { cmpc_set_error("conv_nhwc: bad args"); return CMPC_EINVAL; }
+    const int esz = a->dtype == DT_F32 ? 4 : 2, bk = BKB / esz;
+    if ((a->ksize != 1 && a->ksize != 3) || (a->stride != 1 && a->stride != 2) || a->dil < 1 || a->Cin % bk || a->Cout % 4 ||
+        (a->ldx * esz) % 16 || (a->ldw * esz) % 16 || a->ldy % 4) {
+        cmpc_set_error("conv_nhwc: need k in {1,3}, stride in {1,2}, Cin %% %d == 0, Cout %% 4 == 0, 16-B aligned rows", bk); return CMPC_EINVAL;
+    }
+    if (a->dtype == DT_F32) return launch_conv<float>(a, (hipStream_t)stream);
+    if (a->dtype == DT_BF16) return launch_conv<bf16_t>(a, (hipStream_t)stream);
+    cmpc_set_error("conv_nhwc: bad dtype"); return CMPC_EINVAL;
 }
 
 extern "C" int cmpc_gemm_tn(const cmpc_gemm_tn_args* a, void* stream) {

@@ -63,6 +63,22 @@ typedef struct {
 } cmpc_gemm_tn_args;
 int cmpc_gemm_tn(const cmpc_gemm_tn_args* a, void* stream);
 
+/* ---- backbone convolutions as implicit GEMM (deeplab_resnet/model.py:19-401; network.py:105-188 conv /
+ *      atrous_conv 'SAME', :260-270 frozen batch_norm folded into Wt and bias, :194-201,233-235 relu / add).
+ *      X [B,H,W,Cin] NHWC (row stride ldx), Wt [Cout][k*k*Cin] (tap-major, Cin fastest), Y / res [B,Ho,Wo,Cout];
+ *      zeros: >= 256 bytes of device zeros (source for out-of-image taps). ------------------------------- */
+typedef struct {
+    int dtype;
+    const void* X; int ldx;
+    const void* Wt; int ldw;
+    const float* bias;
+    const void* res;            /* optional residual added before the ReLU */
+    void* Y; int ldy;
+    int B, H, W, Cin, Cout, ksize, stride, dil, relu;
+    const void* zeros;
+} cmpc_conv_args;
+int cmpc_conv_nhwc(const cmpc_conv_args* a, void* stream);
+
 /* ---- utilities ---------------------------------------------------------------------------- */
 int cmpc_cast(int src_dt, const void* src, int dst_dt, void* dst, int64_t n, void* stream);
 /* act'(y) applied to a gradient, plus column sums:  dpre = dy * act'(y);  db[c] += sum_r dpre

@@ -1,0 +1,70 @@
+"""GPU tests of the backbone path: the implicit-GEMM HIP convolution (cmpc_conv_nhwc) against
+torch.nn.functional.conv2d with explicit TF-SAME padding, and the whole DeepLab-ResNet against the oracle."""
+import importlib
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from tests import util as U
+from tests.util import O
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-5), (torch.bfloat16, 2e-2)])
+def test_conv_nhwc_matches_torch(dtype, tol):
+    bb = importlib.import_module("cmpc-refseg_amd.backbone")
+    dev = torch.device("cuda:0")
+    torch.manual_seed(0)
+    for (k, cin, cout, stride, dil, hw, B, with_res, relu) in (
+            (1, 64, 256, 1, 1, 20, 2, False, False), (1, 256, 64, 1, 1, 20, 2, False, True), (3, 64, 64, 1, 1, 20, 2, False, True),
+            (1, 256, 128, 2, 1, 20, 2, False, True), (3, 128, 128, 1, 2, 12, 3, False, True), (3, 64, 128, 1, 4, 10, 1, False, True),
+            (1, 128, 512, 1, 1, 12, 3, True, True), (3, 256, 256, 1, 2, 40, 8, False, True), (1, 192, 72, 2, 1, 9, 2, True, False)):
+        m = bb._ConvBN(k, cin, cout, stride, dil, relu=relu)
+        w = torch.randn(k, k, cin, cout) * (2.0 / (k * k * cin)) ** 0.5
+        p = {"c/weights": w, "b/gamma": torch.rand(cout) + 0.5, "b/beta": torch.randn(cout) * 0.1,
+             "b/moving_mean": torch.randn(cout) * 0.1, "b/moving_variance": torch.rand(cout) + 0.5}
+        m.load(p, "c", "b")
+        m = m.to(dev).to(dtype).to(memory_format=torch.channels_last)
+        assert m.use_hip
+        x = torch.randn(B, cin, hw, hw, device=dev).to(dtype).contiguous(memory_format=torch.channels_last)
+        ho = -(-hw // stride)
+        res = torch.randn(B, cout, ho, ho, device=dev).to(dtype).contiguous(memory_format=torch.channels_last) if with_res else None
+        y = m(x, res)
+        # reference: fp32 conv of the same (rounded) operands with explicit SAME padding
+        pt, pb = bb._same_pad(hw, k, stride, dil)
+        ref = F.conv2d(F.pad(x.float(), (pt, pb, pt, pb)), m.weight.float(), m.bias32, stride=stride, dilation=dil)
+        if res is not None:
+            ref = ref + res.float()
+        if relu:
+            ref = torch.relu(ref)
+        assert y.shape == ref.shape
+        assert U.rel_err(y.float().cpu(), ref.cpu()) < tol, (k, cin, cout, stride, dil)
+
+
+def test_backbone_matches_oracle():
+    cfg = U.tiny_cfg()
+    bp = O.init_backbone_params(cfg)
+    _, im, _, _ = O.synth_batch(cfg)
+    ref = O.backbone_forward(bp, im, cfg)
+    bb = importlib.import_module("cmpc-refseg_amd.backbone")
+    net = bb.DeepLabResNet(cfg.backbone_width, cfg.backbone_blocks)
+    net.load_tf(bp)
+    net = net.to("cuda:0").to(memory_format=torch.channels_last).eval()
+    out = net(im.to("cuda:0"))
+    for a, b in zip(out, ref):
+        assert tuple(a.shape) == tuple(b.shape)
+        assert U.rel_err(a.float().cpu(), b) < 1e-4
+    # full width, fp32, one image: the HIP convolutions carry 100 of the 104 layers
+    cfg2 = O.Cfg(batch_size=1)
+    bp2 = O.init_backbone_params(cfg2)
+    _, im2, _, _ = O.synth_batch(cfg2)
+    torch.set_num_threads(8)
+    ref2 = O.backbone_forward(bp2, im2, cfg2)
+    net2 = bb.DeepLabResNet()
+    net2.load_tf(bp2)
+    net2 = net2.to("cuda:0").to(memory_format=torch.channels_last).eval()
+    out2 = net2(im2.to("cuda:0"))
+    for a, b in zip(out2, ref2):
+        assert U.rel_err(a.float().cpu(), b) < 2e-4
