@@ -109,8 +109,8 @@ SIGNATURES = {
     "cmpc_sample_stats": [_I, _P, _P, _I, _I, _I, _I, _P],
     "cmpc_mutan_fwd": [_I, _P, _P, _P, _P, _I, _I, _I, _I, _P],
     "cmpc_mutan_bwd": [_I, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
-    "cmpc_graph_softmax_fwd": [_I, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
-    "cmpc_graph_softmax_bwd": [_I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
+    "cmpc_graph_softmax_fwd": [_I, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
+    "cmpc_graph_softmax_bwd": [_I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
     "cmpc_gconv_pre_fwd": [_I, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
     "cmpc_gconv_pre_bwd": [_I, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _I, _I, _I, _I, _P],
     "cmpc_gconv_post_fwd": [_I, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P],

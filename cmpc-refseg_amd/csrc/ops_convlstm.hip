@@ -259,7 +259,6 @@ __global__ __launch_bounds__(256) void clstm_bwd2_kernel(const T* __restrict__ Y
                         float dc = rc * (dxc[e] - c_m1 - xhc * c_m2);
                         const float wco = W_co[(long)n * M + m];
                         dc += dop * wco;
-                        atomicAdd(dW_co + (long)n * M + m, dop * cp[e]);
                         dxo[e] = dop;
                         const float xhj = (j[e] - mj) * rj, xhi = (i[e] - mi) * ri, xhf = (f[e] - mf) * rf;
                         const float jn = xhj * ln.gamma[0][m] + ln.beta[0][m];
@@ -322,15 +321,48 @@ __global__ __launch_bounds__(256) void clstm_bwd3_kernel(const T* __restrict__ Y
                     const float xh = (x[q][e] - mean[q]) * rstd[q];
                     d[q][e] = (m < M) ? rstd[q] * (d[q][e] - m1[q] - xh * m2[q]) : 0.f;
                 }
-                if (c_prev && m < M) {
-                    atomicAdd(dW_ci + (long)n * M + m, d[1][e] * c[e]);
-                    atomicAdd(dW_cf + (long)n * M + m, d[2][e] * c[e]);
-                    dcp[e] += d[1][e] * W_ci[(long)n * M + m] + d[2][e] * W_cf[(long)n * M + m];
-                }
+                if (c_prev && m < M) dcp[e] += d[1][e] * W_ci[(long)n * M + m] + d[2][e] * W_cf[(long)n * M + m];
             }
 #pragma unroll
             for (int q = 0; q < 3; ++q) st8<T>(dYg + r * 4 * ld + q * ld + c0, d[q]);
             if (c_prev) st8<T>(dc_prev + r * ld + c0, dcp);
+        }
+    }
+}
+
+
+// ---- peephole gradients: dW_c*[n,m] += sum_b dgate[b,n,m] * c[b,n,m]; one wave per spatial row n,
+// the batch loop inside, so no atomics (the three time steps are sequential launches) --------------
+template <typename T>
+__global__ __launch_bounds__(256) void clstm_peephole_grad_kernel(const T* __restrict__ dYg, const T* __restrict__ c_prev, const T* __restrict__ c_pre,
+                                                                 float* __restrict__ dW_ci, float* __restrict__ dW_cf, float* __restrict__ dW_co,
+                                                                 int B, int N, int ld, int M) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    for (int n = blockIdx.x * WPB + w; n < N; n += gridDim.x * WPB) {
+        for (int c0 = lane * 8; c0 < ld; c0 += 512) {
+            float ai[8], af[8], ao[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { ai[e] = af[e] = ao[e] = 0.f; }
+            for (int b = 0; b < B; ++b) {
+                const long r = (long)b * N + n;
+                float di[8], df[8], dop[8], cp[8], cq[8];
+                ld8<T>(dYg + r * 4 * ld + 3 * ld + c0, dop); ld8<T>(c_pre + r * ld + c0, cq);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) ao[e] += dop[e] * cq[e];
+                if (c_prev) {
+                    ld8<T>(dYg + r * 4 * ld + ld + c0, di); ld8<T>(dYg + r * 4 * ld + 2 * ld + c0, df); ld8<T>(c_prev + r * ld + c0, cp);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) { ai[e] += di[e] * cp[e]; af[e] += df[e] * cp[e]; }
+                }
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int m = c0 + e;
+                if (m < M) {
+                    dW_co[(long)n * M + m] += ao[e];
+                    if (c_prev) { dW_ci[(long)n * M + m] += ai[e]; dW_cf[(long)n * M + m] += af[e]; }
+                }
+            }
         }
     }
 }
@@ -351,7 +383,7 @@ extern "C" int cmpc_convlstm_a(int dt, void* Yg, const void* c_prev, const float
                                int B, int N, int ld, int M, void* stream) {
     if (!ok("convlstm_a", dt, ld, M)) return CMPC_EINVAL;
     if (hipMemsetAsync(sums, 0, sizeof(double) * 5 * B * 2, ST) != hipSuccess) { cmpc_set_error("convlstm_a: memset"); return CMPC_EHIP; }
-    CMPC_DISPATCH_DT(dt, hipLaunchKernelGGL((clstm_a_kernel<T>), dim3(rows_grid(N, 64), B), dim3(256), 0, ST,
+    CMPC_DISPATCH_DT(dt, hipLaunchKernelGGL((clstm_a_kernel<T>), dim3(rows_grid(N, 200), B), dim3(256), 0, ST,
                                              (T*)Yg, (const T*)c_prev, W_ci, W_cf, sums, B, N, ld, M));
     return cmpc_check_launch("convlstm_a");
 }
@@ -359,7 +391,7 @@ extern "C" int cmpc_convlstm_a(int dt, void* Yg, const void* c_prev, const float
 extern "C" int cmpc_convlstm_b(int dt, void* Yg, const void* c_prev, const float* W_co, const cmpc_convlstm_ln* ln,
                                double* sums, void* c_pre, int B, int N, int ld, int M, void* stream) {
     if (!ok("convlstm_b", dt, ld, M)) return CMPC_EINVAL;
-    CMPC_DISPATCH_DT(dt, hipLaunchKernelGGL((clstm_b_kernel<T>), dim3(rows_grid(N, 64), B), dim3(256), 0, ST,
+    CMPC_DISPATCH_DT(dt, hipLaunchKernelGGL((clstm_b_kernel<T>), dim3(rows_grid(N, 200), B), dim3(256), 0, ST,
                                              (T*)Yg, (const T*)c_prev, W_co, to_lnp(ln), sums, (T*)c_pre, B, N, ld, M));
     return cmpc_check_launch("convlstm_b");
 }
@@ -367,7 +399,7 @@ extern "C" int cmpc_convlstm_b(int dt, void* Yg, const void* c_prev, const float
 extern "C" int cmpc_convlstm_c(int dt, const void* Yg, const void* c_pre, const cmpc_convlstm_ln* ln, const double* sums,
                                void* c_new, void* h, int B, int N, int ld, int M, void* stream) {
     if (!ok("convlstm_c", dt, ld, M)) return CMPC_EINVAL;
-    CMPC_DISPATCH_DT(dt, hipLaunchKernelGGL((clstm_c_kernel<T>), dim3(rows_grid(N, 64), B), dim3(256), 0, ST,
+    CMPC_DISPATCH_DT(dt, hipLaunchKernelGGL((clstm_c_kernel<T>), dim3(rows_grid(N, 200), B), dim3(256), 0, ST,
                                              (const T*)Yg, (const T*)c_pre, to_lnp(ln), sums, (T*)c_new, (T*)h, B, N, ld, M));
     return cmpc_check_launch("convlstm_c");
 }
@@ -381,13 +413,15 @@ extern "C" int cmpc_convlstm_bwd(int dt, const void* dh, const void* dc_new, con
     if (hipMemsetAsync(bsums, 0, sizeof(double) * 5 * B * 2, ST) != hipSuccess) { cmpc_set_error("convlstm_bwd: memset"); return CMPC_EHIP; }
     const size_t lds = WPB * ld * sizeof(float);
     CMPC_DISPATCH_DT(dt, {
-        hipLaunchKernelGGL((clstm_bwd1_kernel<T>), dim3(rows_grid(N, 32), B), dim3(256), lds, ST,
+        hipLaunchKernelGGL((clstm_bwd1_kernel<T>), dim3(rows_grid(N, 100), B), dim3(256), lds, ST,
                            (const T*)dh, (const T*)dc_new, (const T*)Yg, (const T*)c_pre, to_lnp(ln), sums, (T*)dYg, (T*)scr, to_lng(dln), bsums, B, N, ld, M);
-        hipLaunchKernelGGL((clstm_bwd2_kernel<T>), dim3(rows_grid(N, 32), B), dim3(256), lds, ST,
+        hipLaunchKernelGGL((clstm_bwd2_kernel<T>), dim3(rows_grid(N, 100), B), dim3(256), lds, ST,
                            (const T*)Yg, (const T*)c_prev, (const T*)c_pre, W_co, to_lnp(ln), sums, bsums, (T*)dYg, (const T*)scr, (T*)dc_prev,
                            dW_co, to_lng(dln), bsums, B, N, ld, M);
-        hipLaunchKernelGGL((clstm_bwd3_kernel<T>), dim3(rows_grid(N, 64), B), dim3(256), 0, ST,
+        hipLaunchKernelGGL((clstm_bwd3_kernel<T>), dim3(rows_grid(N, 200), B), dim3(256), 0, ST,
                            (const T*)Yg, (const T*)c_prev, W_ci, W_cf, sums, bsums, (T*)dYg, (T*)dc_prev, dW_ci, dW_cf, B, N, ld, M);
+        hipLaunchKernelGGL((clstm_peephole_grad_kernel<T>), dim3(rows_grid(N, 512)), dim3(256), 0, ST,
+                           (const T*)dYg, (const T*)c_prev, (const T*)c_pre, dW_ci, dW_cf, dW_co, B, N, ld, M);
     });
     return cmpc_check_launch("convlstm_bwd");
 }

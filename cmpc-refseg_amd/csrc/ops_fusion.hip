@@ -153,30 +153,35 @@ __global__ __launch_bounds__(256) void mutan_bwd_kernel(T* __restrict__ Th, cons
 // ------------------------------------------------------------------------------------------
 constexpr float F32_MIN = -3.4028234663852886e38f;     // tf.float32.min
 
+// Chunked over the N nodes: grid (chunks, B), 4 waves per workgroup, one node row per wave step,
+// lane = word index.  Pass 1 writes gw_w and per-chunk online column statistics (max, sum exp);
+// pass 2 folds the chunk statistics and writes gw_v.  (One workgroup per sample was 8 workgroups
+// on a 256-CU chip.)
+constexpr int GS_ROWS = 64;     // node rows per workgroup
+
 template <typename T>
-__global__ __launch_bounds__(1024) void graph_softmax_fwd_kernel(const float* __restrict__ A0, const float* __restrict__ pr, const float* __restrict__ mask,
-                                                                float* __restrict__ gw_w, float* __restrict__ gw_v, T* __restrict__ gw_w_t, T* __restrict__ gw_v_t,
+__global__ __launch_bounds__(256) void graph_softmax_fwd1_kernel(const float* __restrict__ A0, const float* __restrict__ pr, const float* __restrict__ mask,
+                                                                float* __restrict__ gw_w, T* __restrict__ gw_w_t, float* __restrict__ cstat,
                                                                 int N, int Tn, int Tp) {
-    __shared__ float cmax[16][64], csum[16][64];
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, b = blockIdx.x;
+    __shared__ float cmax[4][64], csum[4][64];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, b = blockIdx.y, ch = blockIdx.x;
     const bool tv = lane < Tn;
     const float prt = tv ? pr[b * Tn + lane] : 0.f;
     const float mk = tv ? mask[b * Tn + lane] : 0.f;
     const long sb = (long)b * N * Tp;
     float m_run = -INFINITY, s_run = 0.f;
-    for (int n = w; n < N; n += 16) {
+    const int n1 = min(N, (ch + 1) * GS_ROWS);
+    for (int n = ch * GS_ROWS + w; n < n1; n += 4) {
         const float a = tv ? prt * A0[sb + (long)n * Tp + lane] : 0.f;
-        // row softmax over t (masked)
         const float lg = tv ? (mk * a + (1.f - mk) * F32_MIN) : -INFINITY;
         const float mx = wave_max(lg);
         const float ex = tv ? expf(lg - mx) : 0.f;
         const float sm = wave_sum(ex);
-        const float p = ex / sm;
+        const float pz = ex / sm;
         if (lane < Tp) {
-            gw_w[sb + (long)n * Tp + lane] = p;
-            Elem<T>::st(gw_w_t + sb + (long)n * Tp + lane, p);
+            gw_w[sb + (long)n * Tp + lane] = pz;
+            Elem<T>::st(gw_w_t + sb + (long)n * Tp + lane, pz);
         }
-        // online column statistics over n
         if (tv) {
             const float mn = fmaxf(m_run, a);
             s_run = s_run * expf(m_run - mn) + expf(a - mn);
@@ -185,13 +190,36 @@ __global__ __launch_bounds__(1024) void graph_softmax_fwd_kernel(const float* __
     }
     cmax[w][lane] = m_run; csum[w][lane] = s_run;
     __syncthreads();
-    float M = -INFINITY;
+    if (w == 0) {
+        float M = fmaxf(fmaxf(cmax[0][lane], cmax[1][lane]), fmaxf(cmax[2][lane], cmax[3][lane]));
+        float S = 0.f;
 #pragma unroll
-    for (int i = 0; i < 16; ++i) M = fmaxf(M, cmax[i][lane]);
-    float S = 0.f;
-#pragma unroll
-    for (int i = 0; i < 16; ++i) S += (cmax[i][lane] == -INFINITY) ? 0.f : csum[i][lane] * expf(cmax[i][lane] - M);
-    for (int n = w; n < N; n += 16) {
+        for (int i = 0; i < 4; ++i) S += (cmax[i][lane] == -INFINITY) ? 0.f : csum[i][lane] * expf(cmax[i][lane] - M);
+        float* st = cstat + (((long)b * gridDim.x + ch) * 64 + lane) * 2;
+        st[0] = M; st[1] = S;
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void graph_softmax_fwd2_kernel(const float* __restrict__ A0, const float* __restrict__ pr, const float* __restrict__ mask,
+                                                                const float* __restrict__ cstat, float* __restrict__ gw_v, T* __restrict__ gw_v_t,
+                                                                int N, int Tn, int Tp) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, b = blockIdx.y, ch = blockIdx.x;
+    const bool tv = lane < Tn;
+    const float prt = tv ? pr[b * Tn + lane] : 0.f;
+    const float mk = tv ? mask[b * Tn + lane] : 0.f;
+    const long sb = (long)b * N * Tp;
+    float M = -INFINITY, S = 0.f;
+    for (int c = 0; c < (int)gridDim.x; ++c) {
+        const float* st = cstat + (((long)b * gridDim.x + c) * 64 + lane) * 2;
+        const float m2 = st[0], s2 = st[1];
+        if (m2 == -INFINITY) continue;
+        const float mn = fmaxf(M, m2);
+        S = S * expf(M - mn) + s2 * expf(m2 - mn);
+        M = mn;
+    }
+    const int n1 = min(N, (ch + 1) * GS_ROWS);
+    for (int n = ch * GS_ROWS + w; n < n1; n += 4) {
         float v = 0.f;
         if (tv) v = expf(prt * A0[sb + (long)n * Tp + lane] - M) / S * mk;
         if (lane < Tp) {
@@ -201,38 +229,47 @@ __global__ __launch_bounds__(1024) void graph_softmax_fwd_kernel(const float* __
     }
 }
 
+// backward pass 1: per-chunk column dots  sum_n gw_v * dgw_v * mask
+__global__ __launch_bounds__(256) void graph_softmax_bwd1_kernel(const float* __restrict__ dgw_v, const float* __restrict__ gw_v,
+                                                                const float* __restrict__ mask, float* __restrict__ cdot, int N, int Tn, int Tp) {
+    __shared__ float red[4][64];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, b = blockIdx.y, ch = blockIdx.x;
+    const bool tv = lane < Tn;
+    const float mk = tv ? mask[b * Tn + lane] : 0.f;
+    const long sb = (long)b * N * Tp;
+    float cd = 0.f;
+    const int n1 = min(N, (ch + 1) * GS_ROWS);
+    for (int n = ch * GS_ROWS + w; n < n1; n += 4)
+        if (tv) cd += gw_v[sb + (long)n * Tp + lane] * dgw_v[sb + (long)n * Tp + lane] * mk;
+    red[w][lane] = cd;
+    __syncthreads();
+    if (w == 0) cdot[((long)b * gridDim.x + ch) * 64 + lane] = red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane];
+}
+
 template <typename T>
-__global__ __launch_bounds__(1024) void graph_softmax_bwd_kernel(const float* __restrict__ dgw_w, const float* __restrict__ dgw_v,
+__global__ __launch_bounds__(256) void graph_softmax_bwd2_kernel(const float* __restrict__ dgw_w, const float* __restrict__ dgw_v,
                                                                 const float* __restrict__ gw_w, const float* __restrict__ gw_v,
                                                                 const float* __restrict__ A0, const float* __restrict__ pr, const float* __restrict__ mask,
-                                                                float* __restrict__ dA0, T* __restrict__ dA0_t, float* __restrict__ dpr,
-                                                                int N, int Tn, int Tp) {
-    __shared__ float red[16][64];
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, b = blockIdx.x;
+                                                                const float* __restrict__ cdot, float* __restrict__ dA0, T* __restrict__ dA0_t,
+                                                                float* dpr, int N, int Tn, int Tp) {
+    __shared__ float red[4][64];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, b = blockIdx.y, ch = blockIdx.x;
     const bool tv = lane < Tn;
     const float prt = tv ? pr[b * Tn + lane] : 0.f;
     const float mk = tv ? mask[b * Tn + lane] : 0.f;
     const long sb = (long)b * N * Tp;
-    // column dots  sum_n sv * dsv   (sv = gw_v where mask = 1; masked columns contribute 0)
-    float cd = 0.f;
-    for (int n = w; n < N; n += 16)
-        if (tv) cd += gw_v[sb + (long)n * Tp + lane] * dgw_v[sb + (long)n * Tp + lane] * mk;
-    red[w][lane] = cd;
-    __syncthreads();
     float CD = 0.f;
-#pragma unroll
-    for (int i = 0; i < 16; ++i) CD += red[i][lane];
-    __syncthreads();
+    for (int c = 0; c < (int)gridDim.x; ++c) CD += cdot[((long)b * gridDim.x + c) * 64 + lane];
     float dp = 0.f;
-    for (int n = w; n < N; n += 16) {
+    const int n1 = min(N, (ch + 1) * GS_ROWS);
+    for (int n = ch * GS_ROWS + w; n < n1; n += 4) {
         const long o = sb + (long)n * Tp + lane;
         const float pw = tv ? gw_w[o] : 0.f, dw = tv ? dgw_w[o] : 0.f;
         const float rd = wave_sum(pw * dw);
         float dA = 0.f;
         if (tv) {
             dA = mk * pw * (dw - rd);
-            const float sv = gw_v[o];
-            dA += sv * (dgw_v[o] * mk - CD);
+            dA += gw_v[o] * (dgw_v[o] * mk - CD);
             dp += dA * A0[o];
         }
         if (lane < Tp) {
@@ -244,10 +281,8 @@ __global__ __launch_bounds__(1024) void graph_softmax_bwd_kernel(const float* __
     red[w][lane] = dp;
     __syncthreads();
     if (w == 0 && tv) {
-        float s = 0.f;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) s += red[i][lane];
-        dpr[b * Tn + lane] = s;
+        const float sdp = red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane];
+        if (sdp != 0.f) atomicAdd(dpr + b * Tn + lane, sdp);
     }
 }
 
@@ -418,31 +453,40 @@ bool map_ok(const char* what, int ld, int C, int dt) {
 
 extern "C" int cmpc_mutan_fwd(int dt, void* P, const float* g, void* X1, float* rstd, int B, int N, int ld, int C, void* stream) {
     if (!map_ok("mutan_fwd", ld, C, dt)) return CMPC_EINVAL;
-    CMPC_DISPATCH_DT(dt, hipLaunchKernelGGL((mutan_fwd_kernel<T>), dim3(rows_grid(N, 64), B), dim3(256), 0, ST, (T*)P, g, (T*)X1, rstd, N, ld, C));
+    CMPC_DISPATCH_DT(dt, hipLaunchKernelGGL((mutan_fwd_kernel<T>), dim3(rows_grid(N, 400), B), dim3(256), 0, ST, (T*)P, g, (T*)X1, rstd, N, ld, C));
     return cmpc_check_launch("mutan_fwd");
 }
 
 extern "C" int cmpc_mutan_bwd(int dt, void* Th, const float* g, const void* X1, const float* rstd, const void* dX1,
                               float* dg, int B, int N, int ld, int C, void* stream) {
     if (!map_ok("mutan_bwd", ld, C, dt)) return CMPC_EINVAL;
-    CMPC_DISPATCH_DT(dt, hipLaunchKernelGGL((mutan_bwd_kernel<T>), dim3(rows_grid(N, 32), B), dim3(256), WPB * ld * sizeof(float), ST,
+    CMPC_DISPATCH_DT(dt, hipLaunchKernelGGL((mutan_bwd_kernel<T>), dim3(rows_grid(N, 100), B), dim3(256), WPB * ld * sizeof(float), ST,
                                              (T*)Th, g, (const T*)X1, rstd, (const T*)dX1, dg, N, ld, C));
     return cmpc_check_launch("mutan_bwd");
 }
 
 extern "C" int cmpc_graph_softmax_fwd(int dt, const float* A0, const float* pr, const float* mask, float* gw_w, float* gw_v,
-                                      void* gw_w_t, void* gw_v_t, int B, int N, int T_, int Tp, void* stream) {
+                                      void* gw_w_t, void* gw_v_t, float* scratch, int B, int N, int T_, int Tp, void* stream) {
     if (T_ <= 0 || T_ > 64 || Tp < T_ || Tp > 64) { cmpc_set_error("graph_softmax: need 0 < T <= Tp <= 64"); return CMPC_EINVAL; }
-    CMPC_DISPATCH_DT(dt, hipLaunchKernelGGL((graph_softmax_fwd_kernel<T>), dim3(B), dim3(1024), 0, ST, A0, pr, mask, gw_w, gw_v, (T*)gw_w_t, (T*)gw_v_t, N, T_, Tp));
+    if (!scratch) { cmpc_set_error("graph_softmax: scratch (B*ceil(N/64)*128 floats) required"); return CMPC_EINVAL; }
+    const int ch = (N + GS_ROWS - 1) / GS_ROWS;
+    CMPC_DISPATCH_DT(dt, {
+        hipLaunchKernelGGL((graph_softmax_fwd1_kernel<T>), dim3(ch, B), dim3(256), 0, ST, A0, pr, mask, gw_w, (T*)gw_w_t, scratch, N, T_, Tp);
+        hipLaunchKernelGGL((graph_softmax_fwd2_kernel<T>), dim3(ch, B), dim3(256), 0, ST, A0, pr, mask, scratch, gw_v, (T*)gw_v_t, N, T_, Tp);
+    });
     return cmpc_check_launch("graph_softmax_fwd");
 }
 
 extern "C" int cmpc_graph_softmax_bwd(int dt, const float* dgw_w, const float* dgw_v, const float* gw_w, const float* gw_v,
                                       const float* A0, const float* pr, const float* mask, float* dA0, void* dA0_t, float* dpr,
-                                      int B, int N, int T_, int Tp, void* stream) {
+                                      float* scratch, int B, int N, int T_, int Tp, void* stream) {
     if (T_ <= 0 || T_ > 64 || Tp < T_ || Tp > 64) { cmpc_set_error("graph_softmax: need 0 < T <= Tp <= 64"); return CMPC_EINVAL; }
-    CMPC_DISPATCH_DT(dt, hipLaunchKernelGGL((graph_softmax_bwd_kernel<T>), dim3(B), dim3(1024), 0, ST, dgw_w, dgw_v, gw_w, gw_v, A0, pr, mask,
-                                             dA0, (T*)dA0_t, dpr, N, T_, Tp));
+    if (!scratch) { cmpc_set_error("graph_softmax: scratch (B*ceil(N/64)*128 floats) required"); return CMPC_EINVAL; }
+    const int ch = (N + GS_ROWS - 1) / GS_ROWS;
+    if (hipMemsetAsync(dpr, 0, sizeof(float) * B * T_, ST) != hipSuccess) { cmpc_set_error("graph_softmax_bwd: memset"); return CMPC_EHIP; }
+    hipLaunchKernelGGL(graph_softmax_bwd1_kernel, dim3(ch, B), dim3(256), 0, ST, dgw_v, gw_v, mask, scratch, N, T_, Tp);
+    CMPC_DISPATCH_DT(dt, hipLaunchKernelGGL((graph_softmax_bwd2_kernel<T>), dim3(ch, B), dim3(256), 0, ST, dgw_w, dgw_v, gw_w, gw_v, A0, pr, mask,
+                                             scratch, dA0, (T*)dA0_t, dpr, N, T_, Tp));
     return cmpc_check_launch("graph_softmax_bwd");
 }
 
@@ -466,7 +510,7 @@ extern "C" int cmpc_l2norm_all_bwd(const float* dy, const float* y, const float*
 extern "C" int cmpc_exchange_combine_fwd(int dt, const void* feat, const void* r1, const void* r2, const float* g1, const float* g2,
                                          int ld_g, void* out, float* rstd, int B, int N, int ld, int C, void* stream) {
     if (!map_ok("exchange_combine_fwd", ld, C, dt)) return CMPC_EINVAL;
-    CMPC_DISPATCH_DT(dt, hipLaunchKernelGGL((exch_combine_fwd_kernel<T>), dim3(rows_grid(N, 64), B), dim3(256), 0, ST,
+    CMPC_DISPATCH_DT(dt, hipLaunchKernelGGL((exch_combine_fwd_kernel<T>), dim3(rows_grid(N, 400), B), dim3(256), 0, ST,
                                              (const T*)feat, (const T*)r1, (const T*)r2, g1, g2, ld_g, (T*)out, rstd, N, ld, C));
     return cmpc_check_launch("exchange_combine_fwd");
 }
@@ -475,7 +519,7 @@ extern "C" int cmpc_exchange_combine_bwd(int dt, const void* dout, const void* o
                                          const float* g1, const float* g2, int ld_g, void* dfeat, int accumulate_dfeat,
                                          void* dp1, void* dp2, float* dg1, float* dg2, int B, int N, int ld, int C, void* stream) {
     if (!map_ok("exchange_combine_bwd", ld, C, dt)) return CMPC_EINVAL;
-    CMPC_DISPATCH_DT(dt, hipLaunchKernelGGL((exch_combine_bwd_kernel<T>), dim3(rows_grid(N, 32), B), dim3(256), WPB * 2 * ld * sizeof(float), ST,
+    CMPC_DISPATCH_DT(dt, hipLaunchKernelGGL((exch_combine_bwd_kernel<T>), dim3(rows_grid(N, 100), B), dim3(256), WPB * 2 * ld * sizeof(float), ST,
                                              (const T*)dout, (const T*)out, rstd, (const T*)r1, (const T*)r2, g1, g2, ld_g,
                                              (T*)dfeat, accumulate_dfeat, (T*)dp1, (T*)dp2, dg1, dg2, N, ld, C));
     return cmpc_check_launch("exchange_combine_bwd");

@@ -27,7 +27,7 @@ namespace {
 constexpr int MAXBLK = 4;      // ld <= 2048 for kernels that keep per-column registers
 constexpr int WPB = 4;         // waves per 256-thread block
 
-__host__ inline int rows_grid(int N) { int g = (N + WPB - 1) / WPB; return g < 1 ? 1 : (g > 64 ? 64 : g); }
+__host__ inline int rows_grid(int N) { int g = (N + WPB - 1) / WPB; return g < 1 ? 1 : (g > 400 ? 400 : g); }
 
 // flush per-lane column accumulators (lane owns columns blk*512 + lane*8 + e) into out[c] (atomics)
 __device__ __forceinline__ void colsum_flush(const float (&acc)[MAXBLK][8], float* out, int ld, int C, float* lds) {
@@ -561,7 +561,7 @@ extern "C" int cmpc_act_bwd(int dt, const void* dy, const void* y, void* dpre, i
     int N = R, B = 1;
     if (dsb) { if (rows_per_sample <= 0 || R % rows_per_sample) { cmpc_set_error("act_bwd: bad rows_per_sample"); return CMPC_EINVAL; } N = rows_per_sample; B = R / N; }
     if (R == 0) return CMPC_OK;
-    const int gx = dsb ? rows_grid(N) : ((R + 3) / 4 > 256 ? 256 : (R + 3) / 4);
+    const int gx = dsb ? (rows_grid(N) > 64 ? 64 : rows_grid(N)) : ((R + 3) / 4 > 512 ? 512 : (R + 3) / 4);
     CMPC_DISPATCH_DT(dt, hipLaunchKernelGGL((act_bwd_kernel<T>), dim3(gx, B), dim3(256), WPB * ld * sizeof(float), ST,
                                              (const T*)dy, (const T*)y, (T*)dpre, act, N, stride, ld, C, db, dsb, ld_dsb));
     return cmpc_check_launch("act_bwd");
@@ -624,7 +624,7 @@ extern "C" int cmpc_gconv_pre_bwd(int dt, const void* dG, const void* G, const v
     if (!map_ok("gconv_pre_bwd", ld, C, dt)) return CMPC_EINVAL;
     if (hipMemsetAsync(bsums, 0, sizeof(double) * 2 * B, ST) != hipSuccess) { cmpc_set_error("gconv_pre_bwd: memset failed"); return CMPC_EHIP; }
     CMPC_DISPATCH_DT(dt, {
-        hipLaunchKernelGGL((gconv_pre_bwd1_kernel<T>), dim3(rows_grid(N) > 32 ? 32 : rows_grid(N), B), dim3(256), WPB * ld * sizeof(float), ST,
+        hipLaunchKernelGGL((gconv_pre_bwd1_kernel<T>), dim3(rows_grid(N) > 100 ? 100 : rows_grid(N), B), dim3(256), WPB * ld * sizeof(float), ST,
                            (const T*)dG, (const T*)G, (const T*)Y, sums, gamma, (T*)dX, accumulate_dX, (T*)dY, dgamma, dbeta, bsums, N, ld, C);
         hipLaunchKernelGGL((ln_bwd2_kernel<T>), dim3(rows_grid(N), B), dim3(256), 0, ST, (T*)dY, (const T*)Y, sums, bsums, N, ld, C);
     });
@@ -645,7 +645,7 @@ extern "C" int cmpc_gconv_post_bwd(int dt, const void* dout, const void* out, co
     if (!map_ok("gconv_post_bwd", ld, C, dt)) return CMPC_EINVAL;
     if (hipMemsetAsync(bsums, 0, sizeof(double) * 2 * B, ST) != hipSuccess) { cmpc_set_error("gconv_post_bwd: memset failed"); return CMPC_EHIP; }
     CMPC_DISPATCH_DT(dt, {
-        hipLaunchKernelGGL((gconv_post_bwd1_kernel<T>), dim3(rows_grid(N) > 32 ? 32 : rows_grid(N), B), dim3(256), WPB * ld * sizeof(float), ST,
+        hipLaunchKernelGGL((gconv_post_bwd1_kernel<T>), dim3(rows_grid(N) > 100 ? 100 : rows_grid(N), B), dim3(256), WPB * ld * sizeof(float), ST,
                            (const T*)dout, (const T*)out, rstd_row, (const T*)U, sums, gamma, (T*)dU, dgamma, dbeta, bsums, N, ld, C);
         hipLaunchKernelGGL((ln_bwd2_kernel<T>), dim3(rows_grid(N), B), dim3(256), 0, ST, (T*)dU, (const T*)U, sums, bsums, N, ld, C);
     });

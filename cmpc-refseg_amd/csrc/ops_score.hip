@@ -9,28 +9,41 @@ namespace {
 constexpr int WPB = 4;
 constexpr int MB = 2;
 
-template <typename T>
+// Each lane owns the same 8 channels (per 512-block) for every pixel its wave visits, so the 9 x 8
+// filter taps it needs live in registers for the whole grid-stride loop.
+template <typename T, int NB>
 __global__ __launch_bounds__(256) void score_conv_fwd_kernel(const T* __restrict__ feat, const float* __restrict__ Wk, const float* __restrict__ bias,
                                                             float* __restrict__ score, int B, int h, int w, int ld, int M) {
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int total = B * h * w;
+    float wk[NB][9][8];
+#pragma unroll
+    for (int k = 0; k < NB; ++k)
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { const int c = k * 512 + lane * 8 + e; wk[k][t][e] = (c < M) ? Wk[t * M + c] : 0.f; }
     for (int p = blockIdx.x * WPB + wv; p < total; p += gridDim.x * WPB) {
         const int b = p / (h * w), y = (p / w) % h, x = p % w;
         float acc = 0.f;
-        for (int dy = -1; dy <= 1; ++dy) {
-            const int yy = y + dy;
-            if (yy < 0 || yy >= h) continue;
-            for (int dx = -1; dx <= 1; ++dx) {
-                const int xx = x + dx;
-                if (xx < 0 || xx >= w) continue;
-                const T* f = feat + ((long)(b * h + yy) * w + xx) * ld;
-                const float* wk = Wk + ((dy + 1) * 3 + (dx + 1)) * M;
-                for (int c0 = lane * 8; c0 < ld; c0 += 512) {
-                    float v[8];
-                    ld8<T>(f + c0, v);
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) if (c0 + e < M) acc += v[e] * wk[c0 + e];
+        for (int k = 0; k < NB; ++k) {
+            const int c0 = k * 512 + lane * 8;
+            if (c0 < ld) {
+                float v[9][8];
+#pragma unroll
+                for (int t = 0; t < 9; ++t) {
+                    const int yy = y + t / 3 - 1, xx = x + t % 3 - 1;
+                    if (yy >= 0 && yy < h && xx >= 0 && xx < w) ld8<T>(feat + ((long)(b * h + yy) * w + xx) * ld + c0, v[t]);
+                    else {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) v[t][e] = 0.f;
+                    }
                 }
+#pragma unroll
+                for (int t = 0; t < 9; ++t)
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) acc += v[t][e] * wk[k][t][e];
             }
         }
         acc = wave_sum(acc);
@@ -39,11 +52,18 @@ __global__ __launch_bounds__(256) void score_conv_fwd_kernel(const T* __restrict
 }
 
 // dfeat[b,y,x,:] (+)= sum_taps dscore[b, y-dy, x-dx] * W[tap,:]
-template <typename T>
+template <typename T, int NB>
 __global__ __launch_bounds__(256) void score_conv_bwd_data_kernel(const float* __restrict__ dscore, const float* __restrict__ Wk, T* __restrict__ dfeat,
                                                                  int accumulate, int B, int h, int w, int ld, int M) {
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int total = B * h * w;
+    float wk[NB][9][8];
+#pragma unroll
+    for (int k = 0; k < NB; ++k)
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { const int c = k * 512 + lane * 8 + e; wk[k][t][e] = (c < M) ? Wk[t * M + c] : 0.f; }
     for (int p = blockIdx.x * WPB + wv; p < total; p += gridDim.x * WPB) {
         const int b = p / (h * w), y = (p / w) % h, x = p % w;
         float ds[9];
@@ -53,19 +73,21 @@ __global__ __launch_bounds__(256) void score_conv_bwd_data_kernel(const float* _
             ds[t] = (yy >= 0 && yy < h && xx >= 0 && xx < w) ? dscore[(b * h + yy) * w + xx] : 0.f;
         }
         T* d = dfeat + (long)p * ld;
-        for (int c0 = lane * 8; c0 < ld; c0 += 512) {
-            float o[8];
-            if (accumulate) ld8<T>(d + c0, o);
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                float v = 0.f;
-                if (c0 + e < M) {
+        for (int k = 0; k < NB; ++k) {
+            const int c0 = k * 512 + lane * 8;
+            if (c0 < ld) {
+                float o[8];
+                if (accumulate) ld8<T>(d + c0, o);
 #pragma unroll
-                    for (int t = 0; t < 9; ++t) v += ds[t] * Wk[t * M + c0 + e];
+                for (int e = 0; e < 8; ++e) {
+                    float v = 0.f;
+#pragma unroll
+                    for (int t = 0; t < 9; ++t) v += ds[t] * wk[k][t][e];
+                    o[e] = accumulate ? o[e] + v : v;
                 }
-                o[e] = accumulate ? o[e] + v : v;
+                st8<T>(d + c0, o);
             }
-            st8<T>(d + c0, o);
         }
     }
 }
@@ -208,7 +230,10 @@ extern "C" int cmpc_score_conv_fwd(int dt, const void* feat, const float* Wk, co
                                    int B, int h, int w, int ld, int M, void* stream) {
     if (ld % 8 || M > ld || ld > MB * 512) { cmpc_set_error("score_conv_fwd: bad ld/M"); return CMPC_EINVAL; }
     const int total = B * h * w, g = (total + 3) / 4 > 2048 ? 2048 : (total + 3) / 4;
-    CMPC_DISPATCH_DT(dt, hipLaunchKernelGGL((score_conv_fwd_kernel<T>), dim3(g), dim3(256), 0, ST, (const T*)feat, Wk, bias, score, B, h, w, ld, M));
+    CMPC_DISPATCH_DT(dt, {
+        if (ld <= 512) hipLaunchKernelGGL((score_conv_fwd_kernel<T, 1>), dim3(g), dim3(256), 0, ST, (const T*)feat, Wk, bias, score, B, h, w, ld, M);
+        else hipLaunchKernelGGL((score_conv_fwd_kernel<T, 2>), dim3(g), dim3(256), 0, ST, (const T*)feat, Wk, bias, score, B, h, w, ld, M);
+    });
     return cmpc_check_launch("score_conv_fwd");
 }
 
@@ -217,7 +242,8 @@ extern "C" int cmpc_score_conv_bwd(int dt, const float* dscore, const void* feat
     if (ld % 8 || M > ld || ld > MB * 512) { cmpc_set_error("score_conv_bwd: bad ld/M"); return CMPC_EINVAL; }
     const int total = B * h * w, g = (total + 3) / 4 > 2048 ? 2048 : (total + 3) / 4;
     CMPC_DISPATCH_DT(dt, {
-        if (dfeat) hipLaunchKernelGGL((score_conv_bwd_data_kernel<T>), dim3(g), dim3(256), 0, ST, dscore, Wk, (T*)dfeat, accumulate, B, h, w, ld, M);
+        if (dfeat && ld <= 512) hipLaunchKernelGGL((score_conv_bwd_data_kernel<T, 1>), dim3(g), dim3(256), 0, ST, dscore, Wk, (T*)dfeat, accumulate, B, h, w, ld, M);
+        else if (dfeat) hipLaunchKernelGGL((score_conv_bwd_data_kernel<T, 2>), dim3(g), dim3(256), 0, ST, dscore, Wk, (T*)dfeat, accumulate, B, h, w, ld, M);
         if (dWk) hipLaunchKernelGGL((score_conv_bwd_w_kernel<T>), dim3(g > 128 ? 128 : g), dim3(256), WPB * ld * sizeof(float), ST,
                                     dscore, (const T*)feat, dWk, dbias, B, h, w, ld, M);
     });

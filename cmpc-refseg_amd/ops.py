@@ -398,7 +398,8 @@ class SpaGraph(torch.autograd.Function):
         gw_v = empty((B, N, Tp), F32, dev)
         gw_w_t = empty((B, N, Tp), dt, dev)
         gw_v_t = empty((B, N, Tp), dt, dev)
-        _lib.call("cmpc_graph_softmax_fwd", dt, _p(A0), _p(pr), _p(mask), _p(gw_w), _p(gw_v), _p(gw_w_t), _p(gw_v_t), B, N, T, Tp, _st())
+        gsc = empty((B * ((N + 63) // 64) * 128,), F32, dev)
+        _lib.call("cmpc_graph_softmax_fwd", dt, _p(A0), _p(pr), _p(mask), _p(gw_w), _p(gw_v), _p(gw_w_t), _p(gw_v_t), _p(gsc), B, N, T, Tp, _st())
         Ztf = zeros((B, Cp, Tp), F32, dev)        # Z^T = X1^T . gw_v   [C, T] per sample
         gemm_tn(dt, X1, Cp, Cp, gw_v_t, Tp, Tp, Ztf, Tp, N, C, T, nb2=B, a_bs=N * Cp, d_bs=N * Tp, o_bs=Cp * Tp)
         Zt = empty((B, Cp, Tp), dt, dev)
@@ -465,7 +466,7 @@ class SpaGraph(torch.autograd.Function):
         dA0_t = empty((B, N, Tp), dt, dev)
         dpr = empty((B * T,), F32, dev)
         _lib.call("cmpc_graph_softmax_bwd", dt, _p(dgw_w), _p(dgw_v), _p(gw_w), _p(gw_v), _p(A0), _p(pr), _p(mask),
-                  _p(dA0), _p(dA0_t), _p(dpr), B, N, T, Tp, _st())
+                  _p(dA0), _p(dA0_t), _p(dpr), _p(empty((B * ((N + 63) // 64) * 128,), F32, dev)), B, N, T, Tp, _st())
         # A0 = scale * (X1 . PT^T) + k0s
         gemm_nt(dt, [(dA0_t, Tp, PTt, B * Tp, Tp, N * Tp, Tp)], dX1, Cp, N, Cp, n_valid=C, batch=B, sC=N * Cp, alpha=scale, accumulate=True)
         dPT = zeros((B * Tp, Cp), F32, dev)

@@ -120,11 +120,12 @@ int cmpc_mutan_bwd(int dt, void* Th, const float* g, const void* X1, const float
 /* ---- build_spa_graph softmaxes (CMPC_model.py:384-399): A0 [B,N,Tp] f32 = affinity/sqrt(C);
  *      gw_w = softmax_T(mask*pr*A0 + (1-mask)*FLT_MIN), gw_v = softmax_N(pr*A0)*mask.
  *      f32 copies are kept for backward, dt copies ([B,N,Tp], pad columns 0) feed the GEMMs -- */
+/*      scratch: B * ceil(N/64) * 128 floats (per-chunk column statistics) */
 int cmpc_graph_softmax_fwd(int dt, const float* A0, const float* pr, const float* mask, float* gw_w, float* gw_v,
-                           void* gw_w_t, void* gw_v_t, int B, int N, int T, int Tp, void* stream);
+                           void* gw_w_t, void* gw_v_t, float* scratch, int B, int N, int T, int Tp, void* stream);
 int cmpc_graph_softmax_bwd(int dt, const float* dgw_w, const float* dgw_v, const float* gw_w, const float* gw_v,
                            const float* A0, const float* pr, const float* mask, float* dA0, void* dA0_t, float* dpr,
-                           int B, int N, int T, int Tp, void* stream);
+                           float* scratch, int B, int N, int T, int Tp, void* stream);
 
 /* ---- graph_conv (CMPC_model.py:359-374) around the two GEMMs ------------------------------- */
 /* G = relu(X + LN(Y; gamma, beta)) */
