@@ -256,3 +256,36 @@ def test_full_size_properties():
     assert torch.isfinite(g).all() and float(g.abs().max()) > 0
     up = o["up"]
     assert torch.equal(o["sigm"] > 0.5, up > 0)
+
+
+def test_full_size_mean_iou_delta_vs_oracle():
+    """BASELINE.json's parity bar at the benchmark's sizes (320x320, L=20, C=1000, M=500, ResNet-101):
+    |mean-IoU(HIP) - mean-IoU(oracle)| <= 1e-4 on identical inputs and weights.  fp32 mode must meet
+    it; bf16 mode is measured and bounded at 5e-3 (its value is recorded in DESIGN.md).  B=2 keeps the
+    CPU oracle to ~15 s."""
+    from bench import synth_batch
+    torch.set_num_threads(16)
+    B = 2
+    cfg = O.Cfg(batch_size=B)
+    hp, bp = O.init_head_params(cfg), O.init_backbone_params(cfg)
+    w, im, sl, tg = synth_batch(B, 20, 320, 320, cfg.vocab_size, 11)
+    w, im, sl, tg = map(torch.from_numpy, (w, im, sl, tg))
+    with torch.no_grad():
+        feats = O.backbone_forward(bp, im, cfg)
+        taps = O.head_forward(hp, feats, w, sl, cfg)
+        ref = O.losses(hp, taps, tg, cfg)
+    P = U.pkg()
+    res = {}
+    for dtype in ("f32", "bf16"):
+        m = P.LSTM_model(batch_size=B, mode="train", dtype=dtype, head_params=hp, backbone_params=bp)
+        with torch.no_grad():
+            o = m.head(m.features(im), w, sl, tg)
+        torch.cuda.synchronize()
+        up = o["up"].float().cpu()
+        flips = int(((up > 0) != (taps["up"] > 0)).sum())
+        res[dtype] = (abs(float(o["mIoU"]) - float(ref["mIoU"])), flips, U.rel_err(up, taps["up"]))
+        del m
+        torch.cuda.empty_cache()
+    print("full-size parity:", {k: f"dIoU={v[0]:.2e} flipped_px={v[1]} up_rel_err={v[2]:.2e}" for k, v in res.items()}, "oracle mIoU", float(ref["mIoU"]))
+    assert res["f32"][0] <= 1e-4 and res["f32"][2] < 1e-3
+    assert res["bf16"][0] <= 5e-3
