@@ -16,7 +16,6 @@
 
 namespace {
 
-constexpr int BM = 128;       // rows of C per workgroup
 constexpr int BKB = 128;      // bytes of K per row per LDS stage (64 bf16 / 32 f32)
 
 // LDS image of a [rows][128 B] tile: 16-B chunk c of row r lives at slot c ^ ((r>>1)&7).
@@ -44,11 +43,11 @@ template <> struct Mma<float> {
 // ------------------------------------------------------------------------------------------
 // gemm_nt
 // ------------------------------------------------------------------------------------------
-template <typename T, int BN>
+template <typename T, int BM, int BN>
 __global__ __launch_bounds__(256) void gemm_nt_kernel(const cmpc_gemm_nt_args p) {
     constexpr int EPC = 16 / (int)sizeof(T);       // elements per 16-B chunk
     constexpr int BK = BKB / (int)sizeof(T);       // elements of K per stage
-    constexpr int WAVES_N = (BN == 128) ? 2 : 1;
+    constexpr int WAVES_N = (BN == 128 || BM == 64) ? 2 : 1;
     constexpr int WAVES_M = 4 / WAVES_N;
     constexpr int TM = BM / WAVES_M / 16;          // 16x16 tiles per wave along M
     constexpr int TN = BN / WAVES_N / 16;
@@ -151,7 +150,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const cmpc_gemm_nt_args p)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int row = i * 16 + fq * 4 + r, col = j * 16 + fr;
-                slab[row * WC + (col ^ (((row >> 2) & 3) << 4))] = acc[i][j][r];
+                slab[row * WC + (col ^ ((((row >> 2) & 3) << 4) & (WC - 1)))] = acc[i][j][r];
             }
     __builtin_amdgcn_s_waitcnt(0xC07F);            // lgkmcnt(0): own wave's LDS writes landed
     __builtin_amdgcn_wave_barrier();
@@ -165,7 +164,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const cmpc_gemm_nt_args p)
         const int row = pass * RPP + lane / LPR, c4 = (lane % LPR) * 4;
         const int gm = m0 + wm * WR + row, gn = n0 + wn * WC + c4;
         if (gm >= p.M || gn >= p.N) continue;
-        const int sc = c4 ^ (((row >> 2) & 3) << 4);
+        const int sc = c4 ^ ((((row >> 2) & 3) << 4) & (WC - 1));
         const float4 v4 = *reinterpret_cast<const float4*>(slab + row * WC + sc);
         float v[4] = {v4.x, v4.y, v4.z, v4.w};
         const long bm = bz * (long)p.M + gm;       // row index across the batch
@@ -673,10 +672,12 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const cmpc_gemm_tn_args p)
 // ------------------------------------------------------------------------------------------
 template <int MMAX>
 __global__ __launch_bounds__(256) void gemm_nt_skinny_f32_kernel(const cmpc_gemm_nt_args p) {
-    constexpr int NC = 2;
+    // one workgroup = NC output columns; its 4 waves split K (interleaved 1-KiB slices), so a
+    // K = 1024 product is ONE round trip of 12 independent 16-B loads per lane.
+    constexpr int NC = 4;
+    __shared__ float red[4][MMAX * NC];
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-    const int n0 = (blockIdx.x * 4 + wid) * NC;
-    if (n0 >= p.N) return;
+    const int n0 = blockIdx.x * NC;
     float acc[MMAX][NC];
 #pragma unroll
     for (int m = 0; m < MMAX; ++m)
@@ -687,7 +688,7 @@ __global__ __launch_bounds__(256) void gemm_nt_skinny_f32_kernel(const cmpc_gemm
         const float* Bt = reinterpret_cast<const float*>(p.Bt[s]);
         const long lda = p.lda[s], ldb = p.ldb[s];
         const int K = p.K[s];
-        for (int k = lane * 4; k < K; k += 256) {
+        for (int k = (wid * 64 + lane) * 4; k < K; k += 1024) {
             float4 w[NC];
 #pragma unroll
             for (int c = 0; c < NC; ++c)
@@ -702,19 +703,21 @@ __global__ __launch_bounds__(256) void gemm_nt_skinny_f32_kernel(const cmpc_gemm
             }
         }
     }
-    float mine = 0.f;
 #pragma unroll
     for (int m = 0; m < MMAX; ++m)
 #pragma unroll
         for (int c = 0; c < NC; ++c) {
             const float v = wave_sum(acc[m][c]);
-            if (lane == m * NC + c) mine = v;
+            if (lane == 0) red[wid][m * NC + c] = v;
         }
-    const int m = lane / NC, c = lane % NC, gn = n0 + c;
+    __syncthreads();
+    const int t = threadIdx.x;
+    if (t >= MMAX * NC) return;
+    const int m = t / NC, c = t % NC, gn = n0 + c;
     if (m >= p.M || gn >= p.N) return;
     float x = 0.f;
     if (gn < p.n_valid) {
-        x = mine * p.alpha;
+        x = (red[0][t] + red[1][t] + red[2][t] + red[3][t]) * p.alpha;
         const int rps = p.rows_per_sample > 0 ? p.rows_per_sample : 1;
         if (p.bias) x += p.bias[gn];
         if (p.sbias) x += p.sbias[(m / rps) * (long)p.ld_sbias + gn];
@@ -743,7 +746,7 @@ extern "C" int cmpc_gemm_nt(const cmpc_gemm_nt_args* a, void* stream) {
     if (a->N % 4 || a->ldc % 4 || !a->C) { cmpc_set_error("gemm_nt: N/ldc must be multiples of 4"); return CMPC_EINVAL; }
     hipStream_t st = (hipStream_t)stream;
     if (a->dtype == DT_F32 && a->M <= 16 && a->batch == 1) {
-        dim3 grid((a->N + 7) / 8);
+        dim3 grid((a->N + 3) / 4);
         if (a->M <= 8) hipLaunchKernelGGL((gemm_nt_skinny_f32_kernel<8>), grid, dim3(256), 0, st, *a);
         else hipLaunchKernelGGL((gemm_nt_skinny_f32_kernel<16>), grid, dim3(256), 0, st, *a);
         return cmpc_check_launch("gemm_nt(skinny)");
@@ -765,14 +768,21 @@ extern "C" int cmpc_gemm_nt(const cmpc_gemm_nt_args* a, void* stream) {
         return cmpc_check_launch("gemm_nt(v2)");
     }
     const int bn = (a->N % 128 == 0 || a->N > 64) ? 128 : 64;
-    dim3 grid(((a->N + bn - 1) / bn) * ((a->M + BM - 1) / BM), 1, a->batch);
-    const size_t lds = 2 * (BM + bn) * BKB;
+    const long tiles128 = (long)((a->N + bn - 1) / bn) * ((a->M + 127) / 128) * a->batch;
+    if (a->dtype == DT_F32 && tiles128 < 192) {
+        // fp32 MFMA runs at 1/16 of the bf16 rate: small products need many small tiles to use the chip
+        dim3 grid(((a->N + 63) / 64) * ((a->M + 63) / 64), 1, a->batch);
+        hipLaunchKernelGGL((gemm_nt_kernel<float, 64, 64>), grid, dim3(256), 2 * (64 + 64) * BKB, st, *a);
+        return cmpc_check_launch("gemm_nt(64x64)");
+    }
+    dim3 grid(((a->N + bn - 1) / bn) * ((a->M + 127) / 128), 1, a->batch);
+    const size_t lds = 2 * (128 + bn) * BKB;
     if (a->dtype == DT_F32) {
-        if (bn == 128) hipLaunchKernelGGL((gemm_nt_kernel<float, 128>), grid, dim3(256), lds, st, *a);
-        else hipLaunchKernelGGL((gemm_nt_kernel<float, 64>), grid, dim3(256), lds, st, *a);
+        if (bn == 128) hipLaunchKernelGGL((gemm_nt_kernel<float, 128, 128>), grid, dim3(256), lds, st, *a);
+        else hipLaunchKernelGGL((gemm_nt_kernel<float, 128, 64>), grid, dim3(256), lds, st, *a);
     } else if (a->dtype == DT_BF16) {
-        if (bn == 128) hipLaunchKernelGGL((gemm_nt_kernel<bf16_t, 128>), grid, dim3(256), lds, st, *a);
-        else hipLaunchKernelGGL((gemm_nt_kernel<bf16_t, 64>), grid, dim3(256), lds, st, *a);
+        if (bn == 128) hipLaunchKernelGGL((gemm_nt_kernel<bf16_t, 128, 128>), grid, dim3(256), lds, st, *a);
+        else hipLaunchKernelGGL((gemm_nt_kernel<bf16_t, 128, 64>), grid, dim3(256), lds, st, *a);
     } else { cmpc_set_error("gemm_nt: bad dtype"); return CMPC_EINVAL; }
     return cmpc_check_launch("gemm_nt");
 }
