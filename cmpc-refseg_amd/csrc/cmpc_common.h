@@ -19,6 +19,13 @@ enum { ACT_NONE = 0, ACT_RELU = 1, ACT_TANH = 2, ACT_SIGMOID = 3 };
 
 void cmpc_set_error(const char* fmt, ...);
 int cmpc_check_launch(const char* what);
+// Library-owned scratch for per-workgroup partial sums (grows on demand; single stream per process).
+void* cmpc_ws(size_t bytes);
+// out[o*ld_out + seg*out_seg + c] (+)= sum_{i<ninner} part[(o*ninner+i)*part_stride + seg*seg_ld + c], c < seg_C
+int cmpc_reduce_parts_f32(const float* part, long part_stride, int nouter, int ninner, int nseg, int seg_ld, int seg_C,
+                          float* out, long ld_out, long out_seg, int accumulate, hipStream_t st);
+// out[o*nval + v] = sum_{i<ninner} part[(o*ninner+i)*nval + v]
+int cmpc_reduce_parts_f64(const double* part, int nouter, int ninner, int nval, double* out, hipStream_t st);
 
 __device__ __forceinline__ float bf2f(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
 __device__ __forceinline__ bf16_t f2bf(float f) {

@@ -17,9 +17,9 @@ __device__ __forceinline__ void flush_sums(double s1, double s2, double* dst, do
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     if (lane == 0) { red[2 * slot][w] = s1; red[2 * slot + 1][w] = s2; }
     __syncthreads();
-    if (threadIdx.x == 0) {
-        atomicAdd(dst, red[2 * slot][0] + red[2 * slot][1] + red[2 * slot][2] + red[2 * slot][3]);
-        atomicAdd(dst + 1, red[2 * slot + 1][0] + red[2 * slot + 1][1] + red[2 * slot + 1][2] + red[2 * slot + 1][3]);
+    if (threadIdx.x == 0) {        // dst = this workgroup's partial pair (folded by reduce_parts_f64)
+        dst[0] = red[2 * slot][0] + red[2 * slot][1] + red[2 * slot][2] + red[2 * slot][3];
+        dst[1] = red[2 * slot + 1][0] + red[2 * slot + 1][1] + red[2 * slot + 1][2] + red[2 * slot + 1][3];
     }
     __syncthreads();
 }
@@ -36,10 +36,8 @@ __device__ __forceinline__ void colflush(const float (&acc)[MB][8], float* out, 
         }
     }
     __syncthreads();
-    for (int c = threadIdx.x; c < C; c += 256) {
-        const float s = lds[c] + lds[ld + c] + lds[2 * ld + c] + lds[3 * ld + c];
-        if (s != 0.f) atomicAdd(out + c, s);
-    }
+    for (int c = threadIdx.x; c < ld; c += 256)      // this workgroup's partial row (plain stores)
+        out[c] = (c < C) ? lds[c] + lds[ld + c] + lds[2 * ld + c] + lds[3 * ld + c] : 0.f;
 }
 
 // ---- forward A: peepholes on i,f (in place) + stats j,i,f -----------------------------------
@@ -77,9 +75,10 @@ __global__ __launch_bounds__(256) void clstm_a_kernel(T* __restrict__ Yg, const 
         }
         sj1 += aj1; sj2 += aj2; si1 += ai1; si2 += ai2; sf1 += af1; sf2 += af2;
     }
-    flush_sums(sj1, sj2, sums + (0 * B + b) * 2, red, 0);
-    flush_sums(si1, si2, sums + (1 * B + b) * 2, red, 1);
-    flush_sums(sf1, sf2, sums + (2 * B + b) * 2, red, 2);
+    const long wg = (long)b * gridDim.x + blockIdx.x, nwg = (long)B * gridDim.x;
+    flush_sums(sj1, sj2, sums + (0 * nwg + wg) * 2, red, 0);
+    flush_sums(si1, si2, sums + (1 * nwg + wg) * 2, red, 1);
+    flush_sums(sf1, sf2, sums + (2 * nwg + wg) * 2, red, 2);
 }
 
 struct LnP { const float* beta[5]; const float* gamma[5]; };
@@ -88,7 +87,7 @@ struct LnG { float* dbeta[5]; float* dgamma[5]; };
 // ---- forward B ---------------------------------------------------------------------------------
 template <typename T>
 __global__ __launch_bounds__(256) void clstm_b_kernel(T* __restrict__ Yg, const T* __restrict__ c_prev, const float* __restrict__ W_co,
-                                                     LnP ln, double* sums, T* __restrict__ c_pre, int B, int N, int ld, int M) {
+                                                     LnP ln, const double* sums, double* dpart, T* __restrict__ c_pre, int B, int N, int ld, int M) {
     __shared__ double red[4][WPB];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, b = blockIdx.y;
     const double cnt = (double)N * M;
@@ -125,8 +124,9 @@ __global__ __launch_bounds__(256) void clstm_b_kernel(T* __restrict__ Yg, const 
         }
         so1 += ao1; so2 += ao2; sc1 += ac1; sc2 += ac2;
     }
-    flush_sums(so1, so2, sums + (3 * B + b) * 2, red, 0);
-    flush_sums(sc1, sc2, sums + (4 * B + b) * 2, red, 1);
+    const long wg = (long)b * gridDim.x + blockIdx.x, nwg = (long)B * gridDim.x;
+    flush_sums(so1, so2, dpart + (0 * nwg + wg) * 2, red, 0);
+    flush_sums(sc1, sc2, dpart + (1 * nwg + wg) * 2, red, 1);
 }
 
 // ---- forward C ---------------------------------------------------------------------------------
@@ -161,7 +161,7 @@ __global__ __launch_bounds__(256) void clstm_c_kernel(const T* __restrict__ Yg, 
 template <typename T>
 __global__ __launch_bounds__(256) void clstm_bwd1_kernel(const T* __restrict__ dh, const T* __restrict__ dc_new, const T* __restrict__ Yg,
                                                         const T* __restrict__ c_pre, LnP ln, const double* sums, T* __restrict__ dYg,
-                                                        T* __restrict__ scr, LnG dl, double* bsums, int B, int N, int ld, int M) {
+                                                        T* __restrict__ scr, float* part, double* dpart, int B, int N, int ld, int M) {
     extern __shared__ float lds[];
     __shared__ double red[4][WPB];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, b = blockIdx.y;
@@ -205,10 +205,12 @@ __global__ __launch_bounds__(256) void clstm_bwd1_kernel(const T* __restrict__ d
         }
         so1 += ao1; so2 += ao2; sc1 += ac1; sc2 += ac2;
     }
-    flush_sums(so1, so2, bsums + (3 * B + b) * 2, red, 0);
-    flush_sums(sc1, sc2, bsums + (4 * B + b) * 2, red, 1);
-    colflush(ago, dl.dgamma[3], ld, M, lds); colflush(abo, dl.dbeta[3], ld, M, lds);
-    colflush(agc, dl.dgamma[4], ld, M, lds); colflush(abc, dl.dbeta[4], ld, M, lds);
+    const long wg = (long)b * gridDim.x + blockIdx.x, nwg = (long)B * gridDim.x;
+    flush_sums(so1, so2, dpart + (0 * nwg + wg) * 2, red, 0);
+    flush_sums(sc1, sc2, dpart + (1 * nwg + wg) * 2, red, 1);
+    float* pr = part + wg * 4 * ld;                 // [dgamma_o, dbeta_o, dgamma_c, dbeta_c]
+    colflush(ago, pr, ld, M, lds); colflush(abo, pr + ld, ld, M, lds);
+    colflush(agc, pr + 2 * ld, ld, M, lds); colflush(abc, pr + 3 * ld, ld, M, lds);
 }
 
 // ---- backward pass 2: finish LN(o), LN(c); through the cell update to dxhat of j,i,f -----------
@@ -216,7 +218,7 @@ template <typename T>
 __global__ __launch_bounds__(256) void clstm_bwd2_kernel(const T* __restrict__ Yg, const T* __restrict__ c_prev, const T* __restrict__ c_pre,
                                                         const float* __restrict__ W_co, LnP ln, const double* sums, const double* bsums_in,
                                                         T* __restrict__ dYg, const T* __restrict__ scr, T* __restrict__ dc_prev,
-                                                        float* dW_co, LnG dl, double* bsums, int B, int N, int ld, int M) {
+                                                        float* part, double* dpart, int B, int N, int ld, int M) {
     extern __shared__ float lds[];
     __shared__ double red[6][WPB];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, b = blockIdx.y;
@@ -285,11 +287,13 @@ __global__ __launch_bounds__(256) void clstm_bwd2_kernel(const T* __restrict__ Y
 #pragma unroll
         for (int q = 0; q < 6; ++q) s[q] += a[q];
     }
-    flush_sums(s[0], s[1], bsums + (0 * B + b) * 2, red, 0);
-    flush_sums(s[2], s[3], bsums + (1 * B + b) * 2, red, 1);
-    flush_sums(s[4], s[5], bsums + (2 * B + b) * 2, red, 2);
+    const long wg = (long)b * gridDim.x + blockIdx.x, nwg = (long)B * gridDim.x;
+    flush_sums(s[0], s[1], dpart + (0 * nwg + wg) * 2, red, 0);
+    flush_sums(s[2], s[3], dpart + (1 * nwg + wg) * 2, red, 1);
+    flush_sums(s[4], s[5], dpart + (2 * nwg + wg) * 2, red, 2);
+    float* pr = part + wg * 6 * ld;                 // [dgamma_q, dbeta_q] for q = j, i, f
 #pragma unroll
-    for (int q = 0; q < 3; ++q) { colflush(ag[q], dl.dgamma[q], ld, M, lds); colflush(ab[q], dl.dbeta[q], ld, M, lds); }
+    for (int q = 0; q < 3; ++q) { colflush(ag[q], pr + (2 * q) * ld, ld, M, lds); colflush(ab[q], pr + (2 * q + 1) * ld, ld, M, lds); }
 }
 
 // ---- backward pass 3: finish LN(j), LN(i), LN(f); peepholes on i,f ----------------------------
@@ -379,20 +383,38 @@ LnG to_lng(const cmpc_convlstm_dln* l) { LnG p; for (int i = 0; i < 5; ++i) { p.
 
 #define ST ((hipStream_t)stream)
 
+// workspace: fp32 column partials [nwg][ncol][ld] followed by fp64 pair partials [npair][nwg][2]
+static int clstm_ws(long nwg, int ncol, int npair, int ld, float** part, double** dpart) {
+    const size_t fbytes = ((size_t)nwg * ncol * ld * sizeof(float) + 15) / 16 * 16;
+    char* ws = (char*)cmpc_ws(fbytes + (size_t)npair * nwg * 2 * sizeof(double));
+    if (!ws) return CMPC_EHIP;
+    *part = (float*)ws; *dpart = (double*)(ws + fbytes);
+    return CMPC_OK;
+}
+
 extern "C" int cmpc_convlstm_a(int dt, void* Yg, const void* c_prev, const float* W_ci, const float* W_cf, double* sums,
                                int B, int N, int ld, int M, void* stream) {
     if (!ok("convlstm_a", dt, ld, M)) return CMPC_EINVAL;
-    if (hipMemsetAsync(sums, 0, sizeof(double) * 5 * B * 2, ST) != hipSuccess) { cmpc_set_error("convlstm_a: memset"); return CMPC_EHIP; }
-    CMPC_DISPATCH_DT(dt, hipLaunchKernelGGL((clstm_a_kernel<T>), dim3(rows_grid(N, 200), B), dim3(256), 0, ST,
-                                             (T*)Yg, (const T*)c_prev, W_ci, W_cf, sums, B, N, ld, M));
+    const int gx = rows_grid(N, 100);
+    float* part; double* dpart;
+    if (clstm_ws((long)B * gx, 0, 3, ld, &part, &dpart)) return CMPC_EHIP;
+    CMPC_DISPATCH_DT(dt, hipLaunchKernelGGL((clstm_a_kernel<T>), dim3(gx, B), dim3(256), 0, ST,
+                                             (T*)Yg, (const T*)c_prev, W_ci, W_cf, dpart, B, N, ld, M));
+    for (int q = 0; q < 3; ++q)
+        if (cmpc_reduce_parts_f64(dpart + (long)q * B * gx * 2, B, gx, 2, sums + (long)q * B * 2, ST)) return CMPC_EHIP;
     return cmpc_check_launch("convlstm_a");
 }
 
 extern "C" int cmpc_convlstm_b(int dt, void* Yg, const void* c_prev, const float* W_co, const cmpc_convlstm_ln* ln,
                                double* sums, void* c_pre, int B, int N, int ld, int M, void* stream) {
     if (!ok("convlstm_b", dt, ld, M)) return CMPC_EINVAL;
-    CMPC_DISPATCH_DT(dt, hipLaunchKernelGGL((clstm_b_kernel<T>), dim3(rows_grid(N, 200), B), dim3(256), 0, ST,
-                                             (T*)Yg, (const T*)c_prev, W_co, to_lnp(ln), sums, (T*)c_pre, B, N, ld, M));
+    const int gx = rows_grid(N, 100);
+    float* part; double* dpart;
+    if (clstm_ws((long)B * gx, 0, 2, ld, &part, &dpart)) return CMPC_EHIP;
+    CMPC_DISPATCH_DT(dt, hipLaunchKernelGGL((clstm_b_kernel<T>), dim3(gx, B), dim3(256), 0, ST,
+                                             (T*)Yg, (const T*)c_prev, W_co, to_lnp(ln), sums, dpart, (T*)c_pre, B, N, ld, M));
+    for (int q = 0; q < 2; ++q)
+        if (cmpc_reduce_parts_f64(dpart + (long)q * B * gx * 2, B, gx, 2, sums + (long)(3 + q) * B * 2, ST)) return CMPC_EHIP;
     return cmpc_check_launch("convlstm_b");
 }
 
@@ -410,14 +432,29 @@ extern "C" int cmpc_convlstm_bwd(int dt, const void* dh, const void* dc_new, con
                                  float* dW_ci, float* dW_cf, float* dW_co, const cmpc_convlstm_dln* dln, void* scr, double* bsums,
                                  int B, int N, int ld, int M, void* stream) {
     if (!ok("convlstm_bwd", dt, ld, M)) return CMPC_EINVAL;
-    if (hipMemsetAsync(bsums, 0, sizeof(double) * 5 * B * 2, ST) != hipSuccess) { cmpc_set_error("convlstm_bwd: memset"); return CMPC_EHIP; }
     const size_t lds = WPB * ld * sizeof(float);
-    CMPC_DISPATCH_DT(dt, {
-        hipLaunchKernelGGL((clstm_bwd1_kernel<T>), dim3(rows_grid(N, 100), B), dim3(256), lds, ST,
-                           (const T*)dh, (const T*)dc_new, (const T*)Yg, (const T*)c_pre, to_lnp(ln), sums, (T*)dYg, (T*)scr, to_lng(dln), bsums, B, N, ld, M);
-        hipLaunchKernelGGL((clstm_bwd2_kernel<T>), dim3(rows_grid(N, 100), B), dim3(256), lds, ST,
+    const int gx = rows_grid(N, 64);
+    const long nwg = (long)B * gx;
+    float* part; double* dpart;
+    if (clstm_ws(nwg, 6, 3, ld, &part, &dpart)) return CMPC_EHIP;
+    // pass 1: LN(o), LN(c) dxhat + their statistics / parameter gradients
+    CMPC_DISPATCH_DT(dt, hipLaunchKernelGGL((clstm_bwd1_kernel<T>), dim3(gx, B), dim3(256), lds, ST,
+                           (const T*)dh, (const T*)dc_new, (const T*)Yg, (const T*)c_pre, to_lnp(ln), sums, (T*)dYg, (T*)scr, part, dpart, B, N, ld, M));
+    for (int q = 0; q < 2; ++q) {
+        if (cmpc_reduce_parts_f64(dpart + (long)q * nwg * 2, B, gx, 2, bsums + (long)(3 + q) * B * 2, ST)) return CMPC_EHIP;
+        if (cmpc_reduce_parts_f32(part + (2 * q) * ld, 4 * ld, 1, (int)nwg, 1, ld, M, dln->dgamma[3 + q], 0, 0, 1, ST)) return CMPC_EHIP;
+        if (cmpc_reduce_parts_f32(part + (2 * q + 1) * ld, 4 * ld, 1, (int)nwg, 1, ld, M, dln->dbeta[3 + q], 0, 0, 1, ST)) return CMPC_EHIP;
+    }
+    // pass 2: finish o, c; cell update; LN(j,i,f) dxhat + statistics
+    CMPC_DISPATCH_DT(dt, hipLaunchKernelGGL((clstm_bwd2_kernel<T>), dim3(gx, B), dim3(256), lds, ST,
                            (const T*)Yg, (const T*)c_prev, (const T*)c_pre, W_co, to_lnp(ln), sums, bsums, (T*)dYg, (const T*)scr, (T*)dc_prev,
-                           dW_co, to_lng(dln), bsums, B, N, ld, M);
+                           part, dpart, B, N, ld, M));
+    for (int q = 0; q < 3; ++q) {
+        if (cmpc_reduce_parts_f64(dpart + (long)q * nwg * 2, B, gx, 2, bsums + (long)q * B * 2, ST)) return CMPC_EHIP;
+        if (cmpc_reduce_parts_f32(part + (2 * q) * ld, 6 * ld, 1, (int)nwg, 1, ld, M, dln->dgamma[q], 0, 0, 1, ST)) return CMPC_EHIP;
+        if (cmpc_reduce_parts_f32(part + (2 * q + 1) * ld, 6 * ld, 1, (int)nwg, 1, ld, M, dln->dbeta[q], 0, 0, 1, ST)) return CMPC_EHIP;
+    }
+    CMPC_DISPATCH_DT(dt, {
         hipLaunchKernelGGL((clstm_bwd3_kernel<T>), dim3(rows_grid(N, 200), B), dim3(256), 0, ST,
                            (const T*)Yg, (const T*)c_prev, W_ci, W_cf, sums, bsums, (T*)dYg, (T*)dc_prev, dW_ci, dW_cf, B, N, ld, M);
         hipLaunchKernelGGL((clstm_peephole_grad_kernel<T>), dim3(rows_grid(N, 512)), dim3(256), 0, ST,

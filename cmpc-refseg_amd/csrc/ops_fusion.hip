@@ -69,7 +69,7 @@ __global__ __launch_bounds__(256) void mutan_fwd_kernel(T* __restrict__ P, const
 
 template <typename T>
 __global__ __launch_bounds__(256) void mutan_bwd_kernel(T* __restrict__ Th, const float* __restrict__ g, const T* __restrict__ X1,
-                                                       const float* __restrict__ rstd, const T* __restrict__ dX1, float* dg,
+                                                       const float* __restrict__ rstd, const T* __restrict__ dX1, float* part,
                                                        int N, int ld, int C) {
     extern __shared__ float lds[];     // [WPB][ld]
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, b = blockIdx.y;
@@ -141,10 +141,9 @@ __global__ __launch_bounds__(256) void mutan_bwd_kernel(T* __restrict__ Th, cons
             }
         }
         __syncthreads();
-        for (int c = threadIdx.x; c < C; c += 256) {
-            const float s = lds[c] + lds[ld + c] + lds[2 * ld + c] + lds[3 * ld + c];
-            if (s != 0.f) atomicAdd(dg + (long)b * 5 * ld + h * ld + c, s);
-        }
+        float* pr = part + (((long)b * gridDim.x + blockIdx.x) * 5 + h) * ld;      // this workgroup's partial row
+        for (int c = threadIdx.x; c < ld; c += 256)
+            pr[c] = (c < C) ? lds[c] + lds[ld + c] + lds[2 * ld + c] + lds[3 * ld + c] : 0.f;
     }
 }
 
@@ -375,7 +374,7 @@ __global__ __launch_bounds__(256) void exch_combine_bwd_kernel(const T* __restri
                                                               const T* __restrict__ r1, const T* __restrict__ r2,
                                                               const float* __restrict__ g1, const float* __restrict__ g2, int ld_g,
                                                               T* __restrict__ dfeat, int accumulate, T* __restrict__ dp1, T* __restrict__ dp2,
-                                                              float* dg1, float* dg2, int N, int ld, int C) {
+                                                              float* part, int N, int ld, int C) {
     extern __shared__ float lds[];     // [WPB][2*ld]
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, b = blockIdx.y;
     float a1[MB][8], a2[MB][8];
@@ -429,12 +428,13 @@ __global__ __launch_bounds__(256) void exch_combine_bwd_kernel(const T* __restri
         }
     }
     __syncthreads();
-    for (int c = threadIdx.x; c < C; c += 256) {
+    float* pr = part + ((long)b * gridDim.x + blockIdx.x) * 2 * ld;                 // partial rows [dg1 | dg2]
+    for (int c = threadIdx.x; c < ld; c += 256) {
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
         for (int ww = 0; ww < WPB; ++ww) { s1 += lds[(ww * 2) * ld + c]; s2 += lds[(ww * 2 + 1) * ld + c]; }
-        if (s1 != 0.f) atomicAdd(dg1 + (long)b * ld_g + c, s1);
-        if (s2 != 0.f) atomicAdd(dg2 + (long)b * ld_g + c, s2);
+        pr[c] = (c < C) ? s1 : 0.f;
+        pr[ld + c] = (c < C) ? s2 : 0.f;
     }
 }
 
@@ -460,8 +460,12 @@ extern "C" int cmpc_mutan_fwd(int dt, void* P, const float* g, void* X1, float* 
 extern "C" int cmpc_mutan_bwd(int dt, void* Th, const float* g, const void* X1, const float* rstd, const void* dX1,
                               float* dg, int B, int N, int ld, int C, void* stream) {
     if (!map_ok("mutan_bwd", ld, C, dt)) return CMPC_EINVAL;
-    CMPC_DISPATCH_DT(dt, hipLaunchKernelGGL((mutan_bwd_kernel<T>), dim3(rows_grid(N, 100), B), dim3(256), WPB * ld * sizeof(float), ST,
-                                             (T*)Th, g, (const T*)X1, rstd, (const T*)dX1, dg, N, ld, C));
+    const int gx = rows_grid(N, 64);
+    float* part = (float*)cmpc_ws((size_t)B * gx * 5 * ld * sizeof(float));
+    if (!part) return CMPC_EHIP;
+    CMPC_DISPATCH_DT(dt, hipLaunchKernelGGL((mutan_bwd_kernel<T>), dim3(gx, B), dim3(256), WPB * ld * sizeof(float), ST,
+                                             (T*)Th, g, (const T*)X1, rstd, (const T*)dX1, part, N, ld, C));
+    if (cmpc_reduce_parts_f32(part, 5L * ld, B, gx, 5, ld, C, dg, 5L * ld, ld, 1, ST)) return CMPC_EHIP;
     return cmpc_check_launch("mutan_bwd");
 }
 
@@ -519,8 +523,13 @@ extern "C" int cmpc_exchange_combine_bwd(int dt, const void* dout, const void* o
                                          const float* g1, const float* g2, int ld_g, void* dfeat, int accumulate_dfeat,
                                          void* dp1, void* dp2, float* dg1, float* dg2, int B, int N, int ld, int C, void* stream) {
     if (!map_ok("exchange_combine_bwd", ld, C, dt)) return CMPC_EINVAL;
-    CMPC_DISPATCH_DT(dt, hipLaunchKernelGGL((exch_combine_bwd_kernel<T>), dim3(rows_grid(N, 100), B), dim3(256), WPB * 2 * ld * sizeof(float), ST,
+    const int gx = rows_grid(N, 64);
+    float* part = (float*)cmpc_ws((size_t)B * gx * 2 * ld * sizeof(float));
+    if (!part) return CMPC_EHIP;
+    CMPC_DISPATCH_DT(dt, hipLaunchKernelGGL((exch_combine_bwd_kernel<T>), dim3(gx, B), dim3(256), WPB * 2 * ld * sizeof(float), ST,
                                              (const T*)dout, (const T*)out, rstd, (const T*)r1, (const T*)r2, g1, g2, ld_g,
-                                             (T*)dfeat, accumulate_dfeat, (T*)dp1, (T*)dp2, dg1, dg2, N, ld, C));
+                                             (T*)dfeat, accumulate_dfeat, (T*)dp1, (T*)dp2, part, N, ld, C));
+    if (cmpc_reduce_parts_f32(part, 2L * ld, B, gx, 1, ld, C, dg1, ld_g, 0, 1, ST)) return CMPC_EHIP;
+    if (cmpc_reduce_parts_f32(part + ld, 2L * ld, B, gx, 1, ld, C, dg2, ld_g, 0, 1, ST)) return CMPC_EHIP;
     return cmpc_check_launch("exchange_combine_bwd");
 }

@@ -20,6 +20,72 @@ int cmpc_check_launch(const char* what) {
     return CMPC_OK;
 }
 extern "C" const char* cmpc_last_error(void) { return g_err; }
+
+static void* g_ws = nullptr;
+static size_t g_ws_bytes = 0;
+void* cmpc_ws(size_t bytes) {
+    if (bytes > g_ws_bytes) {
+        if (g_ws) (void)hipFree(g_ws);
+        const size_t want = bytes < ((size_t)32 << 20) ? ((size_t)32 << 20) : bytes * 2;
+        if (hipMalloc(&g_ws, want) != hipSuccess) { g_ws = nullptr; g_ws_bytes = 0; cmpc_set_error("workspace allocation of %zu bytes failed", want); return nullptr; }
+        g_ws_bytes = want;
+    }
+    return g_ws;
+}
+
+// Column-parallel fold of per-workgroup partial rows: a block owns 64 columns (lane = column, so every
+// part row is read as one 256-B line), its 4 waves and gridDim.z slices split the rows; the few
+// slices of one column meet in a low-contention atomic.
+__global__ __launch_bounds__(256) void reduce_parts_f32_kernel(const float* __restrict__ part, long part_stride, int ninner, int nseg, int seg_ld, int seg_C,
+                                                              float* __restrict__ out, long ld_out, long out_seg) {
+    __shared__ float red[4][64];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int j = blockIdx.x * 64 + lane;
+    const int o = blockIdx.y;
+    const bool ok = j < nseg * seg_ld;
+    const int seg = ok ? j / seg_ld : 0, c = ok ? j - seg * seg_ld : 0;
+    const bool valid = ok && c < seg_C;
+    const int per = (ninner + gridDim.z - 1) / gridDim.z;
+    const int i0 = blockIdx.z * per, i1 = min(ninner, i0 + per);
+    const float* p = part + (long)o * ninner * part_stride + j;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    if (valid) {
+        int i = i0 + w;
+        for (; i + 12 < i1; i += 16) {
+            s0 += p[(long)i * part_stride]; s1 += p[(long)(i + 4) * part_stride];
+            s2 += p[(long)(i + 8) * part_stride]; s3 += p[(long)(i + 12) * part_stride];
+        }
+        for (; i < i1; i += 4) s0 += p[(long)i * part_stride];
+    }
+    red[w][lane] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    if (w == 0 && valid) {
+        const float s = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+        if (s != 0.f) atomicAdd(out + (long)o * ld_out + (long)seg * out_seg + c, s);
+    }
+}
+__global__ __launch_bounds__(64) void reduce_parts_f64_kernel(const double* __restrict__ part, int ninner, int nval, double* __restrict__ out) {
+    const int lane = threadIdx.x, o = blockIdx.x;
+    for (int v = 0; v < nval; ++v) {
+        double s = 0.0;
+        for (int i = lane; i < ninner; i += 64) s += part[((long)o * ninner + i) * nval + v];
+        s = wave_sum_d(s);
+        if (lane == 0) out[(long)o * nval + v] = s;
+    }
+}
+int cmpc_reduce_parts_f32(const float* part, long part_stride, int nouter, int ninner, int nseg, int seg_ld, int seg_C,
+                          float* out, long ld_out, long out_seg, int accumulate, hipStream_t st) {
+    const int cols = nseg * seg_ld;
+    if (!accumulate) { cmpc_set_error("reduce_parts_f32: only the accumulating form is implemented"); return CMPC_EINVAL; }
+    int nz = ninner / 32; nz = nz < 1 ? 1 : (nz > 16 ? 16 : nz);
+    hipLaunchKernelGGL(reduce_parts_f32_kernel, dim3((cols + 63) / 64, nouter, nz), dim3(256), 0, st, part, part_stride, ninner, nseg, seg_ld, seg_C,
+                       out, ld_out, out_seg);
+    return cmpc_check_launch("reduce_parts_f32");
+}
+int cmpc_reduce_parts_f64(const double* part, int nouter, int ninner, int nval, double* out, hipStream_t st) {
+    hipLaunchKernelGGL(reduce_parts_f64_kernel, dim3(nouter), dim3(64), 0, st, part, ninner, nval, out);
+    return cmpc_check_launch("reduce_parts_f64");
+}
 extern "C" int cmpc_abi_version(void) { return 1; }
 
 namespace {
@@ -29,7 +95,8 @@ constexpr int WPB = 4;         // waves per 256-thread block
 
 __host__ inline int rows_grid(int N) { int g = (N + WPB - 1) / WPB; return g < 1 ? 1 : (g > 400 ? 400 : g); }
 
-// flush per-lane column accumulators (lane owns columns blk*512 + lane*8 + e) into out[c] (atomics)
+// per-lane column accumulators (lane owns columns blk*512 + lane*8 + e) -> this workgroup's partial row
+// out[0..ld) (plain stores; a reduce_parts launch folds the rows: no contended atomics)
 __device__ __forceinline__ void colsum_flush(const float (&acc)[MAXBLK][8], float* out, int ld, int C, float* lds) {
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     __syncthreads();
@@ -42,10 +109,8 @@ __device__ __forceinline__ void colsum_flush(const float (&acc)[MAXBLK][8], floa
         }
     }
     __syncthreads();
-    for (int c = threadIdx.x; c < C; c += 256) {
-        const float s = lds[c] + lds[ld + c] + lds[2 * ld + c] + lds[3 * ld + c];
-        if (s != 0.0f) atomicAdd(out + c, s);
-    }
+    for (int c = threadIdx.x; c < ld; c += 256)
+        out[c] = (c < C) ? lds[c] + lds[ld + c] + lds[2 * ld + c] + lds[3 * ld + c] : 0.f;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -69,7 +134,7 @@ __global__ void axpy_kernel(const T* __restrict__ x, T* __restrict__ y, float a,
 // dpre = dy * act'(y); db[c] += sum; dsb[b][c] += per-sample sums
 template <typename T>
 __global__ __launch_bounds__(256) void act_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ y, T* __restrict__ dpre,
-                                                     int act, int N, int stride, int ld, int C, float* db, float* dsb, int ld_dsb) {
+                                                     int act, int N, int stride, int ld, int C, float* part) {
     extern __shared__ float lds[];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, b = blockIdx.y;
     float acc[MAXBLK][8];
@@ -96,13 +161,12 @@ __global__ __launch_bounds__(256) void act_bwd_kernel(const T* __restrict__ dy, 
             }
         }
     }
-    if (db) colsum_flush(acc, db, ld, C, lds);
-    if (dsb) colsum_flush(acc, dsb + (long)b * ld_dsb, ld, C, lds);
+    if (part) colsum_flush(acc, part + ((long)b * gridDim.x + blockIdx.x) * ld, ld, C, lds);
 }
 
 // out[b,c] += sum_n w[b,n] * x[b,n,c]
 template <typename T>
-__global__ __launch_bounds__(256) void wcolsum_kernel(const T* __restrict__ x, const float* __restrict__ wgt, float* out, int ld_out,
+__global__ __launch_bounds__(256) void wcolsum_kernel(const T* __restrict__ x, const float* __restrict__ wgt, float* part,
                                                      int N, int ld, int C, float scale) {
     extern __shared__ float lds[];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, b = blockIdx.y;
@@ -125,7 +189,7 @@ __global__ __launch_bounds__(256) void wcolsum_kernel(const T* __restrict__ x, c
             }
         }
     }
-    colsum_flush(acc, out + (long)b * ld_out, ld, C, lds);
+    colsum_flush(acc, part + ((long)b * gridDim.x + blockIdx.x) * ld, ld, C, lds);
 }
 
 // s[b,n] = scale * x[b,n,:] . v[b,:]
@@ -275,7 +339,7 @@ __global__ __launch_bounds__(256) void l2norm_bwd_kernel(const T* __restrict__ d
 // per-sample {sum x, sum x^2} over (n, c < C)
 // ------------------------------------------------------------------------------------------
 template <typename T>
-__global__ __launch_bounds__(256) void sample_stats_kernel(const T* __restrict__ x, double* __restrict__ sums, int N, int ld, int C) {
+__global__ __launch_bounds__(256) void sample_stats_kernel(const T* __restrict__ x, double* __restrict__ dpart, int N, int ld, int C) {
     __shared__ double red[2][WPB];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, b = blockIdx.y;
     double s1 = 0.0, s2 = 0.0;
@@ -294,8 +358,9 @@ __global__ __launch_bounds__(256) void sample_stats_kernel(const T* __restrict__
     if (lane == 0) { red[0][w] = s1; red[1][w] = s2; }
     __syncthreads();
     if (threadIdx.x == 0) {
-        atomicAdd(sums + 2 * b, red[0][0] + red[0][1] + red[0][2] + red[0][3]);
-        atomicAdd(sums + 2 * b + 1, red[1][0] + red[1][1] + red[1][2] + red[1][3]);
+        double* d = dpart + ((long)b * gridDim.x + blockIdx.x) * 2;
+        d[0] = red[0][0] + red[0][1] + red[0][2] + red[0][3];
+        d[1] = red[1][0] + red[1][1] + red[1][2] + red[1][3];
     }
 }
 
@@ -330,7 +395,7 @@ template <typename T>
 __global__ __launch_bounds__(256) void gconv_pre_bwd1_kernel(const T* __restrict__ dG, const T* __restrict__ G, const T* __restrict__ Y,
                                                             const double* __restrict__ sums, const float* __restrict__ gamma,
                                                             T* __restrict__ dX, int accumulate_dX, T* __restrict__ dY,
-                                                            float* dgamma, float* dbeta, double* bsums, int N, int ld, int C) {
+                                                            float* part, double* dpart, int N, int ld, int C) {
     extern __shared__ float lds[];
     __shared__ double red[2][WPB];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, b = blockIdx.y;
@@ -372,12 +437,13 @@ __global__ __launch_bounds__(256) void gconv_pre_bwd1_kernel(const T* __restrict
     s1 = wave_sum_d(s1); s2 = wave_sum_d(s2);
     if (lane == 0) { red[0][w] = s1; red[1][w] = s2; }
     __syncthreads();
+    const long wg = (long)b * gridDim.x + blockIdx.x;
     if (threadIdx.x == 0) {
-        atomicAdd(bsums + 2 * b, red[0][0] + red[0][1] + red[0][2] + red[0][3]);
-        atomicAdd(bsums + 2 * b + 1, red[1][0] + red[1][1] + red[1][2] + red[1][3]);
+        dpart[wg * 2] = red[0][0] + red[0][1] + red[0][2] + red[0][3];
+        dpart[wg * 2 + 1] = red[1][0] + red[1][1] + red[1][2] + red[1][3];
     }
-    colsum_flush(ag, dgamma, ld, C, lds);
-    colsum_flush(ab, dbeta, ld, C, lds);
+    colsum_flush(ag, part + wg * 2 * ld, ld, C, lds);
+    colsum_flush(ab, part + wg * 2 * ld + ld, ld, C, lds);
 }
 
 // pass 2: dY = rstd * (dxh - mean(dxh) - xhat * mean(dxh*xhat))   (in place on dY; xsrc = pre-LN input)
@@ -449,7 +515,7 @@ __global__ __launch_bounds__(256) void gconv_post_fwd_kernel(const T* __restrict
 template <typename T>
 __global__ __launch_bounds__(256) void gconv_post_bwd1_kernel(const T* __restrict__ dout, const T* __restrict__ out, const float* __restrict__ rstd_row,
                                                              const T* __restrict__ U, const double* __restrict__ sums, const float* __restrict__ gamma,
-                                                             T* __restrict__ dU, float* dgamma, float* dbeta, double* bsums, int N, int ld, int C) {
+                                                             T* __restrict__ dU, float* part, double* dpart, int N, int ld, int C) {
     extern __shared__ float lds[];
     __shared__ double red[2][WPB];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, b = blockIdx.y;
@@ -504,12 +570,13 @@ __global__ __launch_bounds__(256) void gconv_post_bwd1_kernel(const T* __restric
     s1 = wave_sum_d(s1); s2 = wave_sum_d(s2);
     if (lane == 0) { red[0][w] = s1; red[1][w] = s2; }
     __syncthreads();
+    const long wg = (long)b * gridDim.x + blockIdx.x;
     if (threadIdx.x == 0) {
-        atomicAdd(bsums + 2 * b, red[0][0] + red[0][1] + red[0][2] + red[0][3]);
-        atomicAdd(bsums + 2 * b + 1, red[1][0] + red[1][1] + red[1][2] + red[1][3]);
+        dpart[wg * 2] = red[0][0] + red[0][1] + red[0][2] + red[0][3];
+        dpart[wg * 2 + 1] = red[1][0] + red[1][1] + red[1][2] + red[1][3];
     }
-    colsum_flush(ag, dgamma, ld, C, lds);
-    colsum_flush(ab, dbeta, ld, C, lds);
+    colsum_flush(ag, part + wg * 2 * ld, ld, C, lds);
+    colsum_flush(ab, part + wg * 2 * ld + ld, ld, C, lds);
 }
 
 bool map_ok(const char* what, int ld, int C, int dt) {
@@ -562,15 +629,23 @@ extern "C" int cmpc_act_bwd(int dt, const void* dy, const void* y, void* dpre, i
     if (dsb) { if (rows_per_sample <= 0 || R % rows_per_sample) { cmpc_set_error("act_bwd: bad rows_per_sample"); return CMPC_EINVAL; } N = rows_per_sample; B = R / N; }
     if (R == 0) return CMPC_OK;
     const int gx = dsb ? (rows_grid(N) > 64 ? 64 : rows_grid(N)) : ((R + 3) / 4 > 512 ? 512 : (R + 3) / 4);
+    float* part = nullptr;
+    if (db || dsb) { part = (float*)cmpc_ws((size_t)B * gx * ld * sizeof(float)); if (!part) return CMPC_EHIP; }
     CMPC_DISPATCH_DT(dt, hipLaunchKernelGGL((act_bwd_kernel<T>), dim3(gx, B), dim3(256), WPB * ld * sizeof(float), ST,
-                                             (const T*)dy, (const T*)y, (T*)dpre, act, N, stride, ld, C, db, dsb, ld_dsb));
+                                             (const T*)dy, (const T*)y, (T*)dpre, act, N, stride, ld, C, part));
+    if (db && cmpc_reduce_parts_f32(part, ld, 1, B * gx, 1, ld, C, db, 0, 0, 1, ST)) return CMPC_EHIP;
+    if (dsb && cmpc_reduce_parts_f32(part, ld, B, gx, 1, ld, C, dsb, ld_dsb, 0, 1, ST)) return CMPC_EHIP;
     return cmpc_check_launch("act_bwd");
 }
 
 extern "C" int cmpc_wcolsum(int dt, const void* x, const float* w, float* out, int ld_out, int B, int N, int ld, int C, float scale, void* stream) {
     if (!map_ok("wcolsum", ld, C, dt)) return CMPC_EINVAL;
-    CMPC_DISPATCH_DT(dt, hipLaunchKernelGGL((wcolsum_kernel<T>), dim3(rows_grid(N) > 32 ? 32 : rows_grid(N), B), dim3(256), WPB * ld * sizeof(float), ST,
-                                             (const T*)x, w, out, ld_out, N, ld, C, scale));
+    const int gx = rows_grid(N) > 64 ? 64 : rows_grid(N);
+    float* part = (float*)cmpc_ws((size_t)B * gx * ld * sizeof(float));
+    if (!part) return CMPC_EHIP;
+    CMPC_DISPATCH_DT(dt, hipLaunchKernelGGL((wcolsum_kernel<T>), dim3(gx, B), dim3(256), WPB * ld * sizeof(float), ST,
+                                             (const T*)x, w, part, N, ld, C, scale));
+    if (cmpc_reduce_parts_f32(part, ld, B, gx, 1, ld, C, out, ld_out, 0, 1, ST)) return CMPC_EHIP;
     return cmpc_check_launch("wcolsum");
 }
 
@@ -605,8 +680,11 @@ extern "C" int cmpc_l2norm_rows_bwd(int dt, const void* dy, const void* y, const
 
 extern "C" int cmpc_sample_stats(int dt, const void* x, double* sums, int B, int N, int ld, int C, void* stream) {
     if (ld <= 0 || C > ld || ld % 8) { cmpc_set_error("sample_stats: bad ld/C"); return CMPC_EINVAL; }
-    if (hipMemsetAsync(sums, 0, sizeof(double) * 2 * B, ST) != hipSuccess) { cmpc_set_error("sample_stats: memset failed"); return CMPC_EHIP; }
-    CMPC_DISPATCH_DT(dt, hipLaunchKernelGGL((sample_stats_kernel<T>), dim3(rows_grid(N), B), dim3(256), 0, ST, (const T*)x, sums, N, ld, C));
+    const int gx = rows_grid(N) > 128 ? 128 : rows_grid(N);
+    double* dpart = (double*)cmpc_ws((size_t)B * gx * 2 * sizeof(double));
+    if (!dpart) return CMPC_EHIP;
+    CMPC_DISPATCH_DT(dt, hipLaunchKernelGGL((sample_stats_kernel<T>), dim3(gx, B), dim3(256), 0, ST, (const T*)x, dpart, N, ld, C));
+    if (cmpc_reduce_parts_f64(dpart, B, gx, 2, sums, ST)) return CMPC_EHIP;
     return cmpc_check_launch("sample_stats");
 }
 
@@ -618,16 +696,28 @@ extern "C" int cmpc_gconv_pre_fwd(int dt, const void* Y, const void* X, const do
     return cmpc_check_launch("gconv_pre_fwd");
 }
 
+// workspace layout of the LN-backward first passes: [B*gx][2][ld] fp32 column partials, then [B*gx][2] fp64
+static int ln_bwd_ws(int B, int gx, int ld, float** part, double** dpart) {
+    const size_t fbytes = ((size_t)B * gx * 2 * ld * sizeof(float) + 15) / 16 * 16;
+    char* ws = (char*)cmpc_ws(fbytes + (size_t)B * gx * 2 * sizeof(double));
+    if (!ws) return CMPC_EHIP;
+    *part = (float*)ws; *dpart = (double*)(ws + fbytes);
+    return CMPC_OK;
+}
+
 extern "C" int cmpc_gconv_pre_bwd(int dt, const void* dG, const void* G, const void* Y, const double* sums, const float* gamma,
                                   void* dX, int accumulate_dX, void* dY, float* dgamma, float* dbeta, double* bsums,
                                   int B, int N, int ld, int C, void* stream) {
     if (!map_ok("gconv_pre_bwd", ld, C, dt)) return CMPC_EINVAL;
-    if (hipMemsetAsync(bsums, 0, sizeof(double) * 2 * B, ST) != hipSuccess) { cmpc_set_error("gconv_pre_bwd: memset failed"); return CMPC_EHIP; }
-    CMPC_DISPATCH_DT(dt, {
-        hipLaunchKernelGGL((gconv_pre_bwd1_kernel<T>), dim3(rows_grid(N) > 100 ? 100 : rows_grid(N), B), dim3(256), WPB * ld * sizeof(float), ST,
-                           (const T*)dG, (const T*)G, (const T*)Y, sums, gamma, (T*)dX, accumulate_dX, (T*)dY, dgamma, dbeta, bsums, N, ld, C);
-        hipLaunchKernelGGL((ln_bwd2_kernel<T>), dim3(rows_grid(N), B), dim3(256), 0, ST, (T*)dY, (const T*)Y, sums, bsums, N, ld, C);
-    });
+    const int gx = rows_grid(N) > 64 ? 64 : rows_grid(N);
+    float* part; double* dpart;
+    if (ln_bwd_ws(B, gx, ld, &part, &dpart)) return CMPC_EHIP;
+    CMPC_DISPATCH_DT(dt, hipLaunchKernelGGL((gconv_pre_bwd1_kernel<T>), dim3(gx, B), dim3(256), WPB * ld * sizeof(float), ST,
+                           (const T*)dG, (const T*)G, (const T*)Y, sums, gamma, (T*)dX, accumulate_dX, (T*)dY, part, dpart, N, ld, C));
+    if (cmpc_reduce_parts_f64(dpart, B, gx, 2, bsums, ST)) return CMPC_EHIP;
+    if (cmpc_reduce_parts_f32(part, 2 * ld, 1, B * gx, 1, ld, C, dgamma, 0, 0, 1, ST)) return CMPC_EHIP;
+    if (cmpc_reduce_parts_f32(part + ld, 2 * ld, 1, B * gx, 1, ld, C, dbeta, 0, 0, 1, ST)) return CMPC_EHIP;
+    CMPC_DISPATCH_DT(dt, hipLaunchKernelGGL((ln_bwd2_kernel<T>), dim3(rows_grid(N), B), dim3(256), 0, ST, (T*)dY, (const T*)Y, sums, bsums, N, ld, C));
     return cmpc_check_launch("gconv_pre_bwd");
 }
 
@@ -643,11 +733,14 @@ extern "C" int cmpc_gconv_post_bwd(int dt, const void* dout, const void* out, co
                                    const double* sums, const float* gamma, void* dU, float* dgamma, float* dbeta, double* bsums,
                                    int B, int N, int ld, int C, void* stream) {
     if (!map_ok("gconv_post_bwd", ld, C, dt)) return CMPC_EINVAL;
-    if (hipMemsetAsync(bsums, 0, sizeof(double) * 2 * B, ST) != hipSuccess) { cmpc_set_error("gconv_post_bwd: memset failed"); return CMPC_EHIP; }
-    CMPC_DISPATCH_DT(dt, {
-        hipLaunchKernelGGL((gconv_post_bwd1_kernel<T>), dim3(rows_grid(N) > 100 ? 100 : rows_grid(N), B), dim3(256), WPB * ld * sizeof(float), ST,
-                           (const T*)dout, (const T*)out, rstd_row, (const T*)U, sums, gamma, (T*)dU, dgamma, dbeta, bsums, N, ld, C);
-        hipLaunchKernelGGL((ln_bwd2_kernel<T>), dim3(rows_grid(N), B), dim3(256), 0, ST, (T*)dU, (const T*)U, sums, bsums, N, ld, C);
-    });
+    const int gx = rows_grid(N) > 64 ? 64 : rows_grid(N);
+    float* part; double* dpart;
+    if (ln_bwd_ws(B, gx, ld, &part, &dpart)) return CMPC_EHIP;
+    CMPC_DISPATCH_DT(dt, hipLaunchKernelGGL((gconv_post_bwd1_kernel<T>), dim3(gx, B), dim3(256), WPB * ld * sizeof(float), ST,
+                           (const T*)dout, (const T*)out, rstd_row, (const T*)U, sums, gamma, (T*)dU, part, dpart, N, ld, C));
+    if (cmpc_reduce_parts_f64(dpart, B, gx, 2, bsums, ST)) return CMPC_EHIP;
+    if (cmpc_reduce_parts_f32(part, 2 * ld, 1, B * gx, 1, ld, C, dgamma, 0, 0, 1, ST)) return CMPC_EHIP;
+    if (cmpc_reduce_parts_f32(part + ld, 2 * ld, 1, B * gx, 1, ld, C, dbeta, 0, 0, 1, ST)) return CMPC_EHIP;
+    CMPC_DISPATCH_DT(dt, hipLaunchKernelGGL((ln_bwd2_kernel<T>), dim3(rows_grid(N), B), dim3(256), 0, ST, (T*)dU, (const T*)U, sums, bsums, N, ld, C));
     return cmpc_check_launch("gconv_post_bwd");
 }

@@ -94,7 +94,7 @@ __global__ __launch_bounds__(256) void score_conv_bwd_data_kernel(const float* _
 
 // dW[tap,m] += sum_pixels dscore[b, y-dy, x-dx] * feat[b,y,x,m];  dbias += sum dscore
 template <typename T>
-__global__ __launch_bounds__(256) void score_conv_bwd_w_kernel(const float* __restrict__ dscore, const T* __restrict__ feat, float* dWk, float* dbias,
+__global__ __launch_bounds__(256) void score_conv_bwd_w_kernel(const float* __restrict__ dscore, const T* __restrict__ feat, float* part, float* dbias,
                                                               int B, int h, int w, int ld, int M) {
     extern __shared__ float lds[];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -142,10 +142,9 @@ __global__ __launch_bounds__(256) void score_conv_bwd_w_kernel(const float* __re
             }
         }
         __syncthreads();
-        for (int c = threadIdx.x; c < M; c += 256) {
-            const float s = lds[c] + lds[ld + c] + lds[2 * ld + c] + lds[3 * ld + c];
-            if (s != 0.f) atomicAdd(dWk + t * M + c, s);
-        }
+        float* pr = part + ((long)blockIdx.x * 9 + t) * ld;                          // this workgroup's partial row of tap t
+        for (int c = threadIdx.x; c < ld; c += 256)
+            pr[c] = (c < M) ? lds[c] + lds[ld + c] + lds[2 * ld + c] + lds[3 * ld + c] : 0.f;
     }
     if (lane == 0 && sb != 0.f) atomicAdd(dbias, sb);
 }
@@ -244,9 +243,15 @@ extern "C" int cmpc_score_conv_bwd(int dt, const float* dscore, const void* feat
     CMPC_DISPATCH_DT(dt, {
         if (dfeat && ld <= 512) hipLaunchKernelGGL((score_conv_bwd_data_kernel<T, 1>), dim3(g), dim3(256), 0, ST, dscore, Wk, (T*)dfeat, accumulate, B, h, w, ld, M);
         else if (dfeat) hipLaunchKernelGGL((score_conv_bwd_data_kernel<T, 2>), dim3(g), dim3(256), 0, ST, dscore, Wk, (T*)dfeat, accumulate, B, h, w, ld, M);
-        if (dWk) hipLaunchKernelGGL((score_conv_bwd_w_kernel<T>), dim3(g > 128 ? 128 : g), dim3(256), WPB * ld * sizeof(float), ST,
-                                    dscore, (const T*)feat, dWk, dbias, B, h, w, ld, M);
     });
+    if (dWk) {
+        const int gw = g > 256 ? 256 : g;
+        float* part = (float*)cmpc_ws((size_t)gw * 9 * ld * sizeof(float));
+        if (!part) return CMPC_EHIP;
+        CMPC_DISPATCH_DT(dt, hipLaunchKernelGGL((score_conv_bwd_w_kernel<T>), dim3(gw), dim3(256), WPB * ld * sizeof(float), ST,
+                                                 dscore, (const T*)feat, part, dbias, B, h, w, ld, M));
+        if (cmpc_reduce_parts_f32(part, 9L * ld, 1, gw, 9, ld, M, dWk, 0, M, 1, ST)) return CMPC_EHIP;
+    }
     return cmpc_check_launch("score_conv_bwd");
 }
 
