@@ -62,7 +62,7 @@ class GemmTimer:
         ops, orig, me = self.ops, self.orig, self
 
         def timed(dt, segs, C, ldc, M, N, n_valid=None, batch=1, **kw):
-            if not me.on or dt != 1:
+            if not me.on or dt != 1 or N < 128 or M < 512:      # only launches that dispatch to gemm_nt_v2_kernel<bf16>
                 return orig(dt, segs, C, ldc, M, N, n_valid=n_valid, batch=batch, **kw)
             k_alg = sum(me.valid.get(s[4], s[4]) for s in segs)
             nv = N if n_valid is None else n_valid
@@ -167,13 +167,25 @@ def main():
         torch.cuda.synchronize()
         log(f"warmup step {i} done")
     barrier()
-    timer.on = True
     t0 = time.perf_counter()
     for _ in range(args.steps):
         _, scal = model.train_step(words, im, target, seq_len)
     barrier()
     dt = time.perf_counter() - t0
-    timer.on = False
+    # Per-launch timing of the dominant kernel: in the timed region above the three pyramid levels run
+    # on three streams, so a kernel's start->end event interval also contains other streams' kernels.
+    # The event pairs are therefore taken over the same K steps re-run on ONE stream (same kernels,
+    # same shapes, same data), which is also how the committed rocprof summary is collected.
+    if not args.no_kernel_timing:
+        model.set_streams(1)
+        model.train_step(words, im, target, seq_len)
+        torch.cuda.synchronize()
+        timer.on = True
+        for _ in range(args.steps):
+            model.train_step(words, im, target, seq_len)
+        torch.cuda.synchronize()
+        timer.on = False
+        model.set_streams(int(os.environ.get("CMPC_STREAMS", "3")))
     tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
     if world > 1:
         torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
@@ -196,7 +208,8 @@ def main():
             peak = 2500.0 if args.dtype == "bf16" else 157.3
             out["roofline"] = {"bound": "mfma", "achieved": f / t / 1e12, "peak": peak, "unit": "TFLOP/s",
                                "frac": f / t / 1e12 / peak, "traffic": None,
-                               "kernel": "gemm_nt_kernel<bf16> (all 1x1-conv / dX products of the head)",
+                               "kernel": "gemm_nt_v2_kernel<bf16> (all 1x1-conv / dX products of the head)",
+                               "measured": "event pairs around every launch over the same K steps re-run on one stream (the timed region overlaps 3 streams)",
                                "launches_per_step": n / args.steps, "ms_per_step_in_kernel": 1e3 * t / args.steps}
         if world == 1 and not args.no_cpu_baseline:
             log("cpu baseline (oracle on host cores)")

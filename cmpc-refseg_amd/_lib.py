@@ -168,10 +168,14 @@ def load():
 
 
 _DEBUG_SYNC = bool(os.environ.get("CMPC_DEBUG_SYNC"))
+_DEBUG_TRACE = os.environ.get("CMPC_DEBUG_TRACE")
 
 
 def call(name: str, *args):
     lib = load()
+    if _DEBUG_TRACE:                     # CMPC_DEBUG_TRACE=<file>: last line = the launch in flight when a fault hit
+        with open(_DEBUG_TRACE, "a") as f:
+            f.write(name + "\n")
     rc = getattr(lib, name)(*args)
     if rc != 0:
         raise CmpcError(f"{name} failed ({rc}): {lib.cmpc_last_error().decode()}")

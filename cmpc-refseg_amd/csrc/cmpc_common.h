@@ -19,8 +19,9 @@ enum { ACT_NONE = 0, ACT_RELU = 1, ACT_TANH = 2, ACT_SIGMOID = 3 };
 
 void cmpc_set_error(const char* fmt, ...);
 int cmpc_check_launch(const char* what);
-// Library-owned scratch for per-workgroup partial sums (grows on demand; single stream per process).
-void* cmpc_ws(size_t bytes);
+// Library-owned scratch for per-workgroup partial sums: one growing buffer PER STREAM (up to 64
+// streams), so stage operators running on different streams never share partial rows.
+void* cmpc_ws(size_t bytes, hipStream_t st);
 // out[o*ld_out + seg*out_seg + c] (+)= sum_{i<ninner} part[(o*ninner+i)*part_stride + seg*seg_ld + c], c < seg_C
 int cmpc_reduce_parts_f32(const float* part, long part_stride, int nouter, int ninner, int nseg, int seg_ld, int seg_C,
                           float* out, long ld_out, long out_seg, int accumulate, hipStream_t st);

@@ -384,9 +384,9 @@ LnG to_lng(const cmpc_convlstm_dln* l) { LnG p; for (int i = 0; i < 5; ++i) { p.
 #define ST ((hipStream_t)stream)
 
 // workspace: fp32 column partials [nwg][ncol][ld] followed by fp64 pair partials [npair][nwg][2]
-static int clstm_ws(long nwg, int ncol, int npair, int ld, float** part, double** dpart) {
+static int clstm_ws(long nwg, int ncol, int npair, int ld, float** part, double** dpart, hipStream_t st) {
     const size_t fbytes = ((size_t)nwg * ncol * ld * sizeof(float) + 15) / 16 * 16;
-    char* ws = (char*)cmpc_ws(fbytes + (size_t)npair * nwg * 2 * sizeof(double));
+    char* ws = (char*)cmpc_ws(fbytes + (size_t)npair * nwg * 2 * sizeof(double), st);
     if (!ws) return CMPC_EHIP;
     *part = (float*)ws; *dpart = (double*)(ws + fbytes);
     return CMPC_OK;
@@ -397,7 +397,7 @@ extern "C" int cmpc_convlstm_a(int dt, void* Yg, const void* c_prev, const float
     if (!ok("convlstm_a", dt, ld, M)) return CMPC_EINVAL;
     const int gx = rows_grid(N, 100);
     float* part; double* dpart;
-    if (clstm_ws((long)B * gx, 0, 3, ld, &part, &dpart)) return CMPC_EHIP;
+    if (clstm_ws((long)B * gx, 0, 3, ld, &part, &dpart, ST)) return CMPC_EHIP;
     CMPC_DISPATCH_DT(dt, hipLaunchKernelGGL((clstm_a_kernel<T>), dim3(gx, B), dim3(256), 0, ST,
                                              (T*)Yg, (const T*)c_prev, W_ci, W_cf, dpart, B, N, ld, M));
     for (int q = 0; q < 3; ++q)
@@ -410,7 +410,7 @@ extern "C" int cmpc_convlstm_b(int dt, void* Yg, const void* c_prev, const float
     if (!ok("convlstm_b", dt, ld, M)) return CMPC_EINVAL;
     const int gx = rows_grid(N, 100);
     float* part; double* dpart;
-    if (clstm_ws((long)B * gx, 0, 2, ld, &part, &dpart)) return CMPC_EHIP;
+    if (clstm_ws((long)B * gx, 0, 2, ld, &part, &dpart, ST)) return CMPC_EHIP;
     CMPC_DISPATCH_DT(dt, hipLaunchKernelGGL((clstm_b_kernel<T>), dim3(gx, B), dim3(256), 0, ST,
                                              (T*)Yg, (const T*)c_prev, W_co, to_lnp(ln), sums, dpart, (T*)c_pre, B, N, ld, M));
     for (int q = 0; q < 2; ++q)
@@ -436,7 +436,7 @@ extern "C" int cmpc_convlstm_bwd(int dt, const void* dh, const void* dc_new, con
     const int gx = rows_grid(N, 64);
     const long nwg = (long)B * gx;
     float* part; double* dpart;
-    if (clstm_ws(nwg, 6, 3, ld, &part, &dpart)) return CMPC_EHIP;
+    if (clstm_ws(nwg, 6, 3, ld, &part, &dpart, ST)) return CMPC_EHIP;
     // pass 1: LN(o), LN(c) dxhat + their statistics / parameter gradients
     CMPC_DISPATCH_DT(dt, hipLaunchKernelGGL((clstm_bwd1_kernel<T>), dim3(gx, B), dim3(256), lds, ST,
                            (const T*)dh, (const T*)dc_new, (const T*)Yg, (const T*)c_pre, to_lnp(ln), sums, (T*)dYg, (T*)scr, part, dpart, B, N, ld, M));

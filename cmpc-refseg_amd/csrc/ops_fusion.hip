@@ -461,7 +461,7 @@ extern "C" int cmpc_mutan_bwd(int dt, void* Th, const float* g, const void* X1, 
                               float* dg, int B, int N, int ld, int C, void* stream) {
     if (!map_ok("mutan_bwd", ld, C, dt)) return CMPC_EINVAL;
     const int gx = rows_grid(N, 64);
-    float* part = (float*)cmpc_ws((size_t)B * gx * 5 * ld * sizeof(float));
+    float* part = (float*)cmpc_ws((size_t)B * gx * 5 * ld * sizeof(float), ST);
     if (!part) return CMPC_EHIP;
     CMPC_DISPATCH_DT(dt, hipLaunchKernelGGL((mutan_bwd_kernel<T>), dim3(gx, B), dim3(256), WPB * ld * sizeof(float), ST,
                                              (T*)Th, g, (const T*)X1, rstd, (const T*)dX1, part, N, ld, C));
@@ -524,7 +524,7 @@ extern "C" int cmpc_exchange_combine_bwd(int dt, const void* dout, const void* o
                                          void* dp1, void* dp2, float* dg1, float* dg2, int B, int N, int ld, int C, void* stream) {
     if (!map_ok("exchange_combine_bwd", ld, C, dt)) return CMPC_EINVAL;
     const int gx = rows_grid(N, 64);
-    float* part = (float*)cmpc_ws((size_t)B * gx * 2 * ld * sizeof(float));
+    float* part = (float*)cmpc_ws((size_t)B * gx * 2 * ld * sizeof(float), ST);
     if (!part) return CMPC_EHIP;
     CMPC_DISPATCH_DT(dt, hipLaunchKernelGGL((exch_combine_bwd_kernel<T>), dim3(gx, B), dim3(256), WPB * 2 * ld * sizeof(float), ST,
                                              (const T*)dout, (const T*)out, rstd, (const T*)r1, (const T*)r2, g1, g2, ld_g,

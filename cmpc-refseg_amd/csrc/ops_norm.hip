@@ -21,16 +21,23 @@ int cmpc_check_launch(const char* what) {
 }
 extern "C" const char* cmpc_last_error(void) { return g_err; }
 
-static void* g_ws = nullptr;
-static size_t g_ws_bytes = 0;
-void* cmpc_ws(size_t bytes) {
-    if (bytes > g_ws_bytes) {
-        if (g_ws) (void)hipFree(g_ws);
-        const size_t want = bytes < ((size_t)32 << 20) ? ((size_t)32 << 20) : bytes * 2;
-        if (hipMalloc(&g_ws, want) != hipSuccess) { g_ws = nullptr; g_ws_bytes = 0; cmpc_set_error("workspace allocation of %zu bytes failed", want); return nullptr; }
-        g_ws_bytes = want;
+struct WsSlot { hipStream_t st; void* p; size_t bytes; bool used; };
+static WsSlot g_ws[64];
+void* cmpc_ws(size_t bytes, hipStream_t st) {
+    WsSlot* slot = nullptr;
+    for (auto& w : g_ws) if (w.used && w.st == st) { slot = &w; break; }
+    if (!slot) {
+        for (auto& w : g_ws) if (!w.used) { slot = &w; w.used = true; w.st = st; w.p = nullptr; w.bytes = 0; break; }
+        if (!slot) { cmpc_set_error("workspace: more than 64 streams in use"); return nullptr; }
     }
-    return g_ws;
+    if (bytes > slot->bytes) {
+        // growth only happens while shapes are first seen (never inside a steady-state step)
+        if (slot->p) { (void)hipStreamSynchronize(st); (void)hipFree(slot->p); }
+        const size_t want = bytes < ((size_t)32 << 20) ? ((size_t)32 << 20) : bytes * 2;
+        if (hipMalloc(&slot->p, want) != hipSuccess) { slot->p = nullptr; slot->bytes = 0; cmpc_set_error("workspace allocation of %zu bytes failed", want); return nullptr; }
+        slot->bytes = want;
+    }
+    return slot->p;
 }
 
 // Column-parallel fold of per-workgroup partial rows: a block owns 64 columns (lane = column, so every
@@ -630,7 +637,7 @@ extern "C" int cmpc_act_bwd(int dt, const void* dy, const void* y, void* dpre, i
     if (R == 0) return CMPC_OK;
     const int gx = dsb ? (rows_grid(N) > 64 ? 64 : rows_grid(N)) : ((R + 3) / 4 > 512 ? 512 : (R + 3) / 4);
     float* part = nullptr;
-    if (db || dsb) { part = (float*)cmpc_ws((size_t)B * gx * ld * sizeof(float)); if (!part) return CMPC_EHIP; }
+    if (db || dsb) { part = (float*)cmpc_ws((size_t)B * gx * ld * sizeof(float), ST); if (!part) return CMPC_EHIP; }
     CMPC_DISPATCH_DT(dt, hipLaunchKernelGGL((act_bwd_kernel<T>), dim3(gx, B), dim3(256), WPB * ld * sizeof(float), ST,
                                              (const T*)dy, (const T*)y, (T*)dpre, act, N, stride, ld, C, part));
     if (db && cmpc_reduce_parts_f32(part, ld, 1, B * gx, 1, ld, C, db, 0, 0, 1, ST)) return CMPC_EHIP;
@@ -641,7 +648,7 @@ extern "C" int cmpc_act_bwd(int dt, const void* dy, const void* y, void* dpre, i
 extern "C" int cmpc_wcolsum(int dt, const void* x, const float* w, float* out, int ld_out, int B, int N, int ld, int C, float scale, void* stream) {
     if (!map_ok("wcolsum", ld, C, dt)) return CMPC_EINVAL;
     const int gx = rows_grid(N) > 64 ? 64 : rows_grid(N);
-    float* part = (float*)cmpc_ws((size_t)B * gx * ld * sizeof(float));
+    float* part = (float*)cmpc_ws((size_t)B * gx * ld * sizeof(float), ST);
     if (!part) return CMPC_EHIP;
     CMPC_DISPATCH_DT(dt, hipLaunchKernelGGL((wcolsum_kernel<T>), dim3(gx, B), dim3(256), WPB * ld * sizeof(float), ST,
                                              (const T*)x, w, part, N, ld, C, scale));
@@ -681,7 +688,7 @@ extern "C" int cmpc_l2norm_rows_bwd(int dt, const void* dy, const void* y, const
 extern "C" int cmpc_sample_stats(int dt, const void* x, double* sums, int B, int N, int ld, int C, void* stream) {
     if (ld <= 0 || C > ld || ld % 8) { cmpc_set_error("sample_stats: bad ld/C"); return CMPC_EINVAL; }
     const int gx = rows_grid(N) > 128 ? 128 : rows_grid(N);
-    double* dpart = (double*)cmpc_ws((size_t)B * gx * 2 * sizeof(double));
+    double* dpart = (double*)cmpc_ws((size_t)B * gx * 2 * sizeof(double), ST);
     if (!dpart) return CMPC_EHIP;
     CMPC_DISPATCH_DT(dt, hipLaunchKernelGGL((sample_stats_kernel<T>), dim3(gx, B), dim3(256), 0, ST, (const T*)x, dpart, N, ld, C));
     if (cmpc_reduce_parts_f64(dpart, B, gx, 2, sums, ST)) return CMPC_EHIP;
@@ -697,9 +704,9 @@ extern "C" int cmpc_gconv_pre_fwd(int dt, const void* Y, const void* X, const do
 }
 
 // workspace layout of the LN-backward first passes: [B*gx][2][ld] fp32 column partials, then [B*gx][2] fp64
-static int ln_bwd_ws(int B, int gx, int ld, float** part, double** dpart) {
+static int ln_bwd_ws(int B, int gx, int ld, float** part, double** dpart, hipStream_t st) {
     const size_t fbytes = ((size_t)B * gx * 2 * ld * sizeof(float) + 15) / 16 * 16;
-    char* ws = (char*)cmpc_ws(fbytes + (size_t)B * gx * 2 * sizeof(double));
+    char* ws = (char*)cmpc_ws(fbytes + (size_t)B * gx * 2 * sizeof(double), st);
     if (!ws) return CMPC_EHIP;
     *part = (float*)ws; *dpart = (double*)(ws + fbytes);
     return CMPC_OK;
@@ -711,7 +718,7 @@ extern "C" int cmpc_gconv_pre_bwd(int dt, const void* dG, const void* G, const v
     if (!map_ok("gconv_pre_bwd", ld, C, dt)) return CMPC_EINVAL;
     const int gx = rows_grid(N) > 64 ? 64 : rows_grid(N);
     float* part; double* dpart;
-    if (ln_bwd_ws(B, gx, ld, &part, &dpart)) return CMPC_EHIP;
+    if (ln_bwd_ws(B, gx, ld, &part, &dpart, ST)) return CMPC_EHIP;
     CMPC_DISPATCH_DT(dt, hipLaunchKernelGGL((gconv_pre_bwd1_kernel<T>), dim3(gx, B), dim3(256), WPB * ld * sizeof(float), ST,
                            (const T*)dG, (const T*)G, (const T*)Y, sums, gamma, (T*)dX, accumulate_dX, (T*)dY, part, dpart, N, ld, C));
     if (cmpc_reduce_parts_f64(dpart, B, gx, 2, bsums, ST)) return CMPC_EHIP;
@@ -735,7 +742,7 @@ extern "C" int cmpc_gconv_post_bwd(int dt, const void* dout, const void* out, co
     if (!map_ok("gconv_post_bwd", ld, C, dt)) return CMPC_EINVAL;
     const int gx = rows_grid(N) > 64 ? 64 : rows_grid(N);
     float* part; double* dpart;
-    if (ln_bwd_ws(B, gx, ld, &part, &dpart)) return CMPC_EHIP;
+    if (ln_bwd_ws(B, gx, ld, &part, &dpart, ST)) return CMPC_EHIP;
     CMPC_DISPATCH_DT(dt, hipLaunchKernelGGL((gconv_post_bwd1_kernel<T>), dim3(gx, B), dim3(256), WPB * ld * sizeof(float), ST,
                            (const T*)dout, (const T*)out, rstd_row, (const T*)U, sums, gamma, (T*)dU, part, dpart, N, ld, C));
     if (cmpc_reduce_parts_f64(dpart, B, gx, 2, bsums, ST)) return CMPC_EHIP;

@@ -246,7 +246,7 @@ extern "C" int cmpc_score_conv_bwd(int dt, const float* dscore, const void* feat
     });
     if (dWk) {
         const int gw = g > 256 ? 256 : g;
-        float* part = (float*)cmpc_ws((size_t)gw * 9 * ld * sizeof(float));
+        float* part = (float*)cmpc_ws((size_t)gw * 9 * ld * sizeof(float), ST);
         if (!part) return CMPC_EHIP;
         CMPC_DISPATCH_DT(dt, hipLaunchKernelGGL((score_conv_bwd_w_kernel<T>), dim3(gw), dim3(256), WPB * ld * sizeof(float), ST,
                                                  dscore, (const T*)feat, part, dbias, B, h, w, ld, M));

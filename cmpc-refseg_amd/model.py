@@ -70,6 +70,23 @@ class LSTM_model(object):
         self.backbone = self.backbone.to(self.device).to(ops.tdt(self.dt)).to(memory_format=torch.channels_last).eval()
         self.world = 1
         self.last = {}
+        # the three pyramid levels (and the three exchange modules of a round) are independent: each gets
+        # its own HIP stream so HBM-bound stage kernels of one level overlap MFMA-bound GEMMs of another.
+        # autograd replays every backward on the stream of its forward, so the backward overlaps too.
+        self.set_streams(int(os.environ.get("CMPC_STREAMS", "3")))
+
+    _SIDE_STREAMS = {}          # device -> 3 side streams shared by every model on that device
+
+    def set_streams(self, n: int):
+        """n > 1: independent levels / exchange modules run on 3 side streams; n = 1: everything on the caller's stream."""
+        self.n_streams = n
+        if n > 1:
+            key = str(self.device)
+            if key not in LSTM_model._SIDE_STREAMS:
+                LSTM_model._SIDE_STREAMS[key] = [torch.cuda.Stream(device=self.device) for _ in range(3)]
+            self.side = LSTM_model._SIDE_STREAMS[key]
+        else:
+            self.side = None
 
     # ------------------------------------------------------------------------------------------
     def _check_feeds(self, words, im, seq_len, target=None):
@@ -106,25 +123,46 @@ class LSTM_model(object):
         vl = O.LangPool.apply(parse, wf, 2, cx)                 # valid_lang: entity + attribute
         out = {"words_feat": wf, "seq_mask": mask, "words_parse": parse}
         fus, losses = {}, {}
-        for lv, f in (("c5", c5), ("c4", c4), ("c3", c3)):
-            X0 = O.Lateral.apply(a, f, lv, cx)
-            X1 = O.Mutan.apply(X0, vl, lv, cx)
-            X2, gw_w, gw_v = O.SpaGraph.apply(X1, wf, parse, mask, lv, cx)
-            fus[lv] = O.Fusion.apply(X1, X2, vl, lv, cx)
-            out[f"lat_{lv}"], out[f"vis_la_sp_{lv}"], out[f"spa_graph_{lv}"], out[f"fusion_{lv}"] = X0, X1, X2, fus[lv]
-            out[f"gw_w_{lv}"], out[f"gw_v_{lv}"] = gw_w, gw_v
-        for lv in LEVELS:
-            l, sc, up, _s, _iu = O.ScoreHead.apply(fus[lv], f"score_{lv}", tgt, 0.1, cx)
-            out[f"score_{lv}"], out[f"up_{lv}"], losses[lv] = sc, up, l
+        main = torch.cuda.current_stream(self.device)
+
+        def fork(i):
+            """run a block on side stream i after everything queued so far on the main stream"""
+            if self.side is None:
+                return main
+            st = self.side[i]
+            st.wait_stream(main)
+            return st
+
+        def join():
+            if self.side is not None:
+                for st in self.side:
+                    main.wait_stream(st)
+
+        for i, (lv, f) in enumerate((("c5", c5), ("c4", c4), ("c3", c3))):
+            with torch.cuda.stream(fork(i)):
+                X0 = O.Lateral.apply(a, f, lv, cx)
+                X1 = O.Mutan.apply(X0, vl, lv, cx)
+                X2, gw_w, gw_v = O.SpaGraph.apply(X1, wf, parse, mask, lv, cx)
+                fus[lv] = O.Fusion.apply(X1, X2, vl, lv, cx)
+                out[f"lat_{lv}"], out[f"vis_la_sp_{lv}"], out[f"spa_graph_{lv}"], out[f"fusion_{lv}"] = X0, X1, X2, fus[lv]
+                out[f"gw_w_{lv}"], out[f"gw_v_{lv}"] = gw_w, gw_v
+                l, sc, up, _s, _iu = O.ScoreHead.apply(fus[lv], f"score_{lv}", tgt, 0.1, cx)
+                out[f"score_{lv}"], out[f"up_{lv}"], losses[lv] = sc, up, l
+        join()
         nec = O.LangPool.apply(parse, wf, 3, cx)                # nec_lang: entity + attribute + relation
         out["nec_lang"] = nec
         f3, f4, f5 = fus["c3"], fus["c4"], fus["c5"]
-        e3 = O.Exchange.apply(f3, f4, f5, nec, "c3", cx)
-        e4 = O.Exchange.apply(f4, f3, f5, nec, "c4", cx)
-        e5 = O.Exchange.apply(f5, f3, f4, nec, "c5", cx)
-        e32 = O.Exchange.apply(e3, e4, e5, nec, "c3_2", cx)
-        e42 = O.Exchange.apply(e4, e3, e5, nec, "c4_2", cx)
-        e52 = O.Exchange.apply(e5, e3, e4, nec, "c5_2", cx)
+        ex = {}
+        for i, (nm, fa, fb, fc) in enumerate((("c3", f3, f4, f5), ("c4", f4, f3, f5), ("c5", f5, f3, f4))):
+            with torch.cuda.stream(fork(i)):
+                ex[nm] = O.Exchange.apply(fa, fb, fc, nec, nm, cx)
+        join()
+        e3, e4, e5 = ex["c3"], ex["c4"], ex["c5"]
+        for i, (nm, fa, fb, fc) in enumerate((("c3_2", e3, e4, e5), ("c4_2", e4, e3, e5), ("c5_2", e5, e3, e4))):
+            with torch.cuda.stream(fork(i)):
+                ex[nm] = O.Exchange.apply(fa, fb, fc, nec, nm, cx)
+        join()
+        e32, e42, e52 = ex["c3_2"], ex["c4_2"], ex["c5_2"]
         out.update(exg_c3=e3, exg_c4=e4, exg_c5=e5, exg_c3_2=e32, exg_c4_2=e42, exg_c5_2=e52)
         fused = O.ConvLSTM.apply(e32, e42, e52, cx)
         out["fused"] = fused
@@ -160,6 +198,12 @@ class LSTM_model(object):
         self.store.zero_grads()
         o = self.head(feats, words, seq_len, target_fine)
         o["loss_all"].backward()
+        if self.side is not None:
+            # parameter gradients are written by the kernels themselves (not autograd leaves): the
+            # optimizer on the main stream must wait for every side stream's backward
+            main = torch.cuda.current_stream(self.device)
+            for st in self.side:
+                main.wait_stream(st)
         return o
 
     def train_step(self, words, im, target_fine, seq_len):

@@ -195,8 +195,8 @@ class TextEncoder(torch.autograd.Function):
                     accumulate=True)
         gk = ps.gptr("rnn/lstm_cell/kernel")
         gate_offs = lambda row0: tuple((0, g * Cp, row0 * 4 * R + g * R) for g in range(4))
-        gemm_tn(F32, emb, Gp, Gp, dg, 4 * Cp, 4 * Cp, gk, 4 * R, T * B, G, R, offs=gate_offs(0))
-        gemm_tn(F32, h_all, Cp, Cp, dg, 4 * Cp, 4 * Cp, gk, 4 * R, T * B, R, R, offs=gate_offs(G))
+        gemm_tn(F32, emb, Gp, Gp, dg, 4 * Cp, Cp, gk, 4 * R, T * B, G, R, offs=gate_offs(0))
+        gemm_tn(F32, h_all, Cp, Cp, dg, 4 * Cp, Cp, gk, 4 * R, T * B, R, R, offs=gate_offs(G))
         gb = ps.gptr("rnn/lstm_cell/bias")
         for g in range(4):
             colsum(F32, _p(dg) + 4 * g * Cp, T * B, 4 * Cp, Cp, R, db=gb + 4 * g * R)
@@ -347,8 +347,8 @@ class Mutan(torch.autograd.Function):
             offs_s.append((0, h * Cp, rel + C * C))
             colsum(dt, _p(dP) + h * Cp * e, R, 5 * Cp, Cp, C, db=ps.gptr(f"vis_trans_{lv}_head{h + 1}/biases"))
         gw = ps.gptr(f"vis_trans_{lv}_head1/DW")
-        gemm_tn(dt, X0, Cp, Cp, dP, 5 * Cp, 5 * Cp, gw, C, R, C, C, offs=offs_v)
-        gemm_tn(dt, cx.spatial, 64, 64, dP, 5 * Cp, 5 * Cp, gw, C, R, 8, C, offs=offs_s)
+        gemm_tn(dt, X0, Cp, Cp, dP, 5 * Cp, Cp, gw, C, R, C, C, offs=offs_v)
+        gemm_tn(dt, cx.spatial, 64, 64, dP, 5 * Cp, Cp, gw, C, R, 8, C, offs=offs_s)
         dX0 = empty((R, Cp), dt, dev)
         gemm_nt(dt, [(dP, 5 * Cp, cx.opp(f"mutan_{lv}.n"), 5 * Cp, 5 * Cp)], dX0, Cp, R, Cp, n_valid=C)
         # language gates
@@ -358,7 +358,7 @@ class Mutan(torch.autograd.Function):
             colsum(F32, _p(dg) + 4 * h * Cp, B, 5 * Cp, Cp, C, db=ps.gptr(f"lang_trans_{lv}_head{h + 1}/biases"),
                    y=_p(g) + 4 * h * Cp, dpre=_p(dg) + 4 * h * Cp, act=ACT_TANH)
             offs_l.append((0, h * Cp, ps.poff(f"lang_trans_{lv}_head{h + 1}/DW") - base_l))
-        gemm_tn(F32, vl, Cp, Cp, dg, 5 * Cp, 5 * Cp, ps.gptr(f"lang_trans_{lv}_head1/DW"), C, B, Rr, C, offs=offs_l)
+        gemm_tn(F32, vl, Cp, Cp, dg, 5 * Cp, Cp, ps.gptr(f"lang_trans_{lv}_head1/DW"), C, B, Rr, C, offs=offs_l)
         dvl = empty((B, Cp), F32, dev)
         gemm_nt(F32, [(dg, 5 * Cp, cx.opp(f"mlang_{lv}.n"), 5 * Cp, 5 * Cp)], dvl, Cp, B, Cp, n_valid=Rr)
         return dX0, dvl, None, None
@@ -736,12 +736,12 @@ class ConvLSTM(torch.autograd.Function):
                       ps.pptr(pre + "W_ci"), ps.pptr(pre + "W_cf"), ps.pptr(pre + "W_co"), ctypes.byref(ln), _p(sums),
                       _p(dYg), _p(dc_prev), ps.gptr(pre + "W_ci"), ps.gptr(pre + "W_cf"), ps.gptr(pre + "W_co"),
                       ctypes.byref(dln), _p(scr), _p(bs), B, N, Mp, M, _st())
-            gemm_tn(dt, x, Mp, Mp, dYg, 4 * Mp, 4 * Mp, gk, 4 * M, R, M, M, offs=tuple((0, g * Mp, g * M) for g in range(4)))
+            gemm_tn(dt, x, Mp, Mp, dYg, 4 * Mp, Mp, gk, 4 * M, R, M, M, offs=tuple((0, g * Mp, g * M) for g in range(4)))
             dx = empty((R, Mp), dt, dev)
             gemm_nt(dt, [(dYg, 4 * Mp, cx.opp("clstm.n"), 4 * Mp, 4 * Mp)], dx, Mp, R, Mp, n_valid=M)
             dxs[s] = dx
             if s > 0:
-                gemm_tn(dt, h_prev, Mp, Mp, dYg, 4 * Mp, 4 * Mp, gk, 4 * M, R, M, M,
+                gemm_tn(dt, h_prev, Mp, Mp, dYg, 4 * Mp, Mp, gk, 4 * M, R, M, M,
                         offs=tuple((0, g * Mp, M * 4 * M + g * M) for g in range(4)))
                 dh = empty((R, Mp), dt, dev)
                 gemm_nt(dt, [(dYg, 4 * Mp, cx.opp("clstm.n", Mp, 0), 4 * Mp, 4 * Mp)], dh, Mp, R, Mp, n_valid=M)

@@ -52,8 +52,8 @@ int cmpc_gemm_nt(const cmpc_gemm_nt_args* a, void* stream);
 
 typedef struct {
     int dtype;
-    const void* A; int lda; int Ka;     /* [R, Ka] */
-    const void* D; int ldd; int Nd;     /* [R, Nd] */
+    const void* A; int lda; int Ka;     /* rows of lda elements; Ka = columns READABLE from A + a_off[i] */
+    const void* D; int ldd; int Nd;     /* rows of ldd elements; Nd = columns READABLE from D + d_off[i] (block width when d_off selects a column block) */
     float* out; int ldo;                /* out[k, n] += alpha * sum_r A[r,k] D[r,n]  (fp32 atomics) */
     int R, Kv, Nv;                      /* reduction length, valid output rows / cols */
     int nb; int64_t a_off[8], d_off[8], o_off[8];  /* inner batch: element offsets */

@@ -52,7 +52,7 @@ for dt, tdt, tol in ((0, torch.float32, 2e-6), (1, torch.bfloat16, 2e-2)):
     R, K, N, nb2 = 200, 64, 64, 3
     A = torch.randn(nb2, R, K, device=dev).to(tdt); D = torch.randn(nb2, R, 2 * N, device=dev).to(tdt)
     out = torch.zeros(nb2, K, 2 * N, device=dev)
-    ops.gemm_tn(dt, A, K, K, D, 2 * N, 2 * N, out, 2 * N, R, K, N, offs=((0, 0, 0), (0, N, N)), nb2=nb2, a_bs=R * K, d_bs=R * 2 * N, o_bs=K * 2 * N, alpha=2.0)
+    ops.gemm_tn(dt, A, K, K, D, 2 * N, N, out, 2 * N, R, K, N, offs=((0, 0, 0), (0, N, N)), nb2=nb2, a_bs=R * K, d_bs=R * 2 * N, o_bs=K * 2 * N, alpha=2.0)
     chk(f"tn dt{dt} batched", out, 2.0 * torch.bmm(A.float().transpose(1, 2), D.float()), tol)
 torch.cuda.synchronize()
 print("ALL OK" if ok else "SOME BAD")
