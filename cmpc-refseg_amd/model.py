@@ -109,11 +109,31 @@ class LSTM_model(object):
         """backbone taps (c3, c4, c5), NHWC, head dtype (CMPC_model.py:73-76)."""
         return self.backbone(self._dev(im, torch.float32))
 
-    def head(self, feats, words, seq_len, target=None):
-        """build_graph() on given backbone taps (CMPC_model.py:89-142).  Returns the fetch dict."""
+    def features_async(self, im):
+        """Backbone on side stream 0 so that it overlaps the (sequential, latency-bound) text LSTM on the
+        caller's stream.  Returns (feats, stream-to-wait-on or None)."""
+        if self.side is None:
+            return self.features(im), None
+        main = torch.cuda.current_stream(self.device)
+        im = self._dev(im, torch.float32)
+        st = self.side[0]
+        st.wait_stream(main)
+        with torch.cuda.stream(st):
+            feats = self.backbone(im)
+        for f in feats:
+            f.record_stream(main)
+            for s2 in self.side:
+                f.record_stream(s2)
+        im.record_stream(st)
+        return feats, st
+
+    def head(self, feats, words, seq_len, target=None, after=None):
+        """build_graph() on given backbone taps (CMPC_model.py:89-142).  Returns the fetch dict.
+        `after`: stream that produces `feats` (waited for once the text encoder has been queued)."""
         cfg, cx, O = self.cfg, self.cx, ops
         B, T, N = cfg.batch_size, cfg.num_steps, cfg.N
-        c3, c4, c5 = [f.to(ops.tdt(self.dt)).contiguous() for f in feats]
+        if after is None:
+            c3, c4, c5 = [f.to(ops.tdt(self.dt)).contiguous() for f in feats]
         words = self._dev(words, torch.int32).view(-1)
         seq_len = self._dev(seq_len, torch.int32)
         tgt = self._dev(target, torch.float32) if target is not None else None
@@ -124,6 +144,9 @@ class LSTM_model(object):
         out = {"words_feat": wf, "seq_mask": mask, "words_parse": parse}
         fus, losses = {}, {}
         main = torch.cuda.current_stream(self.device)
+        if after is not None:
+            main.wait_stream(after)
+            c3, c4, c5 = [f.to(ops.tdt(self.dt)).contiguous() for f in feats]
 
         def fork(i):
             """run a block on side stream i after everything queued so far on the main stream"""
@@ -179,7 +202,8 @@ class LSTM_model(object):
     def forward(self, words, im, seq_len):
         """sess.run([pred, up, sigm, ...], {words, im, seq_len}) (test.py:286-296)."""
         self._check_feeds(words, im, seq_len)
-        o = self.head(self.features(im), words, seq_len)
+        feats, st = self.features_async(im)
+        o = self.head(feats, words, seq_len, after=st)
         B, h, w, H, W, T, N = self.batch_size, self.cfg.vf_h, self.cfg.vf_w, self.H, self.W, self.num_steps, self.cfg.N
         res = {"pred": o["pred"], "up": o["up"], "sigm": o["sigm"],
                "up_c3": o["up_c3"], "up_c4": o["up_c4"], "up_c5": o["up_c5"],
@@ -192,11 +216,11 @@ class LSTM_model(object):
         """TF-serving signature of export_model_serving.py:57-71: images, sentences, sequence_lenghts -> masks."""
         return self.forward(sentences, images, sequence_lenghts)["sigm"]
 
-    def loss_and_grads(self, feats, words, target_fine, seq_len):
+    def loss_and_grads(self, feats, words, target_fine, seq_len, after=None):
         """forward + backward of `cost` (CMPC_model.py:447) into the flat gradient buffer (L2 and the
         x2 bias multiplier are applied inside the Adam kernel)."""
         self.store.zero_grads()
-        o = self.head(feats, words, seq_len, target_fine)
+        o = self.head(feats, words, seq_len, target_fine, after=after)
         o["loss_all"].backward()
         if self.side is not None:
             # parameter gradients are written by the kernels themselves (not autograd leaves): the
@@ -211,8 +235,8 @@ class LSTM_model(object):
         if self.mode != 'train':
             raise RuntimeError("model was built with mode='eval' (CMPC_model.py:85-86)")
         self._check_feeds(words, im, seq_len, target_fine)
-        feats = self.features(im)
-        o = self.loss_and_grads(feats, words, target_fine, seq_len)
+        feats, st = self.features_async(im)
+        o = self.loss_and_grads(feats, words, target_fine, seq_len, after=st)
         gscale = dist.allreduce_grads_(self.store.grads)          # RCCL over xGMI: one flat buffer
         lr = self.store.adam_step(gscale)
         scal = {k: o[k].detach() for k in ("loss_all", "loss_c3", "loss_c4", "loss_c5", "loss_last", "mIoU")}
