@@ -372,6 +372,169 @@ __global__ __launch_bounds__(512) void gemm_nt_v2_kernel(const cmpc_gemm_nt_args
     }
 }
 
+// gemm_nt v3 = v2 with producer / consumer wave specialisation.
+template <typename T, int BM>
+__global__ __launch_bounds__(512) void gemm_nt_v3_kernel(const cmpc_gemm_nt_args p) {
+    constexpr int BN = 128;
+    constexpr int EPC = 16 / (int)sizeof(T);
+    constexpr int BK = BKB / (int)sizeof(T);
+    // waves 0-3 (one per SIMD) only multiply, waves 4-7 (their SIMD partners) only issue LDS-DMA: the
+    // ~100-cycle issue cost of each piece then runs beside the partner's MFMAs instead of in front of them
+    constexpr int WAVES_N = 2, WAVES_M = 2;
+    constexpr int TM = BM / WAVES_M / 16, TN = BN / WAVES_N / 16;
+    constexpr int STAGE = (BM + BN) * BKB;
+    constexpr int APW = BM / 8 / 4;                // A pieces (8 rows x 128 B = 1 KiB) per LOADER wave per stage
+    constexpr int BPW = BN / 8 / 4;
+    constexpr int LPT = APW + BPW;                 // LDS-DMA instructions per loader wave per tile
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool loader = wid >= 4;
+    const int lw = wid & 3;                        // index within the role
+    const int wm = lw / WAVES_N, wn = lw % WAVES_N;
+    const int gx = (p.N + BN - 1) / BN, nwg = gridDim.x;
+    const int xq = nwg >> 3, xr = nwg & 7, xcd = blockIdx.x & 7, xi = blockIdx.x >> 3;
+    const int tix = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + xi;
+    const int m0 = (tix / gx) * BM, n0 = (tix % gx) * BN;
+    const long bz = blockIdx.z;
+
+    int ntile[3], ntot = 0;
+#pragma unroll
+    for (int s = 0; s < 3; ++s) { ntile[s] = (s < p.nseg) ? p.K[s] / BK : 0; ntot += ntile[s]; }
+
+    f4 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = f4{0.f, 0.f, 0.f, 0.f};
+
+    const int r8 = lane >> 3, slot = lane & 7;
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+    auto issue = [&](int tile, int buf) {
+        int s = 0, t = tile;
+        if (t >= ntile[0]) { t -= ntile[0]; s = 1; if (t >= ntile[1]) { t -= ntile[1]; s = 2; } }
+        const T* Ap = reinterpret_cast<const T*>(p.A[s]) + bz * p.sA[s];
+        const T* Bp = reinterpret_cast<const T*>(p.Bt[s]) + bz * p.sB[s];
+        const long lda = p.lda[s], ldb = p.ldb[s];
+        const int k0 = t * BK;
+        const uint32_t base = lds0 + buf * STAGE;
+#pragma unroll
+        for (int j = 0; j < APW; ++j) {
+            const int blk = lw * APW + j, row = blk * 8 + r8;
+            const int c = slot ^ ((row >> 1) & 7);
+            const int gm = min(m0 + row, p.M - 1);           // rows past M: any valid address (never stored)
+            glds16(Ap + gm * lda + k0 + c * EPC, __builtin_amdgcn_readfirstlane(base + blk * 1024));
+        }
+#pragma unroll
+        for (int j = 0; j < BPW; ++j) {
+            const int blk = lw * BPW + j, row = blk * 8 + r8;
+            const int c = slot ^ ((row >> 1) & 7);
+            const int gn = min(n0 + row, p.N - 1);
+            glds16(Bp + gn * ldb + k0 + c * EPC, __builtin_amdgcn_readfirstlane(base + BM * BKB + blk * 1024));
+        }
+    };
+
+    const int fr = lane & 15, fq = lane >> 4;
+    if (loader) {
+        if (ntot > 0) issue(0, 0);
+        if (ntot > 1) issue(1, 1);
+        int cur = 0;
+        for (int kt = 0; kt < ntot; ++kt) {
+            if (kt + 1 < ntot) wait_vmcnt<LPT>(); else wait_vmcnt<0>();
+            __builtin_amdgcn_s_barrier();             // tile kt is in LDS; every consumer has finished tile kt-1
+            if (kt + 2 < ntot) issue(kt + 2, cur == 0 ? 2 : cur - 1);
+            cur = (cur == 2) ? 0 : cur + 1;
+        }
+        __builtin_amdgcn_s_barrier();
+        return;
+    }
+    int cur = 0;
+    for (int kt = 0; kt < ntot; ++kt) {
+        __builtin_amdgcn_s_barrier();
+        const char* sA = smem + cur * STAGE;
+        const char* sB = sA + BM * BKB;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            uint4 a[TM], b[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+                a[i] = *reinterpret_cast<const uint4*>(sA + nt_lds_off(wm * TM * 16 + i * 16 + fr, 4 * s + fq));
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+                b[j] = *reinterpret_cast<const uint4*>(sB + nt_lds_off(wn * TN * 16 + j * 16 + fr, 4 * s + fq));
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) acc[i][j] = Mma<T>::run(a[i], b[j], acc[i][j]);
+        }
+        cur = (cur == 2) ? 0 : cur + 1;
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+
+    constexpr int WR = TM * 16, WC = TN * 16;
+    float* slab = reinterpret_cast<float*>(smem) + lw * (WR * WC);
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = i * 16 + fq * 4 + r, col = j * 16 + fr;
+                slab[row * WC + (col ^ (((row >> 2) & 3) << 4))] = acc[i][j][r];
+            }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+
+    constexpr int LPR = WC / 4, RPP = 64 / LPR;
+    T* Ct = reinterpret_cast<T*>(p.C) + bz * p.sC;
+    float* Cf = reinterpret_cast<float*>(p.C) + bz * p.sC;
+    const int rps = p.rows_per_sample > 0 ? p.rows_per_sample : 1;
+    for (int pass = 0; pass < WR / RPP; ++pass) {
+        const int row = pass * RPP + lane / LPR, c4 = (lane % LPR) * 4;
+        const int gm = m0 + wm * WR + row, gn = n0 + wn * WC + c4;
+        if (gm >= p.M || gn >= p.N) continue;
+        const int sc = c4 ^ (((row >> 2) & 3) << 4);
+        const float4 v4 = *reinterpret_cast<const float4*>(slab + row * WC + sc);
+        float v[4] = {v4.x, v4.y, v4.z, v4.w};
+        const long bm = bz * (long)p.M + gm;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float x = v[e] * p.alpha;
+            if (gn + e < p.n_valid) {
+                if (p.bias) x += p.bias[gn + e];
+                if (p.sbias) x += p.sbias[(bm / rps) * (long)p.ld_sbias + gn + e];
+                if (p.pbias) x += p.pbias[(bm % rps) * (long)p.ld_pbias + gn + e];
+                x = act_apply(x, p.act);
+            } else {
+                x = 0.0f;
+            }
+            v[e] = x;
+        }
+        const long off = (long)gm * p.ldc + gn;
+        if (p.c_f32) {
+            if (p.accumulate) {
+                const float4 o = *reinterpret_cast<const float4*>(Cf + off);
+                v[0] += o.x; v[1] += o.y; v[2] += o.z; v[3] += o.w;
+            }
+            *reinterpret_cast<float4*>(Cf + off) = make_float4(v[0], v[1], v[2], v[3]);
+        } else {
+            if (p.accumulate) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] += Elem<T>::ld(Ct + off + e);
+            }
+            if constexpr (sizeof(T) == 4) {
+                *reinterpret_cast<float4*>(Ct + off) = make_float4(v[0], v[1], v[2], v[3]);
+            } else {
+                uint2 o;
+                o.x = (uint32_t)f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16);
+                o.y = (uint32_t)f2bf(v[2]) | ((uint32_t)f2bf(v[3]) << 16);
+                *reinterpret_cast<uint2*>(Ct + off) = o;
+            }
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------
 // conv_v2: NHWC convolution (1x1 or 3x3, stride 1/2, dilation d, TF 'SAME') as an implicit GEMM on
 // the gemm_nt v2 pipeline: K walks (tap, Cin-slice); the weight side is a plain [Cout][taps*Cin]
@@ -753,17 +916,25 @@ extern "C" int cmpc_gemm_nt(const cmpc_gemm_nt_args* a, void* stream) {
     }
     if (a->dtype == DT_BF16 && a->N >= 128 && a->M >= 512 && !getenv("CMPC_GEMM_V1")) {
         const int gn = (a->N + 127) / 128;
+        int ktot = 0;
+        for (int s2 = 0; s2 < a->nseg; ++s2) ktot += a->K[s2];      // long K: producer/consumer waves (v3) win; short K: v2
         const bool big = (long)((a->M + 255) / 256) * gn * a->batch >= 384 || getenv("CMPC_GEMM_BM256");
         if (big) {
             dim3 grid(((a->M + 255) / 256) * gn, 1, a->batch);
             static bool attr256 = false;
             if (!attr256) { (void)hipFuncSetAttribute((const void*)gemm_nt_v2_kernel<bf16_t, 256>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * (256 + 128) * BKB); attr256 = true; }
-            hipLaunchKernelGGL((gemm_nt_v2_kernel<bf16_t, 256>), grid, dim3(512), 3 * (256 + 128) * BKB, st, *a);
+            static bool attr256c = false;
+            if (!attr256c) { (void)hipFuncSetAttribute((const void*)gemm_nt_v3_kernel<bf16_t, 256>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * (256 + 128) * BKB); attr256c = true; }
+            if (ktot < 2048 || getenv("CMPC_GEMM_V2")) hipLaunchKernelGGL((gemm_nt_v2_kernel<bf16_t, 256>), grid, dim3(512), 3 * (256 + 128) * BKB, st, *a);
+            else hipLaunchKernelGGL((gemm_nt_v3_kernel<bf16_t, 256>), grid, dim3(512), 3 * (256 + 128) * BKB, st, *a);
         } else {
             dim3 grid(((a->M + 127) / 128) * gn, 1, a->batch);
             static bool attr128 = false;
             if (!attr128) { (void)hipFuncSetAttribute((const void*)gemm_nt_v2_kernel<bf16_t, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * (128 + 128) * BKB); attr128 = true; }
-            hipLaunchKernelGGL((gemm_nt_v2_kernel<bf16_t, 128>), grid, dim3(512), 3 * (128 + 128) * BKB, st, *a);
+            static bool attr128c = false;
+            if (!attr128c) { (void)hipFuncSetAttribute((const void*)gemm_nt_v3_kernel<bf16_t, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * (128 + 128) * BKB); attr128c = true; }
+            if (ktot < 2048 || getenv("CMPC_GEMM_V2")) hipLaunchKernelGGL((gemm_nt_v2_kernel<bf16_t, 128>), grid, dim3(512), 3 * (128 + 128) * BKB, st, *a);
+            else hipLaunchKernelGGL((gemm_nt_v3_kernel<bf16_t, 128>), grid, dim3(512), 3 * (128 + 128) * BKB, st, *a);
         }
         return cmpc_check_launch("gemm_nt(v2)");
     }

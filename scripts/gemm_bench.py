@@ -21,15 +21,15 @@ tot = 0; tot1 = 0
 for (M, N, K, cnt) in ((12800, 1024, 1024, 12), (12800, 1024, 2048, 1), (12800, 512, 512, 24), (12800, 512, 2112, 3), (12800, 5120, 1088, 3),
                   (12800, 2048, 1024, 2), (12800, 1024, 5120, 3), (12800, 512, 2048, 3), (12800, 1024, 512, 7)):
     A = torch.randn(M, K, device=dev).bfloat16(); Bt = torch.randn(N, K, device=dev).bfloat16(); C = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
-    os.environ["CMPC_GEMM_V1"] = "1"
+    os.environ["CMPC_GEMM_V2"] = "1"
     us1 = bench(lambda: ops.gemm_nt(1, [(A, K, Bt, K, K)], C, N, M, N))
-    del os.environ["CMPC_GEMM_V1"]
+    del os.environ["CMPC_GEMM_V2"]
     us = bench(lambda: ops.gemm_nt(1, [(A, K, Bt, K, K)], C, N, M, N))
     ref = (A[:256].float() @ Bt.float().t())
     err = float((C[:256].float() - ref).abs().max() / ref.abs().max())
     tot += us * cnt; tot1 += us1 * cnt
-    print(f"  {M:6d} {N:5d} {K:5d}  v2 {us:8.1f} us {2*M*N*K/us/1e6:7.1f} TF | v1 {us1:8.1f} us {2*M*N*K/us1/1e6:7.1f} TF   err={err:.1e}")
-print(f"  weighted total v2 {tot/1e3:.2f} ms  v1 {tot1/1e3:.2f} ms")
+    print(f"  {M:6d} {N:5d} {K:5d}  v3 {us:8.1f} us {2*M*N*K/us/1e6:7.1f} TF | v2 {us1:8.1f} us {2*M*N*K/us1/1e6:7.1f} TF   err={err:.1e}")
+print(f"  weighted total v3 {tot/1e3:.2f} ms  v2 {tot1/1e3:.2f} ms")
 print("gemm_tn bf16  R K N  us  TFLOP/s")
 tot = 0
 for (R, K, N, cnt) in ((12800, 1024, 1024, 9), (12800, 512, 512, 24), (12800, 1024, 512, 6), (12800, 2048, 1024, 1), (12800, 512, 2048, 5)):
