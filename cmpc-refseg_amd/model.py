@@ -65,6 +65,9 @@ class LSTM_model(object):
                 head_params["text_objseg/Variable"] = torch.from_numpy(np.asarray(glove, dtype=np.float32))
         self.store.load_state(head_params)
         self.cx = ops.Ctx(self.cfg, self.store, self.dt)
+        # the three pyramid levels (and the three exchange modules of a round) are independent: each gets its own
+        # HIP stream; weight-gradient GEMMs go to a fourth one.  autograd replays every backward on its forward's stream.
+        self.set_streams(int(os.environ.get("CMPC_STREAMS", "3")))
         self.backbone = bb.DeepLabResNet(backbone_width, backbone_blocks)
         self.backbone.load_tf(backbone_params if backbone_params is not None else bb.init_params(backbone_width, backbone_blocks))
         self.backbone = self.backbone.to(self.device).to(ops.tdt(self.dt)).to(memory_format=torch.channels_last).eval()
@@ -73,7 +76,6 @@ class LSTM_model(object):
         # the three pyramid levels (and the three exchange modules of a round) are independent: each gets
         # its own HIP stream so HBM-bound stage kernels of one level overlap MFMA-bound GEMMs of another.
         # autograd replays every backward on the stream of its forward, so the backward overlaps too.
-        self.set_streams(int(os.environ.get("CMPC_STREAMS", "3")))
 
     _SIDE_STREAMS = {}          # device -> 3 side streams shared by every model on that device
 
@@ -85,8 +87,12 @@ class LSTM_model(object):
             if key not in LSTM_model._SIDE_STREAMS:
                 LSTM_model._SIDE_STREAMS[key] = [torch.cuda.Stream(device=self.device) for _ in range(3)]
             self.side = LSTM_model._SIDE_STREAMS[key]
+            if key + "/wg" not in LSTM_model._SIDE_STREAMS:
+                LSTM_model._SIDE_STREAMS[key + "/wg"] = torch.cuda.Stream(device=self.device)
+            self.cx.wg = LSTM_model._SIDE_STREAMS[key + "/wg"] if os.environ.get("CMPC_WGRAD_STREAM", "0") != "0" else None
         else:
             self.side = None
+            self.cx.wg = None
 
     # ------------------------------------------------------------------------------------------
     def _check_feeds(self, words, im, seq_len, target=None):
@@ -228,6 +234,8 @@ class LSTM_model(object):
             main = torch.cuda.current_stream(self.device)
             for st in self.side:
                 main.wait_stream(st)
+            if self.cx.wg is not None:
+                main.wait_stream(self.cx.wg)
         return o
 
     def train_step(self, words, im, target_fine, seq_len):

@@ -82,9 +82,28 @@ def gemm_nt(dt, segs: Sequence[Tuple], C, ldc, M, N, n_valid=None, batch=1, sC=0
     _lib.call("cmpc_gemm_nt", ctypes.byref(a), _st())
 
 
+def on_wgrad_stream(cx, tensors, fn):
+    """Run fn() (a weight-gradient launch: it only feeds the optimizer) on the weight-gradient stream so
+    that it overlaps the dX chain of the backward pass.  `tensors` are its device inputs: they are
+    recorded on that stream so the caching allocator does not recycle them early."""
+    ws = getattr(cx, "wg", None) if cx is not None else None
+    if ws is None:
+        return fn()
+    ws.wait_stream(torch.cuda.current_stream())
+    for t in tensors:
+        if torch.is_tensor(t):
+            t.record_stream(ws)
+    with torch.cuda.stream(ws):
+        fn()
+
+
 def gemm_tn(dt, A, lda, Ka, D, ldd, Nd, out, ldo, R, Kv, Nv, offs=((0, 0, 0),), nb2=1, a_bs=0, d_bs=0, o_bs=0,
-            alpha=1.0, rsplit=None):
-    """out[k, n] += alpha * sum_r A[r, k] D[r, n]; offs: (a_off, d_off, o_off) per inner batch (elements)."""
+            alpha=1.0, rsplit=None, wg=None):
+    """out[k, n] += alpha * sum_r A[r, k] D[r, n]; offs: (a_off, d_off, o_off) per inner batch (elements).
+    wg=cx: weight gradient -> launched on cx's weight-gradient stream."""
+    if wg is not None and getattr(wg, "wg", None) is not None:
+        return on_wgrad_stream(wg, (A, D), lambda: gemm_tn(dt, A, lda, Ka, D, ldd, Nd, out, ldo, R, Kv, Nv, offs, nb2, a_bs, d_bs,
+                                                             o_bs, alpha, rsplit))
     a = GemmTnArgs()
     a.dtype = dt
     a.A, a.lda, a.Ka = _p(A), lda, Ka
@@ -141,6 +160,7 @@ class Ctx:
         sp[:, :8] = grid.reshape(N, 8).float()
         self.spatial = sp.repeat(B, 1).to(self.dev).to(tdt(vis_dt)).contiguous()
         self.anchor = torch.zeros((), device=self.dev, requires_grad=True)
+        self.wg = None              # weight-gradient stream (set by LSTM_model.set_streams)
 
     def op(self, key):
         return self.ps.ops[key]
@@ -201,8 +221,8 @@ class TextEncoder(torch.autograd.Function):
                     accumulate=True)
         gk = ps.gptr("rnn/lstm_cell/kernel")
         gate_offs = lambda row0: tuple((0, g * Cp, row0 * 4 * R + g * R) for g in range(4))
-        gemm_tn(F32, emb, Gp, Gp, dg, 4 * Cp, Cp, gk, 4 * R, T * B, G, R, offs=gate_offs(0))
-        gemm_tn(F32, h_all, Cp, Cp, dg, 4 * Cp, Cp, gk, 4 * R, T * B, R, R, offs=gate_offs(G))
+        gemm_tn(F32, emb, Gp, Gp, dg, 4 * Cp, Cp, gk, 4 * R, T * B, G, R, offs=gate_offs(0), wg=cx)
+        gemm_tn(F32, h_all, Cp, Cp, dg, 4 * Cp, Cp, gk, 4 * R, T * B, R, R, offs=gate_offs(G), wg=cx)
         gb = ps.gptr("rnn/lstm_cell/bias")
         for g in range(4):
             colsum(F32, _p(dg) + 4 * g * Cp, T * B, 4 * Cp, Cp, R, db=gb + 4 * g * R)
@@ -243,11 +263,11 @@ class LangParser(torch.autograd.Function):
         dlg = empty((BT, 64), F32, dev)
         _lib.call("cmpc_parse_softmax_bwd", _p(dparse), _p(parse), _p(mask), _p(dlg), 64, BT, _st())
         colsum(F32, dlg, BT, 64, 64, 4, db=ps.gptr("words_parse_2/biases"))
-        gemm_tn(F32, h1, Pp, Pp, dlg, 64, 64, ps.gptr("words_parse_2/DW"), 4, BT, P, 4)
+        gemm_tn(F32, h1, Pp, Pp, dlg, 64, 64, ps.gptr("words_parse_2/DW"), 4, BT, P, 4, wg=cx)
         dh1 = empty((BT, Pp), F32, dev)
         gemm_nt(F32, [(dlg, 64, cx.opp("parse2.n"), 64, 64)], dh1, Pp, BT, Pp, n_valid=P)
         colsum(F32, dh1, BT, Pp, Pp, P, db=ps.gptr("words_parse_1/biases"), y=h1, dpre=dh1, act=ACT_RELU)
-        gemm_tn(F32, wf, Cp, Cp, dh1, Pp, Pp, ps.gptr("words_parse_1/DW"), P, BT, R, P)
+        gemm_tn(F32, wf, Cp, Cp, dh1, Pp, Pp, ps.gptr("words_parse_1/DW"), P, BT, R, P, wg=cx)
         dwf = empty((BT, Cp), F32, dev)
         gemm_nt(F32, [(dh1, Pp, cx.opp("parse1.n"), Pp, Pp)], dwf, Cp, BT, Cp, n_valid=R)
         return dwf, None, None
@@ -308,7 +328,7 @@ class Lateral(torch.autograd.Function):
         dV = empty((R, Cp), dt, dev)
         _lib.call("cmpc_l2norm_rows_bwd", dt, _p(dX0.contiguous()), _p(X0), _p(rstd), _p(dV), R, Cp, C, 0, _st())
         colsum(dt, dV, R, Cp, Cp, C, db=ps.gptr(f"{lv}_lateral/biases"))
-        gemm_tn(dt, feat, cin, cin, dV, Cp, Cp, ps.gptr(f"{lv}_lateral/DW"), C, R, cin, C)
+        gemm_tn(dt, feat, cin, cin, dV, Cp, Cp, ps.gptr(f"{lv}_lateral/DW"), C, R, cin, C, wg=cx)
         return None, None, None, None
 
 
@@ -353,8 +373,8 @@ class Mutan(torch.autograd.Function):
             offs_s.append((0, h * Cp, rel + C * C))
             colsum(dt, _p(dP) + h * Cp * e, R, 5 * Cp, Cp, C, db=ps.gptr(f"vis_trans_{lv}_head{h + 1}/biases"))
         gw = ps.gptr(f"vis_trans_{lv}_head1/DW")
-        gemm_tn(dt, X0, Cp, Cp, dP, 5 * Cp, Cp, gw, C, R, C, C, offs=offs_v)
-        gemm_tn(dt, cx.spatial, 64, 64, dP, 5 * Cp, Cp, gw, C, R, 8, C, offs=offs_s)
+        gemm_tn(dt, X0, Cp, Cp, dP, 5 * Cp, Cp, gw, C, R, C, C, offs=offs_v, wg=cx)
+        gemm_tn(dt, cx.spatial, 64, 64, dP, 5 * Cp, Cp, gw, C, R, 8, C, offs=offs_s, wg=cx)
         dX0 = empty((R, Cp), dt, dev)
         gemm_nt(dt, [(dP, 5 * Cp, cx.opp(f"mutan_{lv}.n"), 5 * Cp, 5 * Cp)], dX0, Cp, R, Cp, n_valid=C)
         # language gates
@@ -364,7 +384,7 @@ class Mutan(torch.autograd.Function):
             colsum(F32, _p(dg) + 4 * h * Cp, B, 5 * Cp, Cp, C, db=ps.gptr(f"lang_trans_{lv}_head{h + 1}/biases"),
                    y=_p(g) + 4 * h * Cp, dpre=_p(dg) + 4 * h * Cp, act=ACT_TANH)
             offs_l.append((0, h * Cp, ps.poff(f"lang_trans_{lv}_head{h + 1}/DW") - base_l))
-        gemm_tn(F32, vl, Cp, Cp, dg, 5 * Cp, Cp, ps.gptr(f"lang_trans_{lv}_head1/DW"), C, B, Rr, C, offs=offs_l)
+        gemm_tn(F32, vl, Cp, Cp, dg, 5 * Cp, Cp, ps.gptr(f"lang_trans_{lv}_head1/DW"), C, B, Rr, C, offs=offs_l, wg=cx)
         dvl = empty((B, Cp), F32, dev)
         gemm_nt(F32, [(dg, 5 * Cp, cx.opp(f"mlang_{lv}.n"), 5 * Cp, 5 * Cp)], dvl, Cp, B, Cp, n_valid=Rr)
         return dX0, dvl, None, None
@@ -443,11 +463,11 @@ class SpaGraph(torch.autograd.Function):
         _lib.call("cmpc_gconv_post_bwd", dt, _p(dX2.contiguous()), _p(X2), _p(rrow), _p(U), _p(sums2), ps.pptr(ln2 + "/gamma"),
                   _p(dU), ps.gptr(ln2 + "/gamma"), ps.gptr(ln2 + "/beta"), _p(bs), B, N, Cp, C, _st())
         colsum(dt, dU, R, Cp, Cp, C, db=ps.gptr(f"gconv_update_spa_graph_{lv}/biases"))
-        gemm_tn(dt, G, Cp, Cp, dU, Cp, Cp, ps.gptr(f"gconv_update_spa_graph_{lv}/DW"), C, R, C, C)
+        gemm_tn(dt, G, Cp, Cp, dU, Cp, Cp, ps.gptr(f"gconv_update_spa_graph_{lv}/DW"), C, R, C, C, wg=cx)
         dG = empty((R, Cp), dt, dev)
         gemm_nt(dt, [(dU, Cp, cx.opp(f"gupd_{lv}.n"), Cp, Cp)], dG, Cp, R, Cp, n_valid=C)
         dX1 = empty((R, Cp), dt, dev)
-        dY = dU     # reuse
+        dY = empty((R, Cp), dt, dev)      # (dU is still being read by the weight-gradient stream)
         _lib.call("cmpc_gconv_pre_bwd", dt, _p(dG), _p(G), _p(Y), _p(sums1), ps.pptr(ln1 + "/gamma"), _p(dX1), 0, _p(dY),
                   ps.gptr(ln1 + "/gamma"), ps.gptr(ln1 + "/beta"), _p(bs), B, N, Cp, C, _st())
         # Y = gw_w . Z,  Z = gw_v^T . X1
@@ -483,12 +503,12 @@ class SpaGraph(torch.autograd.Function):
         _lib.call("cmpc_wcolsum", F32, _p(Wd), _p(dk0s), ps.gptr(f"spa_graph_trans2_{lv}/biases"), 0, 1, B * Tp, Cp, C, scale, _st())
         dWd = empty((B * Tp, Cp), F32, dev)
         gemm_nt(F32, [(dPT, Cp, cx.opp(f"t2_{lv}.t"), Cp, Cp)], dWd, Cp, B * Tp, Cp, n_valid=C)
-        gemm_tn(F32, dPT, Cp, Cp, Wd, Cp, Cp, ps.gptr(f"spa_graph_trans2_{lv}/DW"), C, B * Tp, C, C)
+        gemm_tn(F32, dPT, Cp, Cp, Wd, Cp, Cp, ps.gptr(f"spa_graph_trans2_{lv}/DW"), C, B * Tp, C, C, wg=cx)
         _lib.call("cmpc_rank1_update", F32, _p(dWd), _p(dk0s), ps.pptr(f"spa_graph_trans2_{lv}/biases"), None, None, 0,
                   scale, 0.0, 1, B * Tp, Cp, C, _st())
         # Wd = wf . W_w + b_w   (rows t < T of every sample; pad rows of dWd are zero)
         colsum(F32, dWd, B * Tp, Cp, Cp, C, db=ps.gptr(f"words_trans_{lv}/biases"))
-        gemm_tn(F32, wf, Cp, Cp, dWd, Cp, Cp, ps.gptr(f"words_trans_{lv}/DW"), C, T, C, C, nb2=B, a_bs=T * Cp, d_bs=Tp * Cp, o_bs=0)
+        gemm_tn(F32, wf, Cp, Cp, dWd, Cp, Cp, ps.gptr(f"words_trans_{lv}/DW"), C, T, C, C, nb2=B, a_bs=T * Cp, d_bs=Tp * Cp, o_bs=0, wg=cx)
         dwf = empty((B * T, Cp), F32, dev)
         gemm_nt(F32, [(dWd, Cp, cx.opp(f"wtrans_{lv}.n"), Cp, Cp, Tp * Cp, 0)], dwf, Cp, T, Cp, n_valid=C, batch=B, sC=T * Cp)
         dparse = zeros((B * T, 4), F32, dev)
@@ -528,10 +548,10 @@ class Fusion(torch.autograd.Function):
         colsum(dt, dF.contiguous(), R, Mp, Mp, M, db=ps.gptr(f"fusion_{lv}/biases"), y=F, dpre=dpre, act=ACT_RELU,
                dsb=dsb, ld_dsb=Mp, rows_per_sample=N)
         gw = ps.gptr(f"fusion_{lv}/DW")
-        gemm_tn(dt, X1, Cp, Cp, dpre, Mp, Mp, gw, M, R, C, M)
-        gemm_tn(dt, X2, Cp, Cp, dpre, Mp, Mp, gw + 4 * C * M, M, R, C, M)
-        gemm_tn(dt, cx.spatial, 64, 64, dpre, Mp, Mp, gw + 4 * (2 * C + Rr) * M, M, R, 8, M)
-        gemm_tn(F32, vl, Cp, Cp, dsb, Mp, Mp, gw + 4 * 2 * C * M, M, B, Rr, M)
+        gemm_tn(dt, X1, Cp, Cp, dpre, Mp, Mp, gw, M, R, C, M, wg=cx)
+        gemm_tn(dt, X2, Cp, Cp, dpre, Mp, Mp, gw + 4 * C * M, M, R, C, M, wg=cx)
+        gemm_tn(dt, cx.spatial, 64, 64, dpre, Mp, Mp, gw + 4 * (2 * C + Rr) * M, M, R, 8, M, wg=cx)
+        gemm_tn(F32, vl, Cp, Cp, dsb, Mp, Mp, gw + 4 * 2 * C * M, M, B, Rr, M, wg=cx)
         dX1 = empty((R, Cp), dt, dev)
         dX2 = empty((R, Cp), dt, dev)
         gemm_nt(dt, [(dpre, Mp, cx.opp(f"fus_{lv}.n"), Mp, Mp)], dX1, Cp, R, Cp, n_valid=C)
@@ -643,19 +663,19 @@ class Exchange(torch.autograd.Function):
         dgv = empty((B, Mp), F32, dev)
         for i, (k, fx) in enumerate((("f1", f1), ("f2", f2))):
             colsum(dt, dp[i], R, Mp, Mp, M, db=ps.gptr(f"trans_feat_{lv}_{k}/biases"))
-            gemm_tn(dt, fx, Mp, Mp, dp[i], Mp, Mp, ps.gptr(f"trans_feat_{lv}_{k}/DW"), M, R, M, M)
+            gemm_tn(dt, fx, Mp, Mp, dp[i], Mp, Mp, ps.gptr(f"trans_feat_{lv}_{k}/DW"), M, R, M, M, wg=cx)
             dfx = empty((R, Mp), dt, dev)
             gemm_nt(dt, [(dp[i], Mp, cx.opp(f"tfeat_{lv}_{k}.n"), Mp, Mp)], dfx, Mp, R, Mp, n_valid=M)
             dfs.append(dfx)
             colsum(F32, dg[i], B, Mp, Mp, M, db=ps.gptr(f"lang_feat_{lv}_{k}/biases"), y=g[i], dpre=dg[i], act=ACT_SIGMOID)
-            gemm_tn(F32, gv, Mp, Mp, dg[i], Mp, Mp, ps.gptr(f"lang_feat_{lv}_{k}/DW"), M, B, M, M)
+            gemm_tn(F32, gv, Mp, Mp, dg[i], Mp, Mp, ps.gptr(f"lang_feat_{lv}_{k}/DW"), M, B, M, M, wg=cx)
             gemm_nt(F32, [(dg[i], Mp, cx.opp(f"lfeat_{lv}_{k}.n"), Mp, Mp)], dgv, Mp, B, Mp, n_valid=M, accumulate=(i == 1))
         dgvpre = empty((B, Mp), F32, dev)
         _lib.call("cmpc_l2norm_all_bwd", _p(dgv), _p(gv), _p(rs1), _p(dgvpre), B * Mp, _st())
         colsum(F32, dgvpre, B, Mp, Mp, M, db=ps.gptr(f"gv_lang_{lv}gv_f1/biases"))
         gwg = ps.gptr(f"gv_lang_{lv}gv_f1/DW")
-        gemm_tn(F32, pooled, Mp, Mp, dgvpre, Mp, Mp, gwg, M, B, M, M)
-        gemm_tn(F32, nec, Cp, Cp, dgvpre, Mp, Mp, gwg + 4 * M * M, M, B, Rr, M)
+        gemm_tn(F32, pooled, Mp, Mp, dgvpre, Mp, Mp, gwg, M, B, M, M, wg=cx)
+        gemm_tn(F32, nec, Cp, Cp, dgvpre, Mp, Mp, gwg + 4 * M * M, M, B, Rr, M, wg=cx)
         dpooled = empty((B, Mp), F32, dev)
         gemm_nt(F32, [(dgvpre, Mp, cx.opp(f"gv_{lv}.n"), Mp, Mp)], dpooled, Mp, B, Mp, n_valid=M)
         dnec = empty((B, Cp), F32, dev)
@@ -669,9 +689,9 @@ class Exchange(torch.autograd.Function):
         _lib.call("cmpc_wcolsum", dt, _p(feat), _p(dlog), _p(dkq), Mp, B, N, Mp, M, s, _st())
         dq = empty((B, Mp), F32, dev)
         gemm_nt(F32, [(dkq, Mp, cx.opp(f"key_{lv}.t"), Mp, Mp)], dq, Mp, B, Mp, n_valid=M)
-        gemm_tn(F32, dkq, Mp, Mp, q, Mp, Mp, ps.gptr(f"spa_graph_key_{lv}gv_f1/DW"), M, B, M, M)
+        gemm_tn(F32, dkq, Mp, Mp, q, Mp, Mp, ps.gptr(f"spa_graph_key_{lv}gv_f1/DW"), M, B, M, M, wg=cx)
         colsum(F32, dq, B, Mp, Mp, M, db=ps.gptr(f"lang_query_{lv}gv_f1/biases"))
-        gemm_tn(F32, nec, Cp, Cp, dq, Mp, Mp, ps.gptr(f"lang_query_{lv}gv_f1/DW"), M, B, Rr, M)
+        gemm_tn(F32, nec, Cp, Cp, dq, Mp, Mp, ps.gptr(f"lang_query_{lv}gv_f1/DW"), M, B, Rr, M, wg=cx)
         gemm_nt(F32, [(dq, Mp, cx.opp(f"query_{lv}.n"), Mp, Mp)], dnec, Cp, B, Cp, n_valid=Rr, accumulate=True)
         return dfeat, dfs[0], dfs[1], dnec, None, None
 
@@ -742,13 +762,13 @@ class ConvLSTM(torch.autograd.Function):
                       ps.pptr(pre + "W_ci"), ps.pptr(pre + "W_cf"), ps.pptr(pre + "W_co"), ctypes.byref(ln), _p(sums),
                       _p(dYg), _p(dc_prev), ps.gptr(pre + "W_ci"), ps.gptr(pre + "W_cf"), ps.gptr(pre + "W_co"),
                       ctypes.byref(dln), _p(scr), _p(bs), B, N, Mp, M, _st())
-            gemm_tn(dt, x, Mp, Mp, dYg, 4 * Mp, Mp, gk, 4 * M, R, M, M, offs=tuple((0, g * Mp, g * M) for g in range(4)))
+            gemm_tn(dt, x, Mp, Mp, dYg, 4 * Mp, Mp, gk, 4 * M, R, M, M, offs=tuple((0, g * Mp, g * M) for g in range(4)), wg=cx)
             dx = empty((R, Mp), dt, dev)
             gemm_nt(dt, [(dYg, 4 * Mp, cx.opp("clstm.n"), 4 * Mp, 4 * Mp)], dx, Mp, R, Mp, n_valid=M)
             dxs[s] = dx
             if s > 0:
                 gemm_tn(dt, h_prev, Mp, Mp, dYg, 4 * Mp, Mp, gk, 4 * M, R, M, M,
-                        offs=tuple((0, g * Mp, M * 4 * M + g * M) for g in range(4)))
+                        offs=tuple((0, g * Mp, M * 4 * M + g * M) for g in range(4)), wg=cx)
                 dh = empty((R, Mp), dt, dev)
                 gemm_nt(dt, [(dYg, 4 * Mp, cx.opp("clstm.n", Mp, 0), 4 * Mp, 4 * Mp)], dh, Mp, R, Mp, n_valid=M)
                 dc = dc_prev
