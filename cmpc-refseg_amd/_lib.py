@@ -55,7 +55,7 @@ class GemmTnArgs(C.Structure):
         ("R", C.c_int), ("Kv", C.c_int), ("Nv", C.c_int),
         ("nb", C.c_int), ("a_off", C.c_int64 * 8), ("d_off", C.c_int64 * 8), ("o_off", C.c_int64 * 8),
         ("nb2", C.c_int), ("a_bs", C.c_int64), ("d_bs", C.c_int64), ("o_bs", C.c_int64),
-        ("rsplit", C.c_int), ("alpha", C.c_float),
+        ("rsplit", C.c_int), ("alpha", C.c_float), ("zeros", C.c_void_p),
     ]
 
 

@@ -829,6 +829,111 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const cmpc_gemm_tn_args p)
 
 
 // ------------------------------------------------------------------------------------------
+// gemm_tn v2 (bf16): same product as gemm_tn_kernel, but the [64 rows][128 cols] operand slabs are
+// filled by LDS-DMA into THREE stages with counted vmcnt (tile t+1 in flight while tile t is
+// multiplied), 8 waves (2 x 4 over the 128 x 128 output, 64 x 32 per wave).  The 32-byte-segment XOR
+// of the LDS image is applied to the per-lane SOURCE column block (linear LDS destination).
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(512) void gemm_tn_v2_kernel(const cmpc_gemm_tn_args p) {
+    constexpr int BR = 64, ROWB = 256, TILE = BR * ROWB;      // one operand slab = 16 KiB
+    constexpr int STAGE = 2 * TILE;
+    constexpr int LPT = 4;                                      // 32 pieces (16 A + 16 D) / 8 waves
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wid >> 2, wn = wid & 3;                      // 2 x 4 waves: 64 (k) x 32 (n) per wave
+    const int ntn = (p.Nv + 127) / 128;
+    const int k0 = (blockIdx.x / ntn) * 128, n0 = (blockIdx.x % ntn) * 128;
+    const int b1 = blockIdx.z % p.nb, b2 = blockIdx.z / p.nb;
+    const bf16_t* A = reinterpret_cast<const bf16_t*>(p.A) + p.a_off[b1] + (long)b2 * p.a_bs;
+    const bf16_t* D = reinterpret_cast<const bf16_t*>(p.D) + p.d_off[b1] + (long)b2 * p.d_bs;
+    float* out = p.out + p.o_off[b1] + (long)b2 * p.o_bs;
+    const int per = (p.R + p.rsplit - 1) / p.rsplit;
+    const int rbeg = blockIdx.y * per;
+    const int rend = min(p.R, rbeg + per);
+    const int nt = (rend > rbeg) ? (rend - rbeg + BR - 1) / BR : 0;
+    if (nt == 0) return;
+
+    f4 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = f4{0.f, 0.f, 0.f, 0.f};
+
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+    const bf16_t* Z = reinterpret_cast<const bf16_t*>(p.zeros);
+    // a piece = 4 slab rows x 256 B; lane -> (row = lane>>4, 16-B chunk = lane&15).  LDS position of
+    // (row, chunk): row*256 + ((chunk>>1) ^ f(row))*32 + (chunk&1)*16  => the lane that lands on LDS chunk
+    // position c must fetch source chunk  ((c>>1) ^ f(row))*2 + (c&1).
+    auto issue = [&](int t, int buf) {
+        const int r0 = rbeg + t * BR;
+#pragma unroll
+        for (int j = 0; j < LPT; ++j) {
+            const int piece = wid * LPT + j;                    // 0..31 : 0..15 -> A slab, 16..31 -> D slab
+            const bool isA = piece < 16;
+            const int pr = (piece & 15) * 4 + (lane >> 4);       // slab row
+            const int cpos = lane & 15;
+            const int f = (pr & 3) | (((pr >> 3) & 1) << 2);
+            const int csrc = ((((cpos >> 1) ^ f) & 7) << 1) | (cpos & 1);
+            const int gr = r0 + pr;
+            const int col = (isA ? k0 : n0) + csrc * 8;
+            const bool ok = gr < rend && col < (isA ? p.Ka : p.Nd);
+            const bf16_t* g = ok ? (isA ? A + (long)gr * p.lda + col : D + (long)gr * p.ldd + col) : Z;
+            glds16(g, __builtin_amdgcn_readfirstlane(lds0 + buf * STAGE + (isA ? 0 : TILE) + (piece & 15) * 1024));
+        }
+    };
+
+    issue(0, 0);
+    if (nt > 1) issue(1, 1);
+    const int fr = lane & 15, fq = lane >> 4;
+    const int q4 = fr >> 2, p4 = fr & 3;
+    int cur = 0;
+    for (int t = 0; t < nt; ++t) {
+        if (t + 1 < nt) wait_vmcnt<LPT>(); else wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();
+        if (t + 2 < nt) issue(t + 2, cur == 0 ? 2 : cur - 1);
+        const char* sA = smem + cur * STAGE;
+        const char* sD = sA + TILE;
+#pragma unroll
+        for (int rs = 0; rs < BR / 32; ++rs) {
+            uint4 a[4], b[2];
+            const int r_lo = rs * 32 + 8 * fq + q4;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int col = wm * 64 + i * 16 + 4 * p4;
+                const s4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s4*)(sA + tn_swz(r_lo, col * 2, ROWB)));
+                const s4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s4*)(sA + tn_swz(r_lo + 4, col * 2, ROWB)));
+                const s8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                a[i] = __builtin_bit_cast(uint4, v);
+            }
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int col = wn * 32 + j * 16 + 4 * p4;
+                const s4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s4*)(sD + tn_swz(r_lo, col * 2, ROWB)));
+                const s4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s4*)(sD + tn_swz(r_lo + 4, col * 2, ROWB)));
+                const s8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                b[j] = __builtin_bit_cast(uint4, v);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf8v, a[i]), __builtin_bit_cast(bf8v, b[j]), acc[i][j], 0, 0, 0);
+        }
+        cur = (cur == 2) ? 0 : cur + 1;
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int k = k0 + wm * 64 + i * 16 + fq * 4 + r;
+                const int n = n0 + wn * 32 + j * 16 + fr;
+                if (k < p.Kv && n < p.Nv) atomicAdd(out + (long)k * p.ldo + n, acc[i][j][r] * p.alpha);
+            }
+}
+
+// ------------------------------------------------------------------------------------------
 // gemm_nt for M <= 16 rows (the language side: [B, .] vectors against whole weight matrices).
 // Weight-streaming: one wave per NC output columns, K split over the 64 lanes (float4 loads of
 // the K-contiguous weight rows), the few A rows re-read from L1/L2; wave-shuffle reduction.
@@ -1007,6 +1112,10 @@ extern "C" int cmpc_gemm_tn(const cmpc_gemm_tn_args* a, void* stream) {
     if (a->dtype == DT_F32) {
         const size_t lds = 2 * 2 * TnCfg<float>::BR * 128 * 4;
         hipLaunchKernelGGL((gemm_tn_kernel<float>), grid, dim3(256), lds, st, *a);
+    } else if (a->dtype == DT_BF16 && a->zeros && a->R >= 256 && getenv("CMPC_TN_V2")) {
+        static bool attr = false;
+        if (!attr) { (void)hipFuncSetAttribute((const void*)gemm_tn_v2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 2 * 64 * 256); attr = true; }
+        hipLaunchKernelGGL(gemm_tn_v2_kernel, grid, dim3(512), 3 * 2 * 64 * 256, st, *a);
     } else if (a->dtype == DT_BF16) {
         const size_t lds = 2 * 2 * TnCfg<bf16_t>::BR * 128 * 2;
         hipLaunchKernelGGL((gemm_tn_kernel<bf16_t>), grid, dim3(256), lds, st, *a);

@@ -119,7 +119,18 @@ def gemm_tn(dt, A, lda, Ka, D, ldd, Nd, out, ldo, R, Kv, Nv, offs=((0, 0, 0),), 
         br = 64 if dt == DT_BF16 else 32
         rsplit = max(1, min((R + 4 * br - 1) // (4 * br), (512 + tiles - 1) // tiles))
     a.rsplit, a.alpha = rsplit, alpha
+    a.zeros = _zero_page(A.device if torch.is_tensor(A) else torch.device('cuda', torch.cuda.current_device()))
     _lib.call("cmpc_gemm_tn", ctypes.byref(a), _st())
+
+
+_ZERO_PAGES = {}
+
+
+def _zero_page(dev):
+    k = str(dev)
+    if k not in _ZERO_PAGES:
+        _ZERO_PAGES[k] = torch.zeros(256, dtype=torch.uint8, device=dev)
+    return _ZERO_PAGES[k].data_ptr()
 
 
 def cast(src, src_dt, dst, dst_dt, n):

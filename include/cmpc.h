@@ -60,6 +60,7 @@ typedef struct {
     int nb2; int64_t a_bs, d_bs, o_bs;  /* outer batch: strides */
     int rsplit;                         /* workgroups along the reduction */
     float alpha;
+    const void* zeros;                  /* optional: >= 256 B of device zeros (enables the LDS-DMA pipeline for bf16) */
 } cmpc_gemm_tn_args;
 int cmpc_gemm_tn(const cmpc_gemm_tn_args* a, void* stream);
 

@@ -31,10 +31,16 @@ for (M, N, K, cnt) in ((12800, 1024, 1024, 12), (12800, 1024, 2048, 1), (12800, 
     print(f"  {M:6d} {N:5d} {K:5d}  v3 {us:8.1f} us {2*M*N*K/us/1e6:7.1f} TF | v2 {us1:8.1f} us {2*M*N*K/us1/1e6:7.1f} TF   err={err:.1e}")
 print(f"  weighted total v3 {tot/1e3:.2f} ms  v2 {tot1/1e3:.2f} ms")
 print("gemm_tn bf16  R K N  us  TFLOP/s")
-tot = 0
+tot = 0; tot1 = 0
 for (R, K, N, cnt) in ((12800, 1024, 1024, 9), (12800, 512, 512, 24), (12800, 1024, 512, 6), (12800, 2048, 1024, 1), (12800, 512, 2048, 5)):
     A = torch.randn(R, K, device=dev).bfloat16(); D = torch.randn(R, N, device=dev).bfloat16(); out = torch.zeros(K, N, device=dev)
+    os.environ["CMPC_TN_V1"] = "1"
+    us1 = bench(lambda: ops.gemm_tn(1, A, K, K, D, N, N, out, N, R, K, N))
+    del os.environ["CMPC_TN_V1"]
+    out.zero_(); ops.gemm_tn(1, A, K, K, D, N, N, out, N, R, K, N)
+    ref = A[:, :64].float().t() @ D.float()
+    err = float((out[:64] - ref).abs().max() / ref.abs().max())
     us = bench(lambda: ops.gemm_tn(1, A, K, K, D, N, N, out, N, R, K, N))
-    tot += us * cnt
-    print(f"  {R:6d} {K:5d} {N:5d}  {us:8.1f}  {2*R*N*K/us/1e6:7.1f}")
-print(f"  weighted total {tot/1e3:.2f} ms")
+    tot += us * cnt; tot1 += us1 * cnt
+    print(f"  {R:6d} {K:5d} {N:5d}  v2 {us:8.1f} us {2*R*N*K/us/1e6:7.1f} TF | v1 {us1:8.1f} us {2*R*N*K/us1/1e6:7.1f} TF  err={err:.1e}")
+print(f"  weighted total v2 {tot/1e3:.2f} ms v1 {tot1/1e3:.2f} ms")
