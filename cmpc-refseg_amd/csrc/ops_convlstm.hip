@@ -24,11 +24,12 @@ __device__ __forceinline__ void flush_sums(double s1, double s2, double* dst, do
     __syncthreads();
 }
 
-__device__ __forceinline__ void colflush(const float (&acc)[MB][8], float* out, int ld, int C, float* lds) {
+template <int NB>
+__device__ __forceinline__ void colflush(const float (&acc)[NB][8], float* out, int ld, int C, float* lds) {
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     __syncthreads();
 #pragma unroll
-    for (int k = 0; k < MB; ++k) {
+    for (int k = 0; k < NB; ++k) {
         const int c0 = k * 512 + lane * 8;
         if (c0 < ld) {
 #pragma unroll
@@ -41,7 +42,7 @@ __device__ __forceinline__ void colflush(const float (&acc)[MB][8], float* out, 
 }
 
 // ---- forward A: peepholes on i,f (in place) + stats j,i,f -----------------------------------
-template <typename T>
+template <typename T, int NB>
 __global__ __launch_bounds__(256) void clstm_a_kernel(T* __restrict__ Yg, const T* __restrict__ c_prev, const float* __restrict__ W_ci,
                                                      const float* __restrict__ W_cf, double* sums, int B, int N, int ld, int M) {
     __shared__ double red[6][WPB];
@@ -51,16 +52,20 @@ __global__ __launch_bounds__(256) void clstm_a_kernel(T* __restrict__ Yg, const 
         const long r = (long)b * N + n;
         T* y = Yg + r * 4 * ld;
         float aj1 = 0, aj2 = 0, ai1 = 0, ai2 = 0, af1 = 0, af2 = 0;
-        for (int c0 = lane * 8; c0 < ld; c0 += 512) {
+#pragma unroll
+        for (int kb = 0; kb < NB; ++kb) {
+            const int c0 = kb * 512 + lane * 8;
+            if (c0 >= ld) continue;
             float j[8], i[8], f[8];
             ld8<T>(y + c0, j); ld8<T>(y + ld + c0, i); ld8<T>(y + 2 * ld + c0, f);
             if (c_prev) {
-                float c[8];
+                float c[8], wi[8], wf[8];
                 ld8<T>(c_prev + r * ld + c0, c);
+                if (c0 < M) { ld8<float>(W_ci + (long)n * M + c0, wi); ld8<float>(W_cf + (long)n * M + c0, wf); }   // M % 8 == 0 or tail masked below
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
                     const int m = c0 + e;
-                    if (m < M) { i[e] += W_ci[(long)n * M + m] * c[e]; f[e] += W_cf[(long)n * M + m] * c[e]; }
+                    if (m < M) { i[e] += wi[e] * c[e]; f[e] += wf[e] * c[e]; }
                 }
                 st8<T>(y + ld + c0, i); st8<T>(y + 2 * ld + c0, f);
                 // statistics must see the values as stored (bf16 rounding included)
@@ -81,11 +86,27 @@ __global__ __launch_bounds__(256) void clstm_a_kernel(T* __restrict__ Yg, const 
     flush_sums(sf1, sf2, sums + (2 * nwg + wg) * 2, red, 2);
 }
 
+
+// this lane's slice of a per-channel fp32 vector (LayerNorm gamma / beta): loaded once per wave
+template <int NB>
+__device__ __forceinline__ void load_vec(const float* v, float (&out)[NB][8], int ld) {
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int k = 0; k < NB; ++k) {
+        const int c0 = k * 512 + lane * 8;
+        if (c0 < ld) ld8<float>(v + c0, out[k]);
+        else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) out[k][e] = 0.f;
+        }
+    }
+}
+
 struct LnP { const float* beta[5]; const float* gamma[5]; };
 struct LnG { float* dbeta[5]; float* dgamma[5]; };
 
 // ---- forward B ---------------------------------------------------------------------------------
-template <typename T>
+template <typename T, int NB>
 __global__ __launch_bounds__(256) void clstm_b_kernel(T* __restrict__ Yg, const T* __restrict__ c_prev, const float* __restrict__ W_co,
                                                      LnP ln, const double* sums, double* dpart, T* __restrict__ c_pre, int B, int N, int ld, int M) {
     __shared__ double red[4][WPB];
@@ -95,25 +116,33 @@ __global__ __launch_bounds__(256) void clstm_b_kernel(T* __restrict__ Yg, const 
     ln_stats(sums + (0 * B + b) * 2, cnt, mj, rj);
     ln_stats(sums + (1 * B + b) * 2, cnt, mi, ri);
     ln_stats(sums + (2 * B + b) * 2, cnt, mf, rf);
+    float gj[NB][8], bj[NB][8], gi[NB][8], bi[NB][8], gf[NB][8], bf_[NB][8];
+    load_vec<NB>(ln.gamma[0], gj, ld); load_vec<NB>(ln.beta[0], bj, ld); load_vec<NB>(ln.gamma[1], gi, ld);
+    load_vec<NB>(ln.beta[1], bi, ld); load_vec<NB>(ln.gamma[2], gf, ld); load_vec<NB>(ln.beta[2], bf_, ld);
     double so1 = 0, so2 = 0, sc1 = 0, sc2 = 0;
     for (int n = blockIdx.x * WPB + w; n < N; n += gridDim.x * WPB) {
         const long r = (long)b * N + n;
         T* y = Yg + r * 4 * ld;
         float ao1 = 0, ao2 = 0, ac1 = 0, ac2 = 0;
-        for (int c0 = lane * 8; c0 < ld; c0 += 512) {
+#pragma unroll
+        for (int kb = 0; kb < NB; ++kb) {
+            const int c0 = kb * 512 + lane * 8;
+            if (c0 >= ld) continue;
             float j[8], i[8], f[8], o[8], c[8], cp[8];
             ld8<T>(y + c0, j); ld8<T>(y + ld + c0, i); ld8<T>(y + 2 * ld + c0, f); ld8<T>(y + 3 * ld + c0, o);
             if (c_prev) ld8<T>(c_prev + r * ld + c0, c);
+            float wo[8];
+            if (c0 < M) ld8<float>(W_co + (long)n * M + c0, wo);
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 const int m = c0 + e;
                 if (m < M) {
-                    const float jn = (j[e] - mj) * rj * ln.gamma[0][m] + ln.beta[0][m];
-                    const float in = (i[e] - mi) * ri * ln.gamma[1][m] + ln.beta[1][m];
-                    const float fn = (f[e] - mf) * rf * ln.gamma[2][m] + ln.beta[2][m];
+                    const float jn = (j[e] - mj) * rj * gj[kb][e] + bj[kb][e];
+                    const float in = (i[e] - mi) * ri * gi[kb][e] + bi[kb][e];
+                    const float fn = (f[e] - mf) * rf * gf[kb][e] + bf_[kb][e];
                     const float fg = sigmoidf_(fn + 1.0f), ig = sigmoidf_(in), jt = tanhf(jn);
                     cp[e] = (c_prev ? c[e] * fg : 0.f) + ig * jt;
-                    o[e] += W_co[(long)n * M + m] * cp[e];
+                    o[e] += wo[e] * cp[e];
                 } else { cp[e] = 0.f; o[e] = 0.f; }
             }
             st8<T>(c_pre + r * ld + c0, cp); st8<T>(y + 3 * ld + c0, o);
@@ -130,7 +159,7 @@ __global__ __launch_bounds__(256) void clstm_b_kernel(T* __restrict__ Yg, const 
 }
 
 // ---- forward C ---------------------------------------------------------------------------------
-template <typename T>
+template <typename T, int NB>
 __global__ __launch_bounds__(256) void clstm_c_kernel(const T* __restrict__ Yg, const T* __restrict__ c_pre, LnP ln, const double* sums,
                                                      T* __restrict__ c_new, T* __restrict__ h, int B, int N, int ld, int M) {
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, b = blockIdx.y;
@@ -138,17 +167,22 @@ __global__ __launch_bounds__(256) void clstm_c_kernel(const T* __restrict__ Yg, 
     float mo, ro, mc, rc;
     ln_stats(sums + (3 * B + b) * 2, cnt, mo, ro);
     ln_stats(sums + (4 * B + b) * 2, cnt, mc, rc);
+    float go[NB][8], bo[NB][8], gc[NB][8], bc[NB][8];
+    load_vec<NB>(ln.gamma[3], go, ld); load_vec<NB>(ln.beta[3], bo, ld); load_vec<NB>(ln.gamma[4], gc, ld); load_vec<NB>(ln.beta[4], bc, ld);
     for (int n = blockIdx.x * WPB + w; n < N; n += gridDim.x * WPB) {
         const long r = (long)b * N + n;
-        for (int c0 = lane * 8; c0 < ld; c0 += 512) {
+#pragma unroll
+        for (int kb = 0; kb < NB; ++kb) {
+            const int c0 = kb * 512 + lane * 8;
+            if (c0 >= ld) continue;
             float o[8], cp[8], cn[8], hh[8];
             ld8<T>(Yg + r * 4 * ld + 3 * ld + c0, o); ld8<T>(c_pre + r * ld + c0, cp);
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 const int m = c0 + e;
                 if (m < M) {
-                    const float on = (o[e] - mo) * ro * ln.gamma[3][m] + ln.beta[3][m];
-                    cn[e] = (cp[e] - mc) * rc * ln.gamma[4][m] + ln.beta[4][m];
+                    const float on = (o[e] - mo) * ro * go[kb][e] + bo[kb][e];
+                    cn[e] = (cp[e] - mc) * rc * gc[kb][e] + bc[kb][e];
                     hh[e] = sigmoidf_(on) * tanhf(cn[e]);
                 } else { cn[e] = 0.f; hh[e] = 0.f; }
             }
@@ -158,7 +192,7 @@ __global__ __launch_bounds__(256) void clstm_c_kernel(const T* __restrict__ Yg, 
 }
 
 // ---- backward pass 1: through h = sig(LN o) * tanh(LN c) up to the LN inputs' dxhat ------------
-template <typename T>
+template <typename T, int NB>
 __global__ __launch_bounds__(256) void clstm_bwd1_kernel(const T* __restrict__ dh, const T* __restrict__ dc_new, const T* __restrict__ Yg,
                                                         const T* __restrict__ c_pre, LnP ln, const double* sums, T* __restrict__ dYg,
                                                         T* __restrict__ scr, float* part, double* dpart, int B, int N, int ld, int M) {
@@ -169,9 +203,11 @@ __global__ __launch_bounds__(256) void clstm_bwd1_kernel(const T* __restrict__ d
     float mo, ro, mc, rc;
     ln_stats(sums + (3 * B + b) * 2, cnt, mo, ro);
     ln_stats(sums + (4 * B + b) * 2, cnt, mc, rc);
-    float ago[MB][8], abo[MB][8], agc[MB][8], abc[MB][8];
+    float go[NB][8], bo[NB][8], gc[NB][8], bc[NB][8];
+    load_vec<NB>(ln.gamma[3], go, ld); load_vec<NB>(ln.beta[3], bo, ld); load_vec<NB>(ln.gamma[4], gc, ld); load_vec<NB>(ln.beta[4], bc, ld);
+    float ago[NB][8], abo[NB][8], agc[NB][8], abc[NB][8];
 #pragma unroll
-    for (int k = 0; k < MB; ++k)
+    for (int k = 0; k < NB; ++k)
 #pragma unroll
         for (int e = 0; e < 8; ++e) { ago[k][e] = abo[k][e] = agc[k][e] = abc[k][e] = 0.f; }
     double so1 = 0, so2 = 0, sc1 = 0, sc2 = 0;
@@ -179,7 +215,7 @@ __global__ __launch_bounds__(256) void clstm_bwd1_kernel(const T* __restrict__ d
         const long r = (long)b * N + n;
         float ao1 = 0, ao2 = 0, ac1 = 0, ac2 = 0;
 #pragma unroll
-        for (int k = 0; k < MB; ++k) {
+        for (int k = 0; k < NB; ++k) {
             const int c0 = k * 512 + lane * 8;
             if (c0 < ld) {
                 float g[8], dcn[8], o[8], cp[8], xo[8], xc[8];
@@ -190,13 +226,13 @@ __global__ __launch_bounds__(256) void clstm_bwd1_kernel(const T* __restrict__ d
                     const int m = c0 + e;
                     if (m < M) {
                         const float xho = (o[e] - mo) * ro, xhc = (cp[e] - mc) * rc;
-                        const float on = xho * ln.gamma[3][m] + ln.beta[3][m];
-                        const float cn = xhc * ln.gamma[4][m] + ln.beta[4][m];
+                        const float on = xho * go[k][e] + bo[k][e];
+                        const float cn = xhc * gc[k][e] + bc[k][e];
                         const float so = sigmoidf_(on), tc = tanhf(cn);
                         const float don = g[e] * tc * so * (1.f - so);
                         const float dcc = g[e] * so * (1.f - tc * tc) + (dc_new ? dcn[e] : 0.f);
                         ago[k][e] += don * xho; abo[k][e] += don; agc[k][e] += dcc * xhc; abc[k][e] += dcc;
-                        xo[e] = don * ln.gamma[3][m]; xc[e] = dcc * ln.gamma[4][m];
+                        xo[e] = don * go[k][e]; xc[e] = dcc * gc[k][e];
                         ao1 += xo[e]; ao2 += xo[e] * xho; ac1 += xc[e]; ac2 += xc[e] * xhc;
                     } else { xo[e] = 0.f; xc[e] = 0.f; }
                 }
@@ -214,7 +250,7 @@ __global__ __launch_bounds__(256) void clstm_bwd1_kernel(const T* __restrict__ d
 }
 
 // ---- backward pass 2: finish LN(o), LN(c); through the cell update to dxhat of j,i,f -----------
-template <typename T>
+template <typename T, int NB>
 __global__ __launch_bounds__(256) void clstm_bwd2_kernel(const T* __restrict__ Yg, const T* __restrict__ c_prev, const T* __restrict__ c_pre,
                                                         const float* __restrict__ W_co, LnP ln, const double* sums, const double* bsums_in,
                                                         T* __restrict__ dYg, const T* __restrict__ scr, T* __restrict__ dc_prev,
@@ -231,11 +267,14 @@ __global__ __launch_bounds__(256) void clstm_bwd2_kernel(const T* __restrict__ Y
     ln_stats(sums + (4 * B + b) * 2, cnt, mc, rc);
     const float o_m1 = (float)(bsums_in[(3 * B + b) * 2] / cnt), o_m2 = (float)(bsums_in[(3 * B + b) * 2 + 1] / cnt);
     const float c_m1 = (float)(bsums_in[(4 * B + b) * 2] / cnt), c_m2 = (float)(bsums_in[(4 * B + b) * 2 + 1] / cnt);
-    float ag[3][MB][8], ab[3][MB][8];
+    float gq[3][NB][8], bq[3][NB][8];
+#pragma unroll
+    for (int q = 0; q < 3; ++q) { load_vec<NB>(ln.gamma[q], gq[q], ld); load_vec<NB>(ln.beta[q], bq[q], ld); }
+    float ag[3][NB][8], ab[3][NB][8];
 #pragma unroll
     for (int q = 0; q < 3; ++q)
 #pragma unroll
-        for (int k = 0; k < MB; ++k)
+        for (int k = 0; k < NB; ++k)
 #pragma unroll
             for (int e = 0; e < 8; ++e) { ag[q][k][e] = 0.f; ab[q][k][e] = 0.f; }
     double s[6] = {0, 0, 0, 0, 0, 0};
@@ -243,7 +282,7 @@ __global__ __launch_bounds__(256) void clstm_bwd2_kernel(const T* __restrict__ Y
         const long r = (long)b * N + n;
         float a[6] = {0, 0, 0, 0, 0, 0};
 #pragma unroll
-        for (int k = 0; k < MB; ++k) {
+        for (int k = 0; k < NB; ++k) {
             const int c0 = k * 512 + lane * 8;
             if (c0 < ld) {
                 float j[8], i[8], f[8], o[8], cp[8], c[8], dxo[8], dxc[8], oj[8], oi[8], of[8], dcp[8];
@@ -252,6 +291,8 @@ __global__ __launch_bounds__(256) void clstm_bwd2_kernel(const T* __restrict__ Y
                 ld8<T>(c_pre + r * ld + c0, cp);
                 if (c_prev) ld8<T>(c_prev + r * ld + c0, c);
                 ld8<T>(dYg + r * 4 * ld + 3 * ld + c0, dxo); ld8<T>(scr + r * ld + c0, dxc);
+                float wo[8];
+                if (c0 < M) ld8<float>(W_co + (long)n * M + c0, wo);
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
                     const int m = c0 + e;
@@ -259,13 +300,13 @@ __global__ __launch_bounds__(256) void clstm_bwd2_kernel(const T* __restrict__ Y
                         const float xho = (o[e] - mo) * ro, xhc = (cp[e] - mc) * rc;
                         const float dop = ro * (dxo[e] - o_m1 - xho * o_m2);
                         float dc = rc * (dxc[e] - c_m1 - xhc * c_m2);
-                        const float wco = W_co[(long)n * M + m];
+                        const float wco = wo[e];
                         dc += dop * wco;
                         dxo[e] = dop;
                         const float xhj = (j[e] - mj) * rj, xhi = (i[e] - mi) * ri, xhf = (f[e] - mf) * rf;
-                        const float jn = xhj * ln.gamma[0][m] + ln.beta[0][m];
-                        const float in = xhi * ln.gamma[1][m] + ln.beta[1][m];
-                        const float fn = xhf * ln.gamma[2][m] + ln.beta[2][m];
+                        const float jn = xhj * gq[0][k][e] + bq[0][k][e];
+                        const float in = xhi * gq[1][k][e] + bq[1][k][e];
+                        const float fn = xhf * gq[2][k][e] + bq[2][k][e];
                         const float fg = sigmoidf_(fn + 1.0f), ig = sigmoidf_(in), jt = tanhf(jn);
                         const float cpv = c_prev ? c[e] : 0.f;
                         const float dfn = dc * cpv * fg * (1.f - fg);
@@ -275,7 +316,7 @@ __global__ __launch_bounds__(256) void clstm_bwd2_kernel(const T* __restrict__ Y
                         ag[0][k][e] += djn * xhj; ab[0][k][e] += djn;
                         ag[1][k][e] += din * xhi; ab[1][k][e] += din;
                         ag[2][k][e] += dfn * xhf; ab[2][k][e] += dfn;
-                        oj[e] = djn * ln.gamma[0][m]; oi[e] = din * ln.gamma[1][m]; of[e] = dfn * ln.gamma[2][m];
+                        oj[e] = djn * gq[0][k][e]; oi[e] = din * gq[1][k][e]; of[e] = dfn * gq[2][k][e];
                         a[0] += oj[e]; a[1] += oj[e] * xhj; a[2] += oi[e]; a[3] += oi[e] * xhi; a[4] += of[e]; a[5] += of[e] * xhf;
                     } else { dxo[e] = 0.f; oj[e] = oi[e] = of[e] = 0.f; dcp[e] = 0.f; }
                 }
@@ -297,7 +338,7 @@ __global__ __launch_bounds__(256) void clstm_bwd2_kernel(const T* __restrict__ Y
 }
 
 // ---- backward pass 3: finish LN(j), LN(i), LN(f); peepholes on i,f ----------------------------
-template <typename T>
+template <typename T, int NB>
 __global__ __launch_bounds__(256) void clstm_bwd3_kernel(const T* __restrict__ Yg, const T* __restrict__ c_prev, const float* __restrict__ W_ci,
                                                         const float* __restrict__ W_cf, const double* sums, const double* bsums,
                                                         T* __restrict__ dYg, T* __restrict__ dc_prev, float* dW_ci, float* dW_cf,
@@ -312,11 +353,15 @@ __global__ __launch_bounds__(256) void clstm_bwd3_kernel(const T* __restrict__ Y
     }
     for (int n = blockIdx.x * WPB + w; n < N; n += gridDim.x * WPB) {
         const long r = (long)b * N + n;
-        for (int c0 = lane * 8; c0 < ld; c0 += 512) {
+#pragma unroll
+        for (int kb = 0; kb < NB; ++kb) {
+            const int c0 = kb * 512 + lane * 8;
+            if (c0 >= ld) continue;
             float x[3][8], d[3][8], c[8], dcp[8];
 #pragma unroll
             for (int q = 0; q < 3; ++q) { ld8<T>(Yg + r * 4 * ld + q * ld + c0, x[q]); ld8<T>(dYg + r * 4 * ld + q * ld + c0, d[q]); }
-            if (c_prev) { ld8<T>(c_prev + r * ld + c0, c); ld8<T>(dc_prev + r * ld + c0, dcp); }
+            float wi[8], wf[8];
+            if (c_prev) { ld8<T>(c_prev + r * ld + c0, c); ld8<T>(dc_prev + r * ld + c0, dcp); if (c0 < M) { ld8<float>(W_ci + (long)n * M + c0, wi); ld8<float>(W_cf + (long)n * M + c0, wf); } }
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 const int m = c0 + e;
@@ -325,7 +370,7 @@ __global__ __launch_bounds__(256) void clstm_bwd3_kernel(const T* __restrict__ Y
                     const float xh = (x[q][e] - mean[q]) * rstd[q];
                     d[q][e] = (m < M) ? rstd[q] * (d[q][e] - m1[q] - xh * m2[q]) : 0.f;
                 }
-                if (c_prev && m < M) dcp[e] += d[1][e] * W_ci[(long)n * M + m] + d[2][e] * W_cf[(long)n * M + m];
+                if (c_prev && m < M) dcp[e] += d[1][e] * wi[e] + d[2][e] * wf[e];
             }
 #pragma unroll
             for (int q = 0; q < 3; ++q) st8<T>(dYg + r * 4 * ld + q * ld + c0, d[q]);
@@ -337,13 +382,16 @@ __global__ __launch_bounds__(256) void clstm_bwd3_kernel(const T* __restrict__ Y
 
 // ---- peephole gradients: dW_c*[n,m] += sum_b dgate[b,n,m] * c[b,n,m]; one wave per spatial row n,
 // the batch loop inside, so no atomics (the three time steps are sequential launches) --------------
-template <typename T>
+template <typename T, int NB>
 __global__ __launch_bounds__(256) void clstm_peephole_grad_kernel(const T* __restrict__ dYg, const T* __restrict__ c_prev, const T* __restrict__ c_pre,
                                                                  float* __restrict__ dW_ci, float* __restrict__ dW_cf, float* __restrict__ dW_co,
                                                                  int B, int N, int ld, int M) {
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     for (int n = blockIdx.x * WPB + w; n < N; n += gridDim.x * WPB) {
-        for (int c0 = lane * 8; c0 < ld; c0 += 512) {
+#pragma unroll
+        for (int kb = 0; kb < NB; ++kb) {
+            const int c0 = kb * 512 + lane * 8;
+            if (c0 >= ld) continue;
             float ai[8], af[8], ao[8];
 #pragma unroll
             for (int e = 0; e < 8; ++e) { ai[e] = af[e] = ao[e] = 0.f; }
@@ -382,6 +430,8 @@ LnG to_lng(const cmpc_convlstm_dln* l) { LnG p; for (int i = 0; i < 5; ++i) { p.
 }  // namespace
 
 #define ST ((hipStream_t)stream)
+// kernels are instantiated for 1 or 2 column blocks of 512
+#define CLSTM_NB(ld, ...) do { if ((ld) <= 512) { constexpr int NBX = 1; __VA_ARGS__; } else { constexpr int NBX = 2; __VA_ARGS__; } } while (0)
 
 // workspace: fp32 column partials [nwg][ncol][ld] followed by fp64 pair partials [npair][nwg][2]
 static int clstm_ws(long nwg, int ncol, int npair, int ld, float** part, double** dpart, hipStream_t st) {
@@ -398,8 +448,8 @@ extern "C" int cmpc_convlstm_a(int dt, void* Yg, const void* c_prev, const float
     const int gx = rows_grid(N, 100);
     float* part; double* dpart;
     if (clstm_ws((long)B * gx, 0, 3, ld, &part, &dpart, ST)) return CMPC_EHIP;
-    CMPC_DISPATCH_DT(dt, hipLaunchKernelGGL((clstm_a_kernel<T>), dim3(gx, B), dim3(256), 0, ST,
-                                             (T*)Yg, (const T*)c_prev, W_ci, W_cf, dpart, B, N, ld, M));
+    CLSTM_NB(ld, CMPC_DISPATCH_DT(dt, hipLaunchKernelGGL((clstm_a_kernel<T, NBX>), dim3(gx, B), dim3(256), 0, ST,
+                                             (T*)Yg, (const T*)c_prev, W_ci, W_cf, dpart, B, N, ld, M)));
     for (int q = 0; q < 3; ++q)
         if (cmpc_reduce_parts_f64(dpart + (long)q * B * gx * 2, B, gx, 2, sums + (long)q * B * 2, ST)) return CMPC_EHIP;
     return cmpc_check_launch("convlstm_a");
@@ -411,8 +461,8 @@ extern "C" int cmpc_convlstm_b(int dt, void* Yg, const void* c_prev, const float
     const int gx = rows_grid(N, 100);
     float* part; double* dpart;
     if (clstm_ws((long)B * gx, 0, 2, ld, &part, &dpart, ST)) return CMPC_EHIP;
-    CMPC_DISPATCH_DT(dt, hipLaunchKernelGGL((clstm_b_kernel<T>), dim3(gx, B), dim3(256), 0, ST,
-                                             (T*)Yg, (const T*)c_prev, W_co, to_lnp(ln), sums, dpart, (T*)c_pre, B, N, ld, M));
+    CLSTM_NB(ld, CMPC_DISPATCH_DT(dt, hipLaunchKernelGGL((clstm_b_kernel<T, NBX>), dim3(gx, B), dim3(256), 0, ST,
+                                             (T*)Yg, (const T*)c_prev, W_co, to_lnp(ln), sums, dpart, (T*)c_pre, B, N, ld, M)));
     for (int q = 0; q < 2; ++q)
         if (cmpc_reduce_parts_f64(dpart + (long)q * B * gx * 2, B, gx, 2, sums + (long)(3 + q) * B * 2, ST)) return CMPC_EHIP;
     return cmpc_check_launch("convlstm_b");
@@ -421,8 +471,8 @@ extern "C" int cmpc_convlstm_b(int dt, void* Yg, const void* c_prev, const float
 extern "C" int cmpc_convlstm_c(int dt, const void* Yg, const void* c_pre, const cmpc_convlstm_ln* ln, const double* sums,
                                void* c_new, void* h, int B, int N, int ld, int M, void* stream) {
     if (!ok("convlstm_c", dt, ld, M)) return CMPC_EINVAL;
-    CMPC_DISPATCH_DT(dt, hipLaunchKernelGGL((clstm_c_kernel<T>), dim3(rows_grid(N, 200), B), dim3(256), 0, ST,
-                                             (const T*)Yg, (const T*)c_pre, to_lnp(ln), sums, (T*)c_new, (T*)h, B, N, ld, M));
+    CLSTM_NB(ld, CMPC_DISPATCH_DT(dt, hipLaunchKernelGGL((clstm_c_kernel<T, NBX>), dim3(rows_grid(N, 200), B), dim3(256), 0, ST,
+                                             (const T*)Yg, (const T*)c_pre, to_lnp(ln), sums, (T*)c_new, (T*)h, B, N, ld, M)));
     return cmpc_check_launch("convlstm_c");
 }
 
@@ -438,27 +488,27 @@ extern "C" int cmpc_convlstm_bwd(int dt, const void* dh, const void* dc_new, con
     float* part; double* dpart;
     if (clstm_ws(nwg, 6, 3, ld, &part, &dpart, ST)) return CMPC_EHIP;
     // pass 1: LN(o), LN(c) dxhat + their statistics / parameter gradients
-    CMPC_DISPATCH_DT(dt, hipLaunchKernelGGL((clstm_bwd1_kernel<T>), dim3(gx, B), dim3(256), lds, ST,
-                           (const T*)dh, (const T*)dc_new, (const T*)Yg, (const T*)c_pre, to_lnp(ln), sums, (T*)dYg, (T*)scr, part, dpart, B, N, ld, M));
+    CLSTM_NB(ld, CMPC_DISPATCH_DT(dt, hipLaunchKernelGGL((clstm_bwd1_kernel<T, NBX>), dim3(gx, B), dim3(256), lds, ST,
+                           (const T*)dh, (const T*)dc_new, (const T*)Yg, (const T*)c_pre, to_lnp(ln), sums, (T*)dYg, (T*)scr, part, dpart, B, N, ld, M)));
     for (int q = 0; q < 2; ++q) {
         if (cmpc_reduce_parts_f64(dpart + (long)q * nwg * 2, B, gx, 2, bsums + (long)(3 + q) * B * 2, ST)) return CMPC_EHIP;
         if (cmpc_reduce_parts_f32(part + (2 * q) * ld, 4 * ld, 1, (int)nwg, 1, ld, M, dln->dgamma[3 + q], 0, 0, 1, ST)) return CMPC_EHIP;
         if (cmpc_reduce_parts_f32(part + (2 * q + 1) * ld, 4 * ld, 1, (int)nwg, 1, ld, M, dln->dbeta[3 + q], 0, 0, 1, ST)) return CMPC_EHIP;
     }
     // pass 2: finish o, c; cell update; LN(j,i,f) dxhat + statistics
-    CMPC_DISPATCH_DT(dt, hipLaunchKernelGGL((clstm_bwd2_kernel<T>), dim3(gx, B), dim3(256), lds, ST,
+    CLSTM_NB(ld, CMPC_DISPATCH_DT(dt, hipLaunchKernelGGL((clstm_bwd2_kernel<T, NBX>), dim3(gx, B), dim3(256), lds, ST,
                            (const T*)Yg, (const T*)c_prev, (const T*)c_pre, W_co, to_lnp(ln), sums, bsums, (T*)dYg, (const T*)scr, (T*)dc_prev,
-                           part, dpart, B, N, ld, M));
+                           part, dpart, B, N, ld, M)));
     for (int q = 0; q < 3; ++q) {
         if (cmpc_reduce_parts_f64(dpart + (long)q * nwg * 2, B, gx, 2, bsums + (long)q * B * 2, ST)) return CMPC_EHIP;
         if (cmpc_reduce_parts_f32(part + (2 * q) * ld, 6 * ld, 1, (int)nwg, 1, ld, M, dln->dgamma[q], 0, 0, 1, ST)) return CMPC_EHIP;
         if (cmpc_reduce_parts_f32(part + (2 * q + 1) * ld, 6 * ld, 1, (int)nwg, 1, ld, M, dln->dbeta[q], 0, 0, 1, ST)) return CMPC_EHIP;
     }
-    CMPC_DISPATCH_DT(dt, {
-        hipLaunchKernelGGL((clstm_bwd3_kernel<T>), dim3(rows_grid(N, 200), B), dim3(256), 0, ST,
+    CLSTM_NB(ld, CMPC_DISPATCH_DT(dt, {
+        hipLaunchKernelGGL((clstm_bwd3_kernel<T, NBX>), dim3(rows_grid(N, 200), B), dim3(256), 0, ST,
                            (const T*)Yg, (const T*)c_prev, W_ci, W_cf, sums, bsums, (T*)dYg, (T*)dc_prev, dW_ci, dW_cf, B, N, ld, M);
-        hipLaunchKernelGGL((clstm_peephole_grad_kernel<T>), dim3(rows_grid(N, 512)), dim3(256), 0, ST,
+        hipLaunchKernelGGL((clstm_peephole_grad_kernel<T, NBX>), dim3(rows_grid(N, 512)), dim3(256), 0, ST,
                            (const T*)dYg, (const T*)c_prev, (const T*)c_pre, dW_ci, dW_cf, dW_co, B, N, ld, M);
-    });
+    }));
     return cmpc_check_launch("convlstm_bwd");
 }

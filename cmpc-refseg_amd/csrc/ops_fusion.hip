@@ -16,6 +16,19 @@ __global__ __launch_bounds__(256) void mutan_fwd_kernel(T* __restrict__ P, const
                                                        float* __restrict__ rstd, int N, int ld, int C) {
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, b = blockIdx.y;
     const float* gb = g + (long)b * 5 * ld;
+    // the language gates of this sample are the same for every node row: keep this lane's 5 x 16 in registers
+    float gv[5][MB][8];
+#pragma unroll
+    for (int h = 0; h < 5; ++h)
+#pragma unroll
+        for (int k = 0; k < MB; ++k) {
+            const int c0 = k * 512 + lane * 8;
+            if (c0 < ld) ld8<float>(gb + h * ld + c0, gv[h][k]);
+            else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) gv[h][k][e] = 0.f;
+            }
+        }
     for (int n = blockIdx.x * WPB + w; n < N; n += gridDim.x * WPB) {
         const long r = (long)b * N + n;
         T* Pr = P + r * 5 * ld;
@@ -36,7 +49,7 @@ __global__ __launch_bounds__(256) void mutan_fwd_kernel(T* __restrict__ P, const
                     for (int e = 0; e < 8; ++e) {
                         const float th = (c0 + e < C) ? tanhf(pv[e]) : 0.f;
                         pv[e] = th;
-                        q[k][e] += th * gb[h * ld + c0 + e];
+                        q[k][e] += th * gv[h][k][e];
                     }
                     st8<T>(Pr + h * ld + c0, pv);
                 }
@@ -74,6 +87,18 @@ __global__ __launch_bounds__(256) void mutan_bwd_kernel(T* __restrict__ Th, cons
     extern __shared__ float lds[];     // [WPB][ld]
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, b = blockIdx.y;
     const float* gb = g + (long)b * 5 * ld;
+    float gv[5][MB][8];
+#pragma unroll
+    for (int h = 0; h < 5; ++h)
+#pragma unroll
+        for (int k = 0; k < MB; ++k) {
+            const int c0 = k * 512 + lane * 8;
+            if (c0 < ld) ld8<float>(gb + h * ld + c0, gv[h][k]);
+            else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) gv[h][k][e] = 0.f;
+            }
+        }
     float acc[5][MB][8];
 #pragma unroll
     for (int h = 0; h < 5; ++h)
@@ -122,7 +147,7 @@ __global__ __launch_bounds__(256) void mutan_bwd_kernel(T* __restrict__ Th, cons
                     for (int e = 0; e < 8; ++e) {
                         const float th = tv[e];
                         acc[h][k][e] += d[k][e] * th;
-                        tv[e] = (c0 + e < C) ? d[k][e] * gb[h * ld + c0 + e] * (1.f - th * th) : 0.f;
+                        tv[e] = (c0 + e < C) ? d[k][e] * gv[h][k][e] * (1.f - th * th) : 0.f;
                     }
                     st8<T>(Tr + h * ld + c0, tv);
                 }
@@ -335,6 +360,12 @@ __global__ __launch_bounds__(256) void exch_combine_fwd_kernel(const T* __restri
                                                               const float* __restrict__ g1, const float* __restrict__ g2, int ld_g,
                                                               T* __restrict__ out, float* __restrict__ rstd, int N, int ld, int C) {
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, b = blockIdx.y;
+    float gv1[MB][8], gv2[MB][8];
+#pragma unroll
+    for (int k = 0; k < MB; ++k) {
+        const int c0 = k * 512 + lane * 8;
+        if (c0 < ld) { ld8<float>(g1 + (long)b * ld_g + c0, gv1[k]); ld8<float>(g2 + (long)b * ld_g + c0, gv2[k]); }
+    }
     for (int n = blockIdx.x * WPB + w; n < N; n += gridDim.x * WPB) {
         const long base = ((long)b * N + n) * ld;
         float v[MB][8];
@@ -348,7 +379,7 @@ __global__ __launch_bounds__(256) void exch_combine_fwd_kernel(const T* __restri
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
                     const int cc = c0 + e;
-                    v[k][e] = (cc < C) ? f[e] + a[e] * g1[(long)b * ld_g + cc] + c[e] * g2[(long)b * ld_g + cc] : 0.f;
+                    v[k][e] = (cc < C) ? f[e] + a[e] * gv1[k][e] + c[e] * gv2[k][e] : 0.f;
                     ss += v[k][e] * v[k][e];
                 }
             }
@@ -377,11 +408,14 @@ __global__ __launch_bounds__(256) void exch_combine_bwd_kernel(const T* __restri
                                                               float* part, int N, int ld, int C) {
     extern __shared__ float lds[];     // [WPB][2*ld]
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, b = blockIdx.y;
-    float a1[MB][8], a2[MB][8];
+    float a1[MB][8], a2[MB][8], gv1[MB][8], gv2[MB][8];
 #pragma unroll
-    for (int k = 0; k < MB; ++k)
+    for (int k = 0; k < MB; ++k) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) { a1[k][e] = 0.f; a2[k][e] = 0.f; }
+        const int c0 = k * 512 + lane * 8;
+        if (c0 < ld) { ld8<float>(g1 + (long)b * ld_g + c0, gv1[k]); ld8<float>(g2 + (long)b * ld_g + c0, gv2[k]); }
+    }
     for (int n = blockIdx.x * WPB + w; n < N; n += gridDim.x * WPB) {
         const long base = ((long)b * N + n) * ld;
         float d[MB][8], ov[MB][8];
@@ -410,8 +444,8 @@ __global__ __launch_bounds__(256) void exch_combine_bwd_kernel(const T* __restri
                     const int cc = c0 + e;
                     const float dE = (cc < C) ? a * (d[k][e] - ov[k][e] * dot) : 0.f;
                     a1[k][e] += dE * x1[e]; a2[k][e] += dE * x2[e];
-                    o1[e] = (cc < C && x1[e] > 0.f) ? dE * g1[(long)b * ld_g + cc] : 0.f;
-                    o2[e] = (cc < C && x2[e] > 0.f) ? dE * g2[(long)b * ld_g + cc] : 0.f;
+                    o1[e] = (cc < C && x1[e] > 0.f) ? dE * gv1[k][e] : 0.f;
+                    o2[e] = (cc < C && x2[e] > 0.f) ? dE * gv2[k][e] : 0.f;
                     df[e] = accumulate ? df[e] + dE : dE;
                 }
                 st8<T>(dp1 + base + c0, o1); st8<T>(dp2 + base + c0, o2); st8<T>(dfeat + base + c0, df);

@@ -208,10 +208,10 @@ __global__ __launch_bounds__(256) void rowdot1_kernel(const T* __restrict__ x, c
         const long base = ((long)b * N + n) * ld;
         float acc = 0.f;
         for (int c0 = lane * 8; c0 < ld; c0 += 512) {
-            float xv[8];
-            ld8<T>(x + base + c0, xv);
+            float xv[8], vv[8];
+            ld8<T>(x + base + c0, xv); ld8<float>(v + (long)b * ld_v + c0, vv);
 #pragma unroll
-            for (int e = 0; e < 8; ++e) if (c0 + e < C) acc += xv[e] * v[(long)b * ld_v + c0 + e];
+            for (int e = 0; e < 8; ++e) if (c0 + e < C) acc += xv[e] * vv[e];
         }
         acc = wave_sum(acc);
         if (lane == 0) s[(long)b * N + n] = acc * scale;
@@ -228,13 +228,14 @@ __global__ __launch_bounds__(256) void rank1_kernel(T* __restrict__ x, const flo
         const float a1 = s1 * w1[(long)b * N + n];
         const float a2 = w2 ? s2 * w2[(long)b * N + n] : 0.f;
         for (int c0 = lane * 8; c0 < ld; c0 += 512) {
-            float xv[8];
-            ld8<T>(x + base + c0, xv);
+            float xv[8], p1[8], p2[8];
+            ld8<T>(x + base + c0, xv); ld8<float>(v1 + (long)b * ld_v + c0, p1);
+            if (w2) ld8<float>(v2 + (long)b * ld_v + c0, p2);
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 if (c0 + e < C) {
-                    xv[e] += a1 * v1[(long)b * ld_v + c0 + e];
-                    if (w2) xv[e] += a2 * v2[(long)b * ld_v + c0 + e];
+                    xv[e] += a1 * p1[e];
+                    if (w2) xv[e] += a2 * p2[e];
                 }
             }
             st8<T>(x + base + c0, xv);
@@ -381,17 +382,27 @@ __global__ __launch_bounds__(256) void gconv_pre_fwd_kernel(const T* __restrict_
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, b = blockIdx.y;
     float mean, rstd;
     ln_stats(sums + 2 * b, (double)N * C, mean, rstd);
+    // per-channel LayerNorm parameters of this lane's columns (the masters are padded past C inside the
+    // flat buffer, values beyond C are never used)
+    float gmv[MAXBLK][8], btv[MAXBLK][8];
+#pragma unroll
+    for (int k = 0; k < MAXBLK; ++k) {
+        const int c0 = k * 512 + lane * 8;
+        if (c0 < ld) { ld8<float>(gamma + c0, gmv[k]); if (beta) ld8<float>(beta + c0, btv[k]); }
+    }
     for (int n = blockIdx.x * WPB + w; n < N; n += gridDim.x * WPB) {
         const long base = ((long)b * N + n) * ld;
-        for (int c0 = lane * 8; c0 < ld; c0 += 512) {
-            float yv[8], xv[8], o[8];
-            ld8<T>(Y + base + c0, yv); ld8<T>(X + base + c0, xv);
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const int c = c0 + e;
-                o[e] = (c < C) ? fmaxf(xv[e] + (yv[e] - mean) * rstd * gamma[c] + beta[c], 0.f) : 0.f;
+        for (int k = 0; k < MAXBLK; ++k) {
+            const int c0 = k * 512 + lane * 8;
+            if (c0 < ld) {
+                float yv[8], xv[8], o[8];
+                ld8<T>(Y + base + c0, yv); ld8<T>(X + base + c0, xv);
+#pragma unroll
+                for (int e = 0; e < 8; ++e)
+                    o[e] = (c0 + e < C) ? fmaxf(xv[e] + (yv[e] - mean) * rstd * gmv[k][e] + btv[k][e], 0.f) : 0.f;
+                st8<T>(G + base + c0, o);
             }
-            st8<T>(G + base + c0, o);
         }
     }
 }
@@ -408,11 +419,14 @@ __global__ __launch_bounds__(256) void gconv_pre_bwd1_kernel(const T* __restrict
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, b = blockIdx.y;
     float mean, rstd;
     ln_stats(sums + 2 * b, (double)N * C, mean, rstd);
-    float ag[MAXBLK][8], ab[MAXBLK][8];
+    float ag[MAXBLK][8], ab[MAXBLK][8], gmv[MAXBLK][8];
 #pragma unroll
-    for (int k = 0; k < MAXBLK; ++k)
+    for (int k = 0; k < MAXBLK; ++k) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) { ag[k][e] = 0.f; ab[k][e] = 0.f; }
+        const int c0 = k * 512 + lane * 8;
+        if (c0 < ld) ld8<float>(gamma + c0, gmv[k]);
+    }
     double s1 = 0.0, s2 = 0.0;
     for (int n = blockIdx.x * WPB + w; n < N; n += gridDim.x * WPB) {
         const long base = ((long)b * N + n) * ld;
@@ -429,7 +443,7 @@ __global__ __launch_bounds__(256) void gconv_pre_bwd1_kernel(const T* __restrict
                     const int c = c0 + e;
                     const float dz = (c < C && gv[e] > 0.f) ? g[e] : 0.f;
                     const float xh = (yv[e] - mean) * rstd;
-                    const float dxh = (c < C) ? dz * gamma[c] : 0.f;
+                    const float dxh = (c < C) ? dz * gmv[k][e] : 0.f;
                     ag[k][e] += dz * xh; ab[k][e] += dz;
                     a1 += dxh; a2 += dxh * xh;
                     o[e] = dxh;
@@ -484,6 +498,14 @@ __global__ __launch_bounds__(256) void gconv_post_fwd_kernel(const T* __restrict
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, b = blockIdx.y;
     float mean, rstd;
     ln_stats(sums + 2 * b, (double)N * C, mean, rstd);
+    // per-channel LayerNorm parameters of this lane's columns (the masters are padded past C inside the
+    // flat buffer, values beyond C are never used)
+    float gmv[MAXBLK][8], btv[MAXBLK][8];
+#pragma unroll
+    for (int k = 0; k < MAXBLK; ++k) {
+        const int c0 = k * 512 + lane * 8;
+        if (c0 < ld) { ld8<float>(gamma + c0, gmv[k]); if (beta) ld8<float>(beta + c0, btv[k]); }
+    }
     for (int n = blockIdx.x * WPB + w; n < N; n += gridDim.x * WPB) {
         const long base = ((long)b * N + n) * ld;
         float hv[MAXBLK][8];
@@ -497,7 +519,7 @@ __global__ __launch_bounds__(256) void gconv_post_fwd_kernel(const T* __restrict
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
                     const int c = c0 + e;
-                    const float h = (c < C) ? fmaxf((uv[e] - mean) * rstd * gamma[c] + beta[c], 0.f) : 0.f;
+                    const float h = (c < C) ? fmaxf((uv[e] - mean) * rstd * gmv[k][e] + btv[k][e], 0.f) : 0.f;
                     hv[k][e] = h; ss += h * h;
                 }
             }
@@ -528,11 +550,14 @@ __global__ __launch_bounds__(256) void gconv_post_bwd1_kernel(const T* __restric
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, b = blockIdx.y;
     float mean, rstd;
     ln_stats(sums + 2 * b, (double)N * C, mean, rstd);
-    float ag[MAXBLK][8], ab[MAXBLK][8];
+    float ag[MAXBLK][8], ab[MAXBLK][8], gmv[MAXBLK][8];
 #pragma unroll
-    for (int k = 0; k < MAXBLK; ++k)
+    for (int k = 0; k < MAXBLK; ++k) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) { ag[k][e] = 0.f; ab[k][e] = 0.f; }
+        const int c0 = k * 512 + lane * 8;
+        if (c0 < ld) ld8<float>(gamma + c0, gmv[k]);
+    }
     double s1 = 0.0, s2 = 0.0;
     for (int n = blockIdx.x * WPB + w; n < N; n += gridDim.x * WPB) {
         const long base = ((long)b * N + n) * ld;
@@ -564,7 +589,7 @@ __global__ __launch_bounds__(256) void gconv_post_bwd1_kernel(const T* __restric
                     const float dh = a * (g[k][e] - ov[k][e] * dot);
                     const float dz = (c < C && ov[k][e] > 0.f) ? dh : 0.f;
                     const float xh = (uv[e] - mean) * rstd;
-                    const float dxh = (c < C) ? dz * gamma[c] : 0.f;
+                    const float dxh = (c < C) ? dz * gmv[k][e] : 0.f;
                     ag[k][e] += dz * xh; ab[k][e] += dz;
                     a1 += dxh; a2 += dxh * xh;
                     o[e] = dxh;
