@@ -168,17 +168,16 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const cmpc_gemm_nt_args p)
         const float4 v4 = *reinterpret_cast<const float4*>(slab + row * WC + sc);
         float v[4] = {v4.x, v4.y, v4.z, v4.w};
         const long bm = bz * (long)p.M + gm;       // row index across the batch
+        // one 16-byte load per bias vector (gn is a multiple of 4, N a multiple of 4, vectors 16-B aligned)
+        float4 bb = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (p.bias) bb = *reinterpret_cast<const float4*>(p.bias + gn);
+        if (p.sbias) { const float4 t = *reinterpret_cast<const float4*>(p.sbias + (bm / rps) * (long)p.ld_sbias + gn); bb.x += t.x; bb.y += t.y; bb.z += t.z; bb.w += t.w; }
+        if (p.pbias) { const float4 t = *reinterpret_cast<const float4*>(p.pbias + (bm % rps) * (long)p.ld_pbias + gn); bb.x += t.x; bb.y += t.y; bb.z += t.z; bb.w += t.w; }
+        const float bv[4] = {bb.x, bb.y, bb.z, bb.w};
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            float x = v[e] * p.alpha;
-            if (gn + e < p.n_valid) {
-                if (p.bias) x += p.bias[gn + e];
-                if (p.sbias) x += p.sbias[(bm / rps) * (long)p.ld_sbias + gn + e];
-                if (p.pbias) x += p.pbias[(bm % rps) * (long)p.ld_pbias + gn + e];
-                x = act_apply(x, p.act);
-            } else {
-                x = 0.0f;                          // keep pad columns exactly zero
-            }
+            float x = 0.0f;                        // pad columns stay exactly zero
+            if (gn + e < p.n_valid) x = act_apply(v[e] * p.alpha + bv[e], p.act);
             v[e] = x;
         }
         const long off = (long)gm * p.ldc + gn;
@@ -335,17 +334,16 @@ __global__ __launch_bounds__(512) void gemm_nt_v2_kernel(const cmpc_gemm_nt_args
         const float4 v4 = *reinterpret_cast<const float4*>(slab + row * WC + sc);
         float v[4] = {v4.x, v4.y, v4.z, v4.w};
         const long bm = bz * (long)p.M + gm;
+        // one 16-byte load per bias vector (gn is a multiple of 4, N a multiple of 4, vectors 16-B aligned)
+        float4 bb = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (p.bias) bb = *reinterpret_cast<const float4*>(p.bias + gn);
+        if (p.sbias) { const float4 t = *reinterpret_cast<const float4*>(p.sbias + (bm / rps) * (long)p.ld_sbias + gn); bb.x += t.x; bb.y += t.y; bb.z += t.z; bb.w += t.w; }
+        if (p.pbias) { const float4 t = *reinterpret_cast<const float4*>(p.pbias + (bm % rps) * (long)p.ld_pbias + gn); bb.x += t.x; bb.y += t.y; bb.z += t.z; bb.w += t.w; }
+        const float bv[4] = {bb.x, bb.y, bb.z, bb.w};
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            float x = v[e] * p.alpha;
-            if (gn + e < p.n_valid) {
-                if (p.bias) x += p.bias[gn + e];
-                if (p.sbias) x += p.sbias[(bm / rps) * (long)p.ld_sbias + gn + e];
-                if (p.pbias) x += p.pbias[(bm % rps) * (long)p.ld_pbias + gn + e];
-                x = act_apply(x, p.act);
-            } else {
-                x = 0.0f;
-            }
+            float x = 0.0f;                        // pad columns stay exactly zero
+            if (gn + e < p.n_valid) x = act_apply(v[e] * p.alpha + bv[e], p.act);
             v[e] = x;
         }
         const long off = (long)gm * p.ldc + gn;
@@ -498,17 +496,16 @@ __global__ __launch_bounds__(512) void gemm_nt_v3_kernel(const cmpc_gemm_nt_args
         const float4 v4 = *reinterpret_cast<const float4*>(slab + row * WC + sc);
         float v[4] = {v4.x, v4.y, v4.z, v4.w};
         const long bm = bz * (long)p.M + gm;
+        // one 16-byte load per bias vector (gn is a multiple of 4, N a multiple of 4, vectors 16-B aligned)
+        float4 bb = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (p.bias) bb = *reinterpret_cast<const float4*>(p.bias + gn);
+        if (p.sbias) { const float4 t = *reinterpret_cast<const float4*>(p.sbias + (bm / rps) * (long)p.ld_sbias + gn); bb.x += t.x; bb.y += t.y; bb.z += t.z; bb.w += t.w; }
+        if (p.pbias) { const float4 t = *reinterpret_cast<const float4*>(p.pbias + (bm % rps) * (long)p.ld_pbias + gn); bb.x += t.x; bb.y += t.y; bb.z += t.z; bb.w += t.w; }
+        const float bv[4] = {bb.x, bb.y, bb.z, bb.w};
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            float x = v[e] * p.alpha;
-            if (gn + e < p.n_valid) {
-                if (p.bias) x += p.bias[gn + e];
-                if (p.sbias) x += p.sbias[(bm / rps) * (long)p.ld_sbias + gn + e];
-                if (p.pbias) x += p.pbias[(bm % rps) * (long)p.ld_pbias + gn + e];
-                x = act_apply(x, p.act);
-            } else {
-                x = 0.0f;
-            }
+            float x = 0.0f;                        // pad columns stay exactly zero
+            if (gn + e < p.n_valid) x = act_apply(v[e] * p.alpha + bv[e], p.act);
             v[e] = x;
         }
         const long off = (long)gm * p.ldc + gn;
@@ -664,10 +661,16 @@ __global__ __launch_bounds__(512) void conv_v2_kernel(const cmpc_conv_args p) {
         const float4 v4 = *reinterpret_cast<const float4*>(slab + row * WC + sc);
         float v[4] = {v4.x, v4.y, v4.z, v4.w};
         const long off = (long)gm * p.ldy + gn;
+        const float4 b4 = *reinterpret_cast<const float4*>(p.bias + gn);
+        const float bv[4] = {b4.x, b4.y, b4.z, b4.w};
+        float rv[4] = {0.f, 0.f, 0.f, 0.f};
+        if (Rs) {
+            if constexpr (sizeof(T) == 4) { const float4 r4 = *reinterpret_cast<const float4*>(Rs + off); rv[0] = r4.x; rv[1] = r4.y; rv[2] = r4.z; rv[3] = r4.w; }
+            else { const uint2 r2 = *reinterpret_cast<const uint2*>(Rs + off); rv[0] = __uint_as_float(r2.x << 16); rv[1] = __uint_as_float(r2.x & 0xffff0000u); rv[2] = __uint_as_float(r2.y << 16); rv[3] = __uint_as_float(r2.y & 0xffff0000u); }
+        }
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            float x = v[e] + p.bias[gn + e];
-            if (Rs) x += Elem<T>::ld(Rs + off + e);
+            const float x = v[e] + bv[e] + rv[e];
             v[e] = p.relu ? fmaxf(x, 0.f) : x;
         }
         if constexpr (sizeof(T) == 4) {
