@@ -40,6 +40,67 @@ template <> struct Mma<float> {
     }
 };
 
+
+// ---- shared epilogue: wave-private fp32 slab [WR][WC] in LDS -> 8 consecutive columns per lane ----
+// (two 16-B LDS reads, 16-B bias loads, ONE 16-B bf16 store or two fp32 stores per lane and pass)
+__device__ __forceinline__ int slab_col(int row, int col, int WC) { return col ^ ((((row >> 2) & 3) << 4) & (WC - 1)); }
+
+template <typename T, int WR, int WC>
+__device__ __forceinline__ void gemm_nt_epilogue(const cmpc_gemm_nt_args& p, const float* slab, int lane, int row0, int col0, long bz) {
+    constexpr int LPR = WC / 8, RPP = 64 / LPR;
+    T* Ct = reinterpret_cast<T*>(p.C) + bz * p.sC;
+    float* Cf = reinterpret_cast<float*>(p.C) + bz * p.sC;
+    const int rps = p.rows_per_sample > 0 ? p.rows_per_sample : 1;
+#pragma unroll 2
+    for (int pass = 0; pass < WR / RPP; ++pass) {
+        const int row = pass * RPP + lane / LPR, c8 = (lane % LPR) * 8;
+        const int gm = row0 + row, gn = col0 + c8;
+        if (gm >= p.M || gn >= p.N) continue;
+        const float4 va = *reinterpret_cast<const float4*>(slab + row * WC + slab_col(row, c8, WC));
+        const float4 vb = *reinterpret_cast<const float4*>(slab + row * WC + slab_col(row, c8 + 4, WC));
+        float v[8] = {va.x, va.y, va.z, va.w, vb.x, vb.y, vb.z, vb.w};
+        const long bm = bz * (long)p.M + gm;
+        float bv[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        const bool full = gn + 8 <= p.N;            // N is only guaranteed to be a multiple of 4
+        auto addv = [&](const float* src) {
+            const float4 t0 = *reinterpret_cast<const float4*>(src);
+            bv[0] += t0.x; bv[1] += t0.y; bv[2] += t0.z; bv[3] += t0.w;
+            if (full) { const float4 t1 = *reinterpret_cast<const float4*>(src + 4); bv[4] += t1.x; bv[5] += t1.y; bv[6] += t1.z; bv[7] += t1.w; }
+        };
+        if (p.bias) addv(p.bias + gn);
+        if (p.sbias) addv(p.sbias + (bm / rps) * (long)p.ld_sbias + gn);
+        if (p.pbias) addv(p.pbias + (bm % rps) * (long)p.ld_pbias + gn);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            float x = 0.0f;                        // pad columns stay exactly zero
+            if (gn + e < p.n_valid) x = act_apply(v[e] * p.alpha + bv[e], p.act);
+            v[e] = x;
+        }
+        const long off = (long)gm * p.ldc + gn;
+        if (p.c_f32 || sizeof(T) == 4) {
+            float* Cp = p.c_f32 ? Cf + off : reinterpret_cast<float*>(Ct) + off;
+            if (p.accumulate) {
+                const float4 o0 = *reinterpret_cast<const float4*>(Cp);
+                v[0] += o0.x; v[1] += o0.y; v[2] += o0.z; v[3] += o0.w;
+                if (full) { const float4 o1 = *reinterpret_cast<const float4*>(Cp + 4); v[4] += o1.x; v[5] += o1.y; v[6] += o1.z; v[7] += o1.w; }
+            }
+            *reinterpret_cast<float4*>(Cp) = make_float4(v[0], v[1], v[2], v[3]);
+            if (full) *reinterpret_cast<float4*>(Cp + 4) = make_float4(v[4], v[5], v[6], v[7]);
+        } else {
+            bf16_t* Cb = reinterpret_cast<bf16_t*>(Ct) + off;
+            if (full && ((reinterpret_cast<uintptr_t>(Cb) & 15) == 0)) {
+                if (p.accumulate) { float o[8]; ld8<bf16_t>(Cb, o);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] += o[e]; }
+                st8<bf16_t>(Cb, v);
+            } else {
+                const int ne = full ? 8 : 4;
+                for (int e = 0; e < ne; ++e) { float x = v[e]; if (p.accumulate) x += bf2f(Cb[e]); Cb[e] = f2bf(x); }
+            }
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------
 // gemm_nt
 // ------------------------------------------------------------------------------------------
@@ -155,53 +216,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const cmpc_gemm_nt_args p)
     __builtin_amdgcn_s_waitcnt(0xC07F);            // lgkmcnt(0): own wave's LDS writes landed
     __builtin_amdgcn_wave_barrier();
 
-    constexpr int LPR = WC / 4;                    // lanes per row (4 floats each)
-    constexpr int RPP = 64 / LPR;                  // rows per pass
-    T* Ct = reinterpret_cast<T*>(p.C) + bz * p.sC;
-    float* Cf = reinterpret_cast<float*>(p.C) + bz * p.sC;
-    const int rps = p.rows_per_sample > 0 ? p.rows_per_sample : 1;
-    for (int pass = 0; pass < WR / RPP; ++pass) {
-        const int row = pass * RPP + lane / LPR, c4 = (lane % LPR) * 4;
-        const int gm = m0 + wm * WR + row, gn = n0 + wn * WC + c4;
-        if (gm >= p.M || gn >= p.N) continue;
-        const int sc = c4 ^ ((((row >> 2) & 3) << 4) & (WC - 1));
-        const float4 v4 = *reinterpret_cast<const float4*>(slab + row * WC + sc);
-        float v[4] = {v4.x, v4.y, v4.z, v4.w};
-        const long bm = bz * (long)p.M + gm;       // row index across the batch
-        // one 16-byte load per bias vector (gn is a multiple of 4, N a multiple of 4, vectors 16-B aligned)
-        float4 bb = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (p.bias) bb = *reinterpret_cast<const float4*>(p.bias + gn);
-        if (p.sbias) { const float4 t = *reinterpret_cast<const float4*>(p.sbias + (bm / rps) * (long)p.ld_sbias + gn); bb.x += t.x; bb.y += t.y; bb.z += t.z; bb.w += t.w; }
-        if (p.pbias) { const float4 t = *reinterpret_cast<const float4*>(p.pbias + (bm % rps) * (long)p.ld_pbias + gn); bb.x += t.x; bb.y += t.y; bb.z += t.z; bb.w += t.w; }
-        const float bv[4] = {bb.x, bb.y, bb.z, bb.w};
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            float x = 0.0f;                        // pad columns stay exactly zero
-            if (gn + e < p.n_valid) x = act_apply(v[e] * p.alpha + bv[e], p.act);
-            v[e] = x;
-        }
-        const long off = (long)gm * p.ldc + gn;
-        if (p.c_f32) {
-            if (p.accumulate) {
-                const float4 o = *reinterpret_cast<const float4*>(Cf + off);
-                v[0] += o.x; v[1] += o.y; v[2] += o.z; v[3] += o.w;
-            }
-            *reinterpret_cast<float4*>(Cf + off) = make_float4(v[0], v[1], v[2], v[3]);
-        } else {
-            if (p.accumulate) {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] += Elem<T>::ld(Ct + off + e);
-            }
-            if constexpr (sizeof(T) == 4) {
-                *reinterpret_cast<float4*>(Ct + off) = make_float4(v[0], v[1], v[2], v[3]);
-            } else {
-                uint2 o;
-                o.x = (uint32_t)f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16);
-                o.y = (uint32_t)f2bf(v[2]) | ((uint32_t)f2bf(v[3]) << 16);
-                *reinterpret_cast<uint2*>(Ct + off) = o;
-            }
-        }
-    }
+    gemm_nt_epilogue<T, WR, WC>(p, slab, lane, m0 + wm * WR, n0 + wn * WC, bz);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -322,52 +337,7 @@ __global__ __launch_bounds__(512) void gemm_nt_v2_kernel(const cmpc_gemm_nt_args
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_wave_barrier();
 
-    constexpr int LPR = WC / 4, RPP = 64 / LPR;
-    T* Ct = reinterpret_cast<T*>(p.C) + bz * p.sC;
-    float* Cf = reinterpret_cast<float*>(p.C) + bz * p.sC;
-    const int rps = p.rows_per_sample > 0 ? p.rows_per_sample : 1;
-    for (int pass = 0; pass < WR / RPP; ++pass) {
-        const int row = pass * RPP + lane / LPR, c4 = (lane % LPR) * 4;
-        const int gm = m0 + wm * WR + row, gn = n0 + wn * WC + c4;
-        if (gm >= p.M || gn >= p.N) continue;
-        const int sc = c4 ^ (((row >> 2) & 3) << 4);
-        const float4 v4 = *reinterpret_cast<const float4*>(slab + row * WC + sc);
-        float v[4] = {v4.x, v4.y, v4.z, v4.w};
-        const long bm = bz * (long)p.M + gm;
-        // one 16-byte load per bias vector (gn is a multiple of 4, N a multiple of 4, vectors 16-B aligned)
-        float4 bb = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (p.bias) bb = *reinterpret_cast<const float4*>(p.bias + gn);
-        if (p.sbias) { const float4 t = *reinterpret_cast<const float4*>(p.sbias + (bm / rps) * (long)p.ld_sbias + gn); bb.x += t.x; bb.y += t.y; bb.z += t.z; bb.w += t.w; }
-        if (p.pbias) { const float4 t = *reinterpret_cast<const float4*>(p.pbias + (bm % rps) * (long)p.ld_pbias + gn); bb.x += t.x; bb.y += t.y; bb.z += t.z; bb.w += t.w; }
-        const float bv[4] = {bb.x, bb.y, bb.z, bb.w};
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            float x = 0.0f;                        // pad columns stay exactly zero
-            if (gn + e < p.n_valid) x = act_apply(v[e] * p.alpha + bv[e], p.act);
-            v[e] = x;
-        }
-        const long off = (long)gm * p.ldc + gn;
-        if (p.c_f32) {
-            if (p.accumulate) {
-                const float4 o = *reinterpret_cast<const float4*>(Cf + off);
-                v[0] += o.x; v[1] += o.y; v[2] += o.z; v[3] += o.w;
-            }
-            *reinterpret_cast<float4*>(Cf + off) = make_float4(v[0], v[1], v[2], v[3]);
-        } else {
-            if (p.accumulate) {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] += Elem<T>::ld(Ct + off + e);
-            }
-            if constexpr (sizeof(T) == 4) {
-                *reinterpret_cast<float4*>(Ct + off) = make_float4(v[0], v[1], v[2], v[3]);
-            } else {
-                uint2 o;
-                o.x = (uint32_t)f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16);
-                o.y = (uint32_t)f2bf(v[2]) | ((uint32_t)f2bf(v[3]) << 16);
-                *reinterpret_cast<uint2*>(Ct + off) = o;
-            }
-        }
-    }
+    gemm_nt_epilogue<T, WR, WC>(p, slab, lane, m0 + wm * WR, n0 + wn * WC, bz);
 }
 
 // gemm_nt v3 = v2 with producer / consumer wave specialisation.
@@ -484,52 +454,7 @@ __global__ __launch_bounds__(512) void gemm_nt_v3_kernel(const cmpc_gemm_nt_args
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_wave_barrier();
 
-    constexpr int LPR = WC / 4, RPP = 64 / LPR;
-    T* Ct = reinterpret_cast<T*>(p.C) + bz * p.sC;
-    float* Cf = reinterpret_cast<float*>(p.C) + bz * p.sC;
-    const int rps = p.rows_per_sample > 0 ? p.rows_per_sample : 1;
-    for (int pass = 0; pass < WR / RPP; ++pass) {
-        const int row = pass * RPP + lane / LPR, c4 = (lane % LPR) * 4;
-        const int gm = m0 + wm * WR + row, gn = n0 + wn * WC + c4;
-        if (gm >= p.M || gn >= p.N) continue;
-        const int sc = c4 ^ (((row >> 2) & 3) << 4);
-        const float4 v4 = *reinterpret_cast<const float4*>(slab + row * WC + sc);
-        float v[4] = {v4.x, v4.y, v4.z, v4.w};
-        const long bm = bz * (long)p.M + gm;
-        // one 16-byte load per bias vector (gn is a multiple of 4, N a multiple of 4, vectors 16-B aligned)
-        float4 bb = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (p.bias) bb = *reinterpret_cast<const float4*>(p.bias + gn);
-        if (p.sbias) { const float4 t = *reinterpret_cast<const float4*>(p.sbias + (bm / rps) * (long)p.ld_sbias + gn); bb.x += t.x; bb.y += t.y; bb.z += t.z; bb.w += t.w; }
-        if (p.pbias) { const float4 t = *reinterpret_cast<const float4*>(p.pbias + (bm % rps) * (long)p.ld_pbias + gn); bb.x += t.x; bb.y += t.y; bb.z += t.z; bb.w += t.w; }
-        const float bv[4] = {bb.x, bb.y, bb.z, bb.w};
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            float x = 0.0f;                        // pad columns stay exactly zero
-            if (gn + e < p.n_valid) x = act_apply(v[e] * p.alpha + bv[e], p.act);
-            v[e] = x;
-        }
-        const long off = (long)gm * p.ldc + gn;
-        if (p.c_f32) {
-            if (p.accumulate) {
-                const float4 o = *reinterpret_cast<const float4*>(Cf + off);
-                v[0] += o.x; v[1] += o.y; v[2] += o.z; v[3] += o.w;
-            }
-            *reinterpret_cast<float4*>(Cf + off) = make_float4(v[0], v[1], v[2], v[3]);
-        } else {
-            if (p.accumulate) {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] += Elem<T>::ld(Ct + off + e);
-            }
-            if constexpr (sizeof(T) == 4) {
-                *reinterpret_cast<float4*>(Ct + off) = make_float4(v[0], v[1], v[2], v[3]);
-            } else {
-                uint2 o;
-                o.x = (uint32_t)f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16);
-                o.y = (uint32_t)f2bf(v[2]) | ((uint32_t)f2bf(v[3]) << 16);
-                *reinterpret_cast<uint2*>(Ct + off) = o;
-            }
-        }
-    }
+    gemm_nt_epilogue<T, WR, WC>(p, slab, lane, m0 + wm * WR, n0 + wn * WC, bz);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -650,37 +575,27 @@ __global__ __launch_bounds__(512) void conv_v2_kernel(const cmpc_conv_args p) {
             }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_wave_barrier();
-    constexpr int LPR = WC / 4, RPP = 64 / LPR;
+    constexpr int LPR = WC / 8, RPP = 64 / LPR;      // 8 columns per lane (Cout % 8 == 0)
     T* Y = reinterpret_cast<T*>(p.Y);
     const T* Rs = reinterpret_cast<const T*>(p.res);
+#pragma unroll 2
     for (int pass = 0; pass < WR / RPP; ++pass) {
-        const int row = pass * RPP + lane / LPR, c4 = (lane % LPR) * 4;
-        const int gm = m0 + wm * WR + row, gn = n0 + wn * WC + c4;
+        const int row = pass * RPP + lane / LPR, c8 = (lane % LPR) * 8;
+        const int gm = m0 + wm * WR + row, gn = n0 + wn * WC + c8;
         if (gm >= M || gn >= N) continue;
-        const int sc = c4 ^ (((row >> 2) & 3) << 4);
-        const float4 v4 = *reinterpret_cast<const float4*>(slab + row * WC + sc);
-        float v[4] = {v4.x, v4.y, v4.z, v4.w};
+        const float4 va = *reinterpret_cast<const float4*>(slab + row * WC + slab_col(row, c8, WC));
+        const float4 vb = *reinterpret_cast<const float4*>(slab + row * WC + slab_col(row, c8 + 4, WC));
+        float v[8] = {va.x, va.y, va.z, va.w, vb.x, vb.y, vb.z, vb.w};
         const long off = (long)gm * p.ldy + gn;
-        const float4 b4 = *reinterpret_cast<const float4*>(p.bias + gn);
-        const float bv[4] = {b4.x, b4.y, b4.z, b4.w};
-        float rv[4] = {0.f, 0.f, 0.f, 0.f};
-        if (Rs) {
-            if constexpr (sizeof(T) == 4) { const float4 r4 = *reinterpret_cast<const float4*>(Rs + off); rv[0] = r4.x; rv[1] = r4.y; rv[2] = r4.z; rv[3] = r4.w; }
-            else { const uint2 r2 = *reinterpret_cast<const uint2*>(Rs + off); rv[0] = __uint_as_float(r2.x << 16); rv[1] = __uint_as_float(r2.x & 0xffff0000u); rv[2] = __uint_as_float(r2.y << 16); rv[3] = __uint_as_float(r2.y & 0xffff0000u); }
-        }
+        float bv[8], rv[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        ld8<float>(p.bias + gn, bv);
+        if (Rs) ld8<T>(Rs + off, rv);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
+        for (int e = 0; e < 8; ++e) {
             const float x = v[e] + bv[e] + rv[e];
             v[e] = p.relu ? fmaxf(x, 0.f) : x;
         }
-        if constexpr (sizeof(T) == 4) {
-            *reinterpret_cast<float4*>(Y + off) = make_float4(v[0], v[1], v[2], v[3]);
-        } else {
-            uint2 o;
-            o.x = (uint32_t)f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16);
-            o.y = (uint32_t)f2bf(v[2]) | ((uint32_t)f2bf(v[3]) << 16);
-            *reinterpret_cast<uint2*>(Y + off) = o;
-        }
+        st8<T>(Y + off, v);
     }
 }
 
@@ -1088,9 +1003,9 @@ static int launch_conv(const cmpc_conv_args* a, hipStream_t st) {
 extern "C" int cmpc_conv_nhwc(const cmpc_conv_args* a, void* stream) {
     if (!a || !a->X || !a->Wt || !a->Y || !a->bias || !a->zeros || a->B <= 0 || a->H <= 0 || a->W <= 0) { cmpc_set_error("conv_nhwc: bad args"); return CMPC_EINVAL; }
     const int esz = a->dtype == DT_F32 ? 4 : 2, bk = BKB / esz;
-    if ((a->ksize != 1 && a->ksize != 3) || (a->stride != 1 && a->stride != 2) || a->dil < 1 || a->Cin % bk || a->Cout % 4 ||
-        (a->ldx * esz) % 16 || (a->ldw * esz) % 16 || a->ldy % 4) {
-        cmpc_set_error("conv_nhwc: need k in {1,3}, stride in {1,2}, Cin %% %d == 0, Cout %% 4 == 0, 16-B aligned rows", bk); return CMPC_EINVAL;
+    if ((a->ksize != 1 && a->ksize != 3) || (a->stride != 1 && a->stride != 2) || a->dil < 1 || a->Cin % bk || a->Cout % 8 ||
+        (a->ldx * esz) % 16 || (a->ldw * esz) % 16 || a->ldy % 8 || (a->res && a->ldy % 8)) {
+        cmpc_set_error("conv_nhwc: need k in {1,3}, stride in {1,2}, Cin %% %d == 0, Cout %% 8 == 0, ldy %% 8 == 0, 16-B aligned rows", bk); return CMPC_EINVAL;
     }
     if (a->dtype == DT_F32) return launch_conv<float>(a, (hipStream_t)stream);
     if (a->dtype == DT_BF16) return launch_conv<bf16_t>(a, (hipStream_t)stream);

@@ -67,7 +67,8 @@ int cmpc_gemm_tn(const cmpc_gemm_tn_args* a, void* stream);
 /* ---- backbone convolutions as implicit GEMM (deeplab_resnet/model.py:19-401; network.py:105-188 conv /
  *      atrous_conv 'SAME', :260-270 frozen batch_norm folded into Wt and bias, :194-201,233-235 relu / add).
  *      X [B,H,W,Cin] NHWC (row stride ldx), Wt [Cout][k*k*Cin] (tap-major, Cin fastest), Y / res [B,Ho,Wo,Cout];
- *      zeros: >= 256 bytes of device zeros (source for out-of-image taps). ------------------------------- */
+ *      zeros: >= 256 bytes of device zeros (source for out-of-image taps). Needs ksize in {1,3}, stride in
+ *      {1,2}, Cin % 64 (bf16) / 32 (f32) == 0, Cout % 8 == 0, ldy % 8 == 0, 16-B aligned rows. ------------- */
 typedef struct {
     int dtype;
     const void* X; int ldx;
