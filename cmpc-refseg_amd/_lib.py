@@ -150,6 +150,8 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
+    global LIB_PATH
+    LIB_PATH = os.environ.get("CMPC_LIB_PATH", LIB_PATH)       # debug builds (e.g. the -DCMPC_GEMM_TRACE one)
     if not os.path.exists(LIB_PATH):
         raise CmpcError(
             f"{LIB_PATH} not found: the CMPC head has no fallback path. Build it with "

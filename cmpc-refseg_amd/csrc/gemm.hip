@@ -225,6 +225,17 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const cmpc_gemm_nt_args p)
 // the loads of tile t+1 stay in flight across the barrier while tile t is multiplied.
 // LDS image identical to v1 (linear destination, XOR applied to the per-lane SOURCE chunk).
 // ------------------------------------------------------------------------------------------
+#ifdef CMPC_GEMM_TRACE
+// per-workgroup phase timestamps (100 MHz wall clock) for scripts/gemm_trace.py; not part of the product build
+__device__ long long g_gemm_trace[8 * 4096];
+#define TRACE_MARK(i) do { if (threadIdx.x == 0 && blockIdx.x < 4096) g_gemm_trace[blockIdx.x * 8 + (i)] = wall_clock64(); } while (0)
+extern "C" int cmpc_debug_gemm_trace(long long* dst, int n) {
+    return hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_gemm_trace), sizeof(long long) * n) == hipSuccess ? 0 : -2;
+}
+#else
+#define TRACE_MARK(i) do {} while (0)
+#endif
+
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
 // One LDS-DMA wave-instruction: 64 lanes x 16 B from per-lane global addresses to 1 KiB of LDS at the
@@ -250,6 +261,7 @@ __global__ __launch_bounds__(512) void gemm_nt_v2_kernel(const cmpc_gemm_nt_args
     constexpr int LPT = APW + BPW;                 // LDS-DMA instructions per wave per tile
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    TRACE_MARK(0);
     const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wid / WAVES_N, wn = wid % WAVES_N;
     const int gx = (p.N + BN - 1) / BN, nwg = gridDim.x;
@@ -301,6 +313,7 @@ __global__ __launch_bounds__(512) void gemm_nt_v2_kernel(const cmpc_gemm_nt_args
     for (int kt = 0; kt < ntot; ++kt) {
         if (kt + 1 < ntot) wait_vmcnt<LPT>(); else wait_vmcnt<0>();
         __builtin_amdgcn_s_barrier();
+        if (kt == 0) TRACE_MARK(1);
         if (kt + 2 < ntot) issue(kt + 2, cur == 0 ? 2 : cur - 1);
         const char* sA = smem + cur * STAGE;
         const char* sB = sA + BM * BKB;
@@ -322,6 +335,7 @@ __global__ __launch_bounds__(512) void gemm_nt_v2_kernel(const cmpc_gemm_nt_args
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
+    TRACE_MARK(2);
 
     constexpr int WR = TM * 16, WC = TN * 16;
     float* slab = reinterpret_cast<float*>(smem) + wid * (WR * WC);
@@ -336,8 +350,185 @@ __global__ __launch_bounds__(512) void gemm_nt_v2_kernel(const cmpc_gemm_nt_args
             }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_wave_barrier();
+    TRACE_MARK(3);
 
     gemm_nt_epilogue<T, WR, WC>(p, slab, lane, m0 + wm * WR, n0 + wn * WC, bz);
+    TRACE_MARK(4);
+#ifdef CMPC_GEMM_TRACE
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    TRACE_MARK(5);
+    if (threadIdx.x == 0 && blockIdx.x < 4096) {
+        unsigned hw; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        unsigned xcc; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        g_gemm_trace[blockIdx.x * 8 + 6] = hw; g_gemm_trace[blockIdx.x * 8 + 7] = xcc;
+    }
+#endif
+}
+
+// ------------------------------------------------------------------------------------------
+// gemm_nt v4: v2's tile and LDS-DMA pipeline with
+//  * fragment double buffering: the ds_reads of the NEXT half k-tile are issued before the 16 MFMAs
+//    of the current one (phase trace of v2: 1.05 us per k-tile against 0.43 us of MFMA time, both
+//    waves of a SIMD exposing their LDS-read latency twice per k-tile in lockstep);
+//  * three k-tiles of loads in flight (the barrier that publishes tile t+1 also retires tile t);
+//  * MFMA operand roles swapped (weights as "A"): a lane then holds 4 CONSECUTIVE output columns of one
+//    row, so the epilogue stores straight from registers (8-B bf16 / 16-B fp32 per lane; the 4 tiles of a
+//    wave complete each 128-B line) -- no fp32 slab round trip through LDS (5 us per tile in v2).
+// ------------------------------------------------------------------------------------------
+template <typename T, int BM>
+__global__ __launch_bounds__(512) void gemm_nt_v4_kernel(const cmpc_gemm_nt_args p) {
+    constexpr int BN = 128;
+    constexpr int EPC = 16 / (int)sizeof(T);
+    constexpr int BK = BKB / (int)sizeof(T);
+    constexpr int WAVES_N = 2, WAVES_M = 4;
+    constexpr int TM = BM / WAVES_M / 16, TN = BN / WAVES_N / 16;
+    constexpr int STAGE = (BM + BN) * BKB;
+    constexpr int APW = BM / 8 / 8;
+    constexpr int BPW = BN / 8 / 8;
+    constexpr int LPT = APW + BPW;
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    TRACE_MARK(0);
+    const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wid / WAVES_N, wn = wid % WAVES_N;
+    const int gx = (p.N + BN - 1) / BN, nwg = gridDim.x;
+    const int xq = nwg >> 3, xr = nwg & 7, xcd = blockIdx.x & 7, xi = blockIdx.x >> 3;
+    const int tix = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + xi;
+    const int m0 = (tix / gx) * BM, n0 = (tix % gx) * BN;
+    const long bz = blockIdx.z;
+
+    int ntile[3], ntot = 0;
+#pragma unroll
+    for (int s = 0; s < 3; ++s) { ntile[s] = (s < p.nseg) ? p.K[s] / BK : 0; ntot += ntile[s]; }
+
+    f4 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = f4{0.f, 0.f, 0.f, 0.f};
+
+    const int r8 = lane >> 3, slot = lane & 7;
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+    auto issue = [&](int tile, int buf) {
+        int s = 0, t = tile;
+        if (t >= ntile[0]) { t -= ntile[0]; s = 1; if (t >= ntile[1]) { t -= ntile[1]; s = 2; } }
+        const T* Ap = reinterpret_cast<const T*>(p.A[s]) + bz * p.sA[s];
+        const T* Bp = reinterpret_cast<const T*>(p.Bt[s]) + bz * p.sB[s];
+        const long lda = p.lda[s], ldb = p.ldb[s];
+        const int k0 = t * BK;
+        const uint32_t base = lds0 + buf * STAGE;
+#pragma unroll
+        for (int j = 0; j < APW; ++j) {
+            const int blk = wid * APW + j, row = blk * 8 + r8;
+            const int c = slot ^ ((row >> 1) & 7);
+            const int gm = min(m0 + row, p.M - 1);
+            glds16(Ap + gm * lda + k0 + c * EPC, __builtin_amdgcn_readfirstlane(base + blk * 1024));
+        }
+#pragma unroll
+        for (int j = 0; j < BPW; ++j) {
+            const int blk = wid * BPW + j, row = blk * 8 + r8;
+            const int c = slot ^ ((row >> 1) & 7);
+            const int gn = min(n0 + row, p.N - 1);
+            glds16(Bp + gn * ldb + k0 + c * EPC, __builtin_amdgcn_readfirstlane(base + BM * BKB + blk * 1024));
+        }
+    };
+    const int fr = lane & 15, fq = lane >> 4;
+    auto read_frags = [&](int buf, int s, uint4 (&a)[TM], uint4 (&b)[TN]) {
+        const char* sA = smem + buf * STAGE;
+        const char* sB = sA + BM * BKB;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+            a[i] = *reinterpret_cast<const uint4*>(sA + nt_lds_off(wm * TM * 16 + i * 16 + fr, 4 * s + fq));
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+            b[j] = *reinterpret_cast<const uint4*>(sB + nt_lds_off(wn * TN * 16 + j * 16 + fr, 4 * s + fq));
+    };
+    auto mma_all = [&](const uint4 (&a)[TM], const uint4 (&b)[TN]) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) acc[i][j] = Mma<T>::run(b[j], a[i], acc[i][j]);     // D[n][m]: lane = (m = fr, n = 4 fq + r)
+    };
+
+    if (ntot > 0) issue(0, 0);
+    if (ntot > 1) issue(1, 1);
+    if (ntot > 2) issue(2, 2);
+    if (ntot > 2) wait_vmcnt<2 * LPT>(); else if (ntot > 1) wait_vmcnt<LPT>(); else wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();
+    TRACE_MARK(1);
+    uint4 a0[TM], b0[TN], a1[TM], b1[TN];
+    if (ntot > 0) read_frags(0, 0, a0, b0);
+    int cur = 0;
+    for (int kt = 0; kt < ntot; ++kt) {
+        read_frags(cur, 1, a1, b1);
+        mma_all(a0, b0);
+        const int nxt = (cur == 2) ? 0 : cur + 1;
+        if (kt + 1 < ntot) {
+            // every read of tile kt has landed in registers before the barrier lets another wave's DMA reuse its buffer
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if (kt + 2 < ntot) wait_vmcnt<LPT>(); else wait_vmcnt<0>();
+            __builtin_amdgcn_s_barrier();
+            if (kt + 3 < ntot) issue(kt + 3, cur);
+            read_frags(nxt, 0, a0, b0);
+        }
+        mma_all(a1, b1);
+        cur = nxt;
+    }
+    TRACE_MARK(2);
+    TRACE_MARK(3);
+
+    // ---- epilogue straight from the accumulators ----
+    T* Ct = reinterpret_cast<T*>(p.C) + bz * p.sC;
+    float* Cf = reinterpret_cast<float*>(p.C) + bz * p.sC;
+    const int rps = p.rows_per_sample > 0 ? p.rows_per_sample : 1;
+    const int col0 = n0 + wn * (TN * 16) + 4 * fq, row0 = m0 + wm * (TM * 16) + fr;
+    float4 bj[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int gn = col0 + j * 16;
+        bj[j] = (p.bias && gn < p.N) ? *reinterpret_cast<const float4*>(p.bias + gn) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int gm = row0 + i * 16;
+        if (gm >= p.M) continue;
+        const long bm = bz * (long)p.M + gm;
+        const float* sb = p.sbias ? p.sbias + (bm / rps) * (long)p.ld_sbias : nullptr;
+        const float* pb = p.pbias ? p.pbias + (bm % rps) * (long)p.ld_pbias : nullptr;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int gn = col0 + j * 16;
+            if (gn >= p.N) continue;
+            float4 bv = bj[j];
+            if (sb) { const float4 t = *reinterpret_cast<const float4*>(sb + gn); bv.x += t.x; bv.y += t.y; bv.z += t.z; bv.w += t.w; }
+            if (pb) { const float4 t = *reinterpret_cast<const float4*>(pb + gn); bv.x += t.x; bv.y += t.y; bv.z += t.z; bv.w += t.w; }
+            float v[4] = {acc[i][j][0] * p.alpha + bv.x, acc[i][j][1] * p.alpha + bv.y, acc[i][j][2] * p.alpha + bv.z, acc[i][j][3] * p.alpha + bv.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = (gn + e < p.n_valid) ? act_apply(v[e], p.act) : 0.0f;     // pad columns stay exactly zero
+            const long off = (long)gm * p.ldc + gn;
+            if (p.c_f32 || sizeof(T) == 4) {
+                float* Cp = p.c_f32 ? Cf + off : reinterpret_cast<float*>(Ct) + off;
+                if (p.accumulate) { const float4 o = *reinterpret_cast<const float4*>(Cp); v[0] += o.x; v[1] += o.y; v[2] += o.z; v[3] += o.w; }
+                *reinterpret_cast<float4*>(Cp) = make_float4(v[0], v[1], v[2], v[3]);
+            } else {
+                bf16_t* Cb = reinterpret_cast<bf16_t*>(Ct) + off;
+                if (p.accumulate) {
+                    const uint2 o = *reinterpret_cast<const uint2*>(Cb);
+                    v[0] += __uint_as_float(o.x << 16); v[1] += __uint_as_float(o.x & 0xffff0000u);
+                    v[2] += __uint_as_float(o.y << 16); v[3] += __uint_as_float(o.y & 0xffff0000u);
+                }
+                uint2 o;
+                o.x = (uint32_t)f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16);
+                o.y = (uint32_t)f2bf(v[2]) | ((uint32_t)f2bf(v[3]) << 16);
+                *reinterpret_cast<uint2*>(Cb) = o;
+            }
+        }
+    }
+    TRACE_MARK(4);
+#ifdef CMPC_GEMM_TRACE
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    TRACE_MARK(5);
+#endif
 }
 
 // gemm_nt v3 = v2 with producer / consumer wave specialisation.
@@ -942,13 +1133,17 @@ extern "C" int cmpc_gemm_nt(const cmpc_gemm_nt_args* a, void* stream) {
         int ktot = 0;
         for (int s2 = 0; s2 < a->nseg; ++s2) ktot += a->K[s2];      // long K: producer/consumer waves (v3) win; short K: v2
         const bool big = (long)((a->M + 255) / 256) * gn * a->batch >= 384 || getenv("CMPC_GEMM_BM256");
+        const bool v4 = getenv("CMPC_GEMM_V4") != nullptr;   // register-epilogue variant: not faster end to end (8-B stores), kept for study
         if (big) {
             dim3 grid(((a->M + 255) / 256) * gn, 1, a->batch);
             static bool attr256 = false;
             if (!attr256) { (void)hipFuncSetAttribute((const void*)gemm_nt_v2_kernel<bf16_t, 256>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * (256 + 128) * BKB); attr256 = true; }
             static bool attr256c = false;
             if (!attr256c) { (void)hipFuncSetAttribute((const void*)gemm_nt_v3_kernel<bf16_t, 256>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * (256 + 128) * BKB); attr256c = true; }
-            if (ktot < 2048 || getenv("CMPC_GEMM_V2")) hipLaunchKernelGGL((gemm_nt_v2_kernel<bf16_t, 256>), grid, dim3(512), 3 * (256 + 128) * BKB, st, *a);
+            static bool attr256d = false;
+            if (!attr256d) { (void)hipFuncSetAttribute((const void*)gemm_nt_v4_kernel<bf16_t, 256>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * (256 + 128) * BKB); attr256d = true; }
+            if (v4) hipLaunchKernelGGL((gemm_nt_v4_kernel<bf16_t, 256>), grid, dim3(512), 3 * (256 + 128) * BKB, st, *a);
+            else if (ktot < 2048 || getenv("CMPC_GEMM_V2")) hipLaunchKernelGGL((gemm_nt_v2_kernel<bf16_t, 256>), grid, dim3(512), 3 * (256 + 128) * BKB, st, *a);
             else hipLaunchKernelGGL((gemm_nt_v3_kernel<bf16_t, 256>), grid, dim3(512), 3 * (256 + 128) * BKB, st, *a);
         } else {
             dim3 grid(((a->M + 127) / 128) * gn, 1, a->batch);
@@ -956,7 +1151,10 @@ extern "C" int cmpc_gemm_nt(const cmpc_gemm_nt_args* a, void* stream) {
             if (!attr128) { (void)hipFuncSetAttribute((const void*)gemm_nt_v2_kernel<bf16_t, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * (128 + 128) * BKB); attr128 = true; }
             static bool attr128c = false;
             if (!attr128c) { (void)hipFuncSetAttribute((const void*)gemm_nt_v3_kernel<bf16_t, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * (128 + 128) * BKB); attr128c = true; }
-            if (ktot < 2048 || getenv("CMPC_GEMM_V2")) hipLaunchKernelGGL((gemm_nt_v2_kernel<bf16_t, 128>), grid, dim3(512), 3 * (128 + 128) * BKB, st, *a);
+            static bool attr128d = false;
+            if (!attr128d) { (void)hipFuncSetAttribute((const void*)gemm_nt_v4_kernel<bf16_t, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * (128 + 128) * BKB); attr128d = true; }
+            if (v4) hipLaunchKernelGGL((gemm_nt_v4_kernel<bf16_t, 128>), grid, dim3(512), 3 * (128 + 128) * BKB, st, *a);
+            else if (ktot < 2048 || getenv("CMPC_GEMM_V2")) hipLaunchKernelGGL((gemm_nt_v2_kernel<bf16_t, 128>), grid, dim3(512), 3 * (128 + 128) * BKB, st, *a);
             else hipLaunchKernelGGL((gemm_nt_v3_kernel<bf16_t, 128>), grid, dim3(512), 3 * (128 + 128) * BKB, st, *a);
         }
         return cmpc_check_launch("gemm_nt(v2)");

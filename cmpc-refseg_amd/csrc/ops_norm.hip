@@ -31,8 +31,14 @@ void* cmpc_ws(size_t bytes, hipStream_t st) {
         if (!slot) { cmpc_set_error("workspace: more than 64 streams in use"); return nullptr; }
     }
     if (bytes > slot->bytes) {
-        // growth only happens while shapes are first seen (never inside a steady-state step)
-        if (slot->p) { (void)hipStreamSynchronize(st); (void)hipFree(slot->p); }
+        // growth only happens while shapes are first seen (never inside a steady-state step).  It cannot happen
+        // inside a stream capture (hipMalloc is illegal there), and a block that is outgrown is retired, not
+        // freed: a HIP graph captured earlier may still hold its address.
+        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(st, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone) {
+            cmpc_set_error("workspace of %zu bytes needed during stream capture: run one eager pass on the same streams first", bytes);
+            return nullptr;
+        }
         const size_t want = bytes < ((size_t)32 << 20) ? ((size_t)32 << 20) : bytes * 2;
         if (hipMalloc(&slot->p, want) != hipSuccess) { slot->p = nullptr; slot->bytes = 0; cmpc_set_error("workspace allocation of %zu bytes failed", want); return nullptr; }
         slot->bytes = want;

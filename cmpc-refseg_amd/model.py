@@ -23,6 +23,19 @@ from .params import EXG, LEVELS, HeadCfg, ParamStore, init_head_params
 MU = (104.00698793, 116.66876762, 122.67891434)       # trainval_model.py:371
 
 
+class _OnMain(torch.autograd.Function):
+    """Identity placed on the main stream between two forked phases.  autograd runs a node's backward on the
+    stream of its forward, so with this node every cross-lane gradient goes lane -> main -> lane; direct
+    lane -> lane event edges inside a stream capture crash hipStreamEndCapture on ROCm 7.2."""
+    @staticmethod
+    def forward(ctx, x):
+        return x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g
+
+
 class LSTM_model(object):
     def __init__(self, batch_size=1, num_steps=20, vf_h=40, vf_w=40, H=320, W=320, vf_dim=2048,
                  vocab_size=12112, w_emb_dim=1000, v_emb_dim=1000, mlp_dim=500, start_lr=0.00025,
@@ -73,6 +86,12 @@ class LSTM_model(object):
         self.backbone = self.backbone.to(self.device).to(ops.tdt(self.dt)).to(memory_format=torch.channels_last).eval()
         self.world = 1
         self.last = {}
+        # CMPC_GRAPH=1: train_step replays forward + backward from ONE captured HIP graph (about 1200 launches
+        # per step, no Python in the loop).  Off by default: on ROCm 7.2 the replay of the 4-stream graph is
+        # slower (17.8 ms) than eager launches on the same 4 streams (15.6 ms); on one stream both take 19.2 ms.
+        self.use_graph = os.environ.get("CMPC_GRAPH", "0") != "0"
+        self._graph, self._gin, self._gout, self._eager_steps = None, None, None, 0
+        self._opt_pending = False
         # the three pyramid levels (and the three exchange modules of a round) are independent: each gets
         # its own HIP stream so HBM-bound stage kernels of one level overlap MFMA-bound GEMMs of another.
         # autograd replays every backward on the stream of its forward, so the backward overlaps too.
@@ -81,17 +100,23 @@ class LSTM_model(object):
 
     def set_streams(self, n: int):
         """n > 1: independent levels / exchange modules run on 3 side streams; n = 1: everything on the caller's stream."""
+        if getattr(self, "_opt_pending", False):
+            self._params_ready()
         self.n_streams = n
         if n > 1:
             key = str(self.device)
             if key not in LSTM_model._SIDE_STREAMS:
                 LSTM_model._SIDE_STREAMS[key] = [torch.cuda.Stream(device=self.device) for _ in range(3)]
             self.side = LSTM_model._SIDE_STREAMS[key]
+            if key + "/opt" not in LSTM_model._SIDE_STREAMS:
+                LSTM_model._SIDE_STREAMS[key + "/opt"] = torch.cuda.Stream(device=self.device)
+            self.opt_stream = LSTM_model._SIDE_STREAMS[key + "/opt"]
             if key + "/wg" not in LSTM_model._SIDE_STREAMS:
                 LSTM_model._SIDE_STREAMS[key + "/wg"] = torch.cuda.Stream(device=self.device)
             self.cx.wg = LSTM_model._SIDE_STREAMS[key + "/wg"] if os.environ.get("CMPC_WGRAD_STREAM", "0") != "0" else None
         else:
             self.side = None
+            self.opt_stream = None
             self.cx.wg = None
 
     # ------------------------------------------------------------------------------------------
@@ -115,15 +140,30 @@ class LSTM_model(object):
         """backbone taps (c3, c4, c5), NHWC, head dtype (CMPC_model.py:73-76)."""
         return self.backbone(self._dev(im, torch.float32))
 
-    def features_async(self, im):
+    def _params_ready(self):
+        """The optimizer of the previous train_step runs on its own stream (it overlaps the next step's frozen
+        backbone); everything that touches parameters, packed operands or the gradient buffer waits for it here."""
+        if self._opt_pending:
+            torch.cuda.current_stream(self.device).wait_stream(self.opt_stream)
+            self._opt_pending = False
+
+    def features_async(self, im, ready=None):
         """Backbone on side stream 0 so that it overlaps the (sequential, latency-bound) text LSTM on the
-        caller's stream.  Returns (feats, stream-to-wait-on or None)."""
+        caller's stream.  Returns (feats, stream-to-wait-on or None).
+        ready: optional torch.cuda.Event recorded after `im` (a device tensor) was produced; the backbone then
+        waits for that event only, not for everything queued on the caller's stream (the tail of the previous
+        train step), which is how a prefetched batch overlaps the previous step's backward tail and optimizer."""
         if self.side is None:
             return self.features(im), None
         main = torch.cuda.current_stream(self.device)
+        if ready is not None and not torch.is_tensor(im):
+            ready = None
         im = self._dev(im, torch.float32)
         st = self.side[0]
-        st.wait_stream(main)
+        if ready is not None:
+            st.wait_event(ready)
+        else:
+            st.wait_stream(main)
         with torch.cuda.stream(st):
             feats = self.backbone(im)
         for f in feats:
@@ -138,6 +178,7 @@ class LSTM_model(object):
         `after`: stream that produces `feats` (waited for once the text encoder has been queued)."""
         cfg, cx, O = self.cfg, self.cx, ops
         B, T, N = cfg.batch_size, cfg.num_steps, cfg.N
+        self._params_ready()
         if after is None:
             c3, c4, c5 = [f.to(ops.tdt(self.dt)).contiguous() for f in feats]
         words = self._dev(words, torch.int32).view(-1)
@@ -154,9 +195,12 @@ class LSTM_model(object):
             main.wait_stream(after)
             c3, c4, c5 = [f.to(ops.tdt(self.dt)).contiguous() for f in feats]
 
+        fmask = int(os.environ.get("CMPC_FORK", "7"))          # debug: bit 0 levels, 1 / 2 exchange rounds
+        phase = [0]
+
         def fork(i):
             """run a block on side stream i after everything queued so far on the main stream"""
-            if self.side is None:
+            if self.side is None or not (fmask >> phase[0]) & 1:
                 return main
             st = self.side[i]
             st.wait_stream(main)
@@ -178,6 +222,8 @@ class LSTM_model(object):
                 l, sc, up, _s, _iu = O.ScoreHead.apply(fus[lv], f"score_{lv}", tgt, 0.1, cx)
                 out[f"score_{lv}"], out[f"up_{lv}"], losses[lv] = sc, up, l
         join()
+        fus = {k: _OnMain.apply(v) for k, v in fus.items()}
+        phase[0] = 1
         nec = O.LangPool.apply(parse, wf, 3, cx)                # nec_lang: entity + attribute + relation
         out["nec_lang"] = nec
         f3, f4, f5 = fus["c3"], fus["c4"], fus["c5"]
@@ -186,7 +232,8 @@ class LSTM_model(object):
             with torch.cuda.stream(fork(i)):
                 ex[nm] = O.Exchange.apply(fa, fb, fc, nec, nm, cx)
         join()
-        e3, e4, e5 = ex["c3"], ex["c4"], ex["c5"]
+        phase[0] = 2
+        e3, e4, e5 = (_OnMain.apply(ex[k]) for k in ("c3", "c4", "c5"))
         for i, (nm, fa, fb, fc) in enumerate((("c3_2", e3, e4, e5), ("c4_2", e4, e3, e5), ("c5_2", e5, e3, e4))):
             with torch.cuda.stream(fork(i)):
                 ex[nm] = O.Exchange.apply(fa, fb, fc, nec, nm, cx)
@@ -225,6 +272,7 @@ class LSTM_model(object):
     def loss_and_grads(self, feats, words, target_fine, seq_len, after=None):
         """forward + backward of `cost` (CMPC_model.py:447) into the flat gradient buffer (L2 and the
         x2 bias multiplier are applied inside the Adam kernel)."""
+        self._params_ready()
         self.store.zero_grads()
         o = self.head(feats, words, seq_len, target_fine, after=after)
         o["loss_all"].backward()
@@ -238,16 +286,72 @@ class LSTM_model(object):
                 main.wait_stream(self.cx.wg)
         return o
 
-    def train_step(self, words, im, target_fine, seq_len):
-        """sess.run([train, train_step, merged], feed) (trainval_model.py:98-107)."""
+    _SCALARS = ("loss_all", "loss_c3", "loss_c4", "loss_c5", "loss_last", "mIoU")
+    GRAPH_WARMUP = 2            # eager steps before capture (sizes the library workspaces, MIOpen find, allocator)
+
+    def _fwd_bwd(self, words, im, target_fine, seq_len, ready=None):
+        feats, st = self.features_async(im, ready)
+        o = self.loss_and_grads(feats, words, target_fine, seq_len, after=st)
+        return torch.stack([o[k].detach().float() for k in self._SCALARS])
+
+    def _fwd_bwd_graphed(self, words, im, target_fine, seq_len):
+        """forward + backward through a captured HIP graph: feeds are copied into static device buffers,
+        the graph (backbone, head forward, head backward into the flat gradient buffer, on 4 streams)
+        is replayed, the six summary scalars are copied out."""
+        if self._gin is None:
+            B, T, H, W = self.batch_size, self.num_steps, self.H, self.W
+            d = self.device
+            self._gstream = torch.cuda.Stream(device=d)
+            self._gin = (torch.zeros(B, T, dtype=torch.int32, device=d), torch.zeros(B, H, W, 3, device=d),
+                         torch.zeros(B, H, W, 1, device=d), torch.zeros(B, dtype=torch.int32, device=d))
+        for dst, src in zip(self._gin, (words, im, target_fine, seq_len)):
+            dst.copy_(src if torch.is_tensor(src) else torch.as_tensor(np.asarray(src)), non_blocking=True)
+        cur = torch.cuda.current_stream(self.device)
+        if self._eager_steps < self.GRAPH_WARMUP:
+            # eager passes run on the stream the capture will use: the library's partial-sum workspaces are
+            # per stream and must have their final size before capture
+            self._eager_steps += 1
+            self._gstream.wait_stream(cur)
+            with torch.cuda.stream(self._gstream):
+                sv = self._fwd_bwd(*self._gin)
+            cur.wait_stream(self._gstream)
+            return sv
+        if self._graph is None:
+            torch.cuda.synchronize(self.device)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, stream=self._gstream):
+                self._gout = self._fwd_bwd(*self._gin)
+            self._graph = g
+        self._graph.replay()
+        return self._gout.clone()
+
+    def capture(self, words, im, target_fine, seq_len):
+        """Optional set-up call: run the eager warm-up passes and capture the train graph now (no optimizer
+        step is taken), so that the first train_step already replays it."""
+        self._check_feeds(words, im, seq_len, target_fine)
+        while self._graph is None and self.use_graph:
+            self._fwd_bwd_graphed(words, im, target_fine, seq_len)
+
+    def train_step(self, words, im, target_fine, seq_len, ready=None):
+        """sess.run([train, train_step, merged], feed) (trainval_model.py:98-107).
+        ready: optional torch.cuda.Event recorded once the (device-resident, prefetched) feeds were complete."""
         if self.mode != 'train':
             raise RuntimeError("model was built with mode='eval' (CMPC_model.py:85-86)")
         self._check_feeds(words, im, seq_len, target_fine)
-        feats, st = self.features_async(im)
-        o = self.loss_and_grads(feats, words, target_fine, seq_len, after=st)
+        if self.use_graph:
+            sv = self._fwd_bwd_graphed(words, im, target_fine, seq_len)
+        else:
+            sv = self._fwd_bwd(words, im, target_fine, seq_len, ready)
         gscale = dist.allreduce_grads_(self.store.grads)          # RCCL over xGMI: one flat buffer
-        lr = self.store.adam_step(gscale)
-        scal = {k: o[k].detach() for k in ("loss_all", "loss_c3", "loss_c4", "loss_c5", "loss_last", "mIoU")}
+        if self.opt_stream is not None:
+            # Adam + repack on the optimizer stream: the next step's backbone does not depend on them
+            self.opt_stream.wait_stream(torch.cuda.current_stream(self.device))
+            with torch.cuda.stream(self.opt_stream):
+                lr = self.store.adam_step(gscale)
+            self._opt_pending = True
+        else:
+            lr = self.store.adam_step(gscale)
+        scal = {k: sv[i] for i, k in enumerate(self._SCALARS)}
         scal["mean_IOU"] = scal.pop("mIoU")
         scal["learning_rate"] = lr
         self.last = scal
@@ -255,9 +359,11 @@ class LSTM_model(object):
 
     # ------------------------------------------------------------------------------------------
     def state_dict(self):
+        self._params_ready()
         return self.store.state_dict()
 
     def load_weights(self, named: Dict[str, torch.Tensor]):
+        self._params_ready()
         self.store.load_state(named)
 
     def enable_data_parallel(self):

@@ -164,17 +164,20 @@ def test_head_bf16_within_tolerance(case):
 
 
 def test_train_steps_match_tf_adam(case):
-    """Two full train steps (backbone included): parameters after TF-Adam with poly LR, L2 on DW and x2 on biases."""
+    """Four full train steps (backbone included; the last two replay the captured HIP graph): parameters after
+    TF-Adam with poly LR, L2 on DW and x2 on biases."""
     cfg = case["cfg"]
     m = _model(case, "f32")
+    m.use_graph = True
     hp = {k: v.clone() for k, v in case["hp"].items()}
     opt = O.TFAdam(hp)
-    for step in range(2):
+    for step in range(4):
         s, scal = m.train_step(case["words"], case["im"], case["tgt"], case["sl"])
         ref = O.train_step(hp, opt, step, case["feats"], case["words"], case["sl"], case["tgt"], cfg)
         assert s == step + 1
         assert abs(float(scal["loss_all"]) - ref["loss_all"]) <= 2e-4 * abs(ref["loss_all"])
         assert abs(scal["learning_rate"] - ref["lr"]) < 1e-12
+    assert m._graph is not None
     torch.cuda.synchronize()
     sd = m.state_dict()
     lr = cfg.start_lr
@@ -186,6 +189,29 @@ def test_train_steps_match_tf_adam(case):
         assert d <= 0.35 * lr, (n, d)
     moved = float((sd["text_objseg/fusion_c5/DW"] - case["hp"]["text_objseg/fusion_c5/DW"]).abs().max())
     assert moved > 0.5 * lr
+
+
+def test_graph_replay_equals_eager(case):
+    """train_step through the captured HIP graph (new feeds copied into the static buffers every step) gives the
+    same parameters and scalars as eager launches."""
+    ms = []
+    for graph in (True, False):
+        m = _model(case, "f32")
+        m.use_graph = graph
+        if graph:
+            m.capture(case["words"], case["im"], case["tgt"], case["sl"])
+            assert m._graph is not None and m.store.step == 0
+        scal = None
+        for step in range(3):
+            w = case["words"] if step != 1 else torch.roll(torch.as_tensor(case["words"]), 1, 0)   # feeds change between replays
+            _, scal = m.train_step(w, case["im"], case["tgt"], case["sl"])
+        ms.append((m.state_dict(), {k: float(v) for k, v in scal.items()}))
+    (sa, ca), (sb, cb) = ms
+    for k in ca:
+        assert abs(ca[k] - cb[k]) <= 1e-5 * max(1.0, abs(cb[k])), k
+    lr = case["cfg"].start_lr
+    for n in sa:
+        assert float((sa[n] - sb[n]).abs().max()) <= 0.05 * lr, n
 
 
 def test_facade_contract_and_errors(case):
