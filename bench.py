@@ -41,7 +41,7 @@ def synth_batch(B, T, H, W, vocab, seed):
         words[b, :seq_len[b]] = rng.integers(4, vocab, size=(seq_len[b],))
     target = np.zeros((B, H, W, 1), dtype=np.float32)
     for b in range(B):
-        hh, ww = rng.integers(40, 201, size=2)
+        hh, ww = rng.integers(40, 201, size=2) if min(H, W) >= 320 else rng.integers(H // 8, H // 2 + 1, size=2)
         y0, x0 = rng.integers(0, H - hh + 1), rng.integers(0, W - ww + 1)
         target[b, y0:y0 + hh, x0:x0 + ww, 0] = 1.0
     return words, np.ascontiguousarray(im), seq_len, target

@@ -96,6 +96,7 @@ _P, _I, _F, _L = C.c_void_p, C.c_int, C.c_float, C.c_int64
 SIGNATURES = {
     "cmpc_gemm_nt": [C.POINTER(GemmNtArgs), _P],
     "cmpc_gemm_tn": [C.POINTER(GemmTnArgs), _P],
+    "cmpc_gemm_tn_grouped": [C.POINTER(GemmTnArgs), C.c_int, _P],
     "cmpc_conv_nhwc": [C.POINTER(ConvArgs), _P],
     "cmpc_cast": [_I, _P, _I, _P, _L, _P],
     "cmpc_act_bwd": [_I, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _I, _I, _P],

@@ -11,6 +11,7 @@
 // fp32 - the parity mode).  Both use the same byte-level LDS image: a lane's 16-byte chunk is
 // one bf16 fragment (8 k-values) or four f32 k-values consumed by four MFMA steps.
 #include "cmpc_common.h"
+#include <algorithm>
 #include "../../include/cmpc.h"
 #include <stdlib.h>
 
@@ -228,7 +229,8 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const cmpc_gemm_nt_args p)
 #ifdef CMPC_GEMM_TRACE
 // per-workgroup phase timestamps (100 MHz wall clock) for scripts/gemm_trace.py; not part of the product build
 __device__ long long g_gemm_trace[8 * 4096];
-#define TRACE_MARK(i) do { if (threadIdx.x == 0 && blockIdx.x < 4096) g_gemm_trace[blockIdx.x * 8 + (i)] = wall_clock64(); } while (0)
+#define TRACE_MARK(i) do { const int tb_ = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z); \
+                           if (threadIdx.x == 0 && tb_ < 4096) g_gemm_trace[tb_ * 8 + (i)] = wall_clock64(); } while (0)
 extern "C" int cmpc_debug_gemm_trace(long long* dst, int n) {
     return hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_gemm_trace), sizeof(long long) * n) == hipSuccess ? 0 : -2;
 }
@@ -805,7 +807,7 @@ __device__ __forceinline__ int tn_swz(int r, int byte, int rowb) {
 }
 
 template <typename T>
-__global__ __launch_bounds__(256) void gemm_tn_kernel(const cmpc_gemm_tn_args p) {
+__device__ __forceinline__ void gemm_tn_body(const cmpc_gemm_tn_args& p, const int bx, const int by, const int bz) {
     constexpr int BR = TnCfg<T>::BR;
     constexpr int ROWB = 128 * (int)sizeof(T);     // bytes per LDS row
     constexpr int EPC = 16 / (int)sizeof(T);
@@ -814,18 +816,19 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const cmpc_gemm_tn_args p)
     constexpr int TILE = BR * ROWB;
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    TRACE_MARK(0);
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wm = wid >> 1, wn = wid & 1;
     const int ntn = (p.Nv + 127) / 128;
-    const int k0 = (blockIdx.x / ntn) * 128, n0 = (blockIdx.x % ntn) * 128;
-    const int b1 = blockIdx.z % p.nb, b2 = blockIdx.z / p.nb;
+    const int k0 = (bx / ntn) * 128, n0 = (bx % ntn) * 128;
+    const int b1 = bz % p.nb, b2 = bz / p.nb;
     const T* A = reinterpret_cast<const T*>(p.A) + p.a_off[b1] + (long)b2 * p.a_bs;
     const T* D = reinterpret_cast<const T*>(p.D) + p.d_off[b1] + (long)b2 * p.d_bs;
     float* out = p.out + p.o_off[b1] + (long)b2 * p.o_bs;
 
     // rows of this split
     const int per = (p.R + p.rsplit - 1) / p.rsplit;
-    const int rbeg = blockIdx.y * per;
+    const int rbeg = by * per;
     const int rend = min(p.R, rbeg + per);
     const int nt = (rend > rbeg) ? (rend - rbeg + BR - 1) / BR : 0;
 
@@ -860,6 +863,7 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const cmpc_gemm_tn_args p)
 
     if (nt > 0) { gload(0); lstore(0); }
     __syncthreads();
+    TRACE_MARK(1);
     const int fr = lane & 15, fq = lane >> 4;
     for (int t = 0; t < nt; ++t) {
         const int cur = t & 1;
@@ -924,6 +928,8 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const cmpc_gemm_tn_args p)
         __syncthreads();
     }
     if (nt == 0) return;
+    TRACE_MARK(2);
+    TRACE_MARK(3);
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -934,8 +940,41 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const cmpc_gemm_tn_args p)
                 const int n = n0 + wn * 64 + j * 16 + fr;
                 if (k < p.Kv && n < p.Nv) atomicAdd(out + (long)k * p.ldo + n, acc[i][j][r] * p.alpha);
             }
+    TRACE_MARK(4);
+#ifdef CMPC_GEMM_TRACE
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    TRACE_MARK(5);
+#endif
 }
 
+
+template <typename T>
+__global__ __launch_bounds__(256) void gemm_tn_kernel(const cmpc_gemm_tn_args p) {
+    gemm_tn_body<T>(p, blockIdx.x, blockIdx.y, blockIdx.z);
+}
+
+// Grouped form: up to TN_GROUP independent products in ONE launch (the deferred weight gradients of a
+// backward pass).  Each product keeps its own tiling; workgroup w serves product g with
+// wg_begin[g] <= w < wg_begin[g+1].  With many products in flight no product needs a deep split of its
+// reduction, so the fp32-atomic epilogue (8-20 us of a 37-57 us stand-alone launch) shrinks to one pass.
+#define TN_GROUP 10
+struct TnGroupArgs {
+    int n;
+    int wg_begin[TN_GROUP + 1];
+    int tiles[TN_GROUP];
+    cmpc_gemm_tn_args a[TN_GROUP];
+};
+template <typename T>
+__global__ __launch_bounds__(256) void gemm_tn_grouped_kernel(const TnGroupArgs ga) {
+    int g = 0;
+#pragma unroll
+    for (int i = 1; i < TN_GROUP; ++i) if (i < ga.n && (int)blockIdx.x >= ga.wg_begin[i]) g = i;
+    g = __builtin_amdgcn_readfirstlane(g);
+    const int local = blockIdx.x - ga.wg_begin[g];
+    const int tiles = ga.tiles[g], rs = ga.a[g].rsplit;
+    const int bx = local % tiles, rest = local / tiles;
+    gemm_tn_body<T>(ga.a[g], bx, rest % rs, rest / rs);
+}
 
 // ------------------------------------------------------------------------------------------
 // gemm_tn v2 (bf16): same product as gemm_tn_kernel, but the [64 rows][128 cols] operand slabs are
@@ -1208,6 +1247,68 @@ extern "C" int cmpc_conv_nhwc(const cmpc_conv_args* a, void* stream) {
     if (a->dtype == DT_F32) return launch_conv<float>(a, (hipStream_t)stream);
     if (a->dtype == DT_BF16) return launch_conv<bf16_t>(a, (hipStream_t)stream);
     cmpc_set_error("conv_nhwc: bad dtype"); return CMPC_EINVAL;
+}
+
+
+static int tn_validate(const cmpc_gemm_tn_args* a) {
+    if (!a || a->R < 0 || a->Kv <= 0 || a->Nv <= 0 || a->nb < 1 || a->nb > 8 || a->nb2 < 1) {
+        cmpc_set_error("gemm_tn: bad args"); return CMPC_EINVAL;
+    }
+    if (a->R == 0) return CMPC_OK;
+    if (!a->A || !a->D || !a->out) { cmpc_set_error("gemm_tn: null operand"); return CMPC_EINVAL; }
+    const int esz = a->dtype == DT_F32 ? 4 : 2;
+    if ((a->lda * esz) % 16 || (a->ldd * esz) % 16 || (a->Ka * esz) % 16 || (a->Nd * esz) % 16) {
+        cmpc_set_error("gemm_tn: rows must be 16-B aligned"); return CMPC_EINVAL;
+    }
+    for (int i = 0; i < a->nb; ++i)
+        if ((a->a_off[i] * esz) % 16 || (a->d_off[i] * esz) % 16) { cmpc_set_error("gemm_tn: offsets must be 16-B aligned"); return CMPC_EINVAL; }
+    if ((a->a_bs * esz) % 16 || (a->d_bs * esz) % 16) { cmpc_set_error("gemm_tn: batch strides must be 16-B aligned"); return CMPC_EINVAL; }
+    if (a->dtype != DT_F32 && a->dtype != DT_BF16) { cmpc_set_error("gemm_tn: bad dtype"); return CMPC_EINVAL; }
+    return CMPC_OK;
+}
+
+extern "C" int cmpc_gemm_tn_grouped(const cmpc_gemm_tn_args* args, int n, void* stream) {
+    if (n < 0 || (n > 0 && !args)) { cmpc_set_error("gemm_tn_grouped: bad args"); return CMPC_EINVAL; }
+    hipStream_t st = (hipStream_t)stream;
+    // products sorted by the work of one workgroup (long ones first: the tail of the launch is made of short ones)
+    int order[2][1024], cnt[2] = {0, 0};
+    for (int i = 0; i < n; ++i) {
+        const int rc = tn_validate(&args[i]);
+        if (rc != CMPC_OK) return rc;
+        if (args[i].R == 0) continue;
+        const int d = args[i].dtype == DT_F32 ? 0 : 1;
+        if (cnt[d] >= 1024) { cmpc_set_error("gemm_tn_grouped: more than 1024 products"); return CMPC_EINVAL; }
+        order[d][cnt[d]++] = i;
+    }
+    for (int d = 0; d < 2; ++d) {
+        std::stable_sort(order[d], order[d] + cnt[d], [&](int x, int y) { return args[x].R > args[y].R; });
+        const int br = d == 0 ? TnCfg<float>::BR : TnCfg<bf16_t>::BR;
+        for (int c0 = 0; c0 < cnt[d]; c0 += TN_GROUP) {
+            TnGroupArgs ga;
+            ga.n = std::min(TN_GROUP, cnt[d] - c0);
+            long tot = 0;
+            for (int i = 0; i < ga.n; ++i) {
+                ga.a[i] = args[order[d][c0 + i]];
+                ga.tiles[i] = ((ga.a[i].Kv + 127) / 128) * ((ga.a[i].Nv + 127) / 128);
+                tot += (long)ga.tiles[i] * ga.a[i].nb * ga.a[i].nb2;
+            }
+            // split reductions only as far as needed to put ~1024 workgroups (2 per CU, 2 rounds) in the launch
+            const int want = (int)((1024 + tot - 1) / tot);
+            int wg = 0;
+            for (int i = 0; i < ga.n; ++i) {
+                const int maxs = std::max(1, ga.a[i].R / (4 * br));
+                ga.a[i].rsplit = std::max(1, std::min(want, maxs));
+                ga.wg_begin[i] = wg;
+                wg += ga.tiles[i] * ga.a[i].rsplit * ga.a[i].nb * ga.a[i].nb2;
+            }
+            for (int i = ga.n; i <= TN_GROUP; ++i) ga.wg_begin[i] = wg;
+            if (d == 0) hipLaunchKernelGGL((gemm_tn_grouped_kernel<float>), dim3(wg), dim3(256), 2 * 2 * TnCfg<float>::BR * 128 * 4, st, ga);
+            else hipLaunchKernelGGL((gemm_tn_grouped_kernel<bf16_t>), dim3(wg), dim3(256), 2 * 2 * TnCfg<bf16_t>::BR * 128 * 2, st, ga);
+            const int rc = cmpc_check_launch("gemm_tn_grouped");
+            if (rc != CMPC_OK) return rc;
+        }
+    }
+    return CMPC_OK;
 }
 
 extern "C" int cmpc_gemm_tn(const cmpc_gemm_tn_args* a, void* stream) {

@@ -284,6 +284,7 @@ class LSTM_model(object):
                 main.wait_stream(st)
             if self.cx.wg is not None:
                 main.wait_stream(self.cx.wg)
+        self.cx.flush_wgrad()
         return o
 
     _SCALARS = ("loss_all", "loss_c3", "loss_c4", "loss_c5", "loss_last", "mIoU")

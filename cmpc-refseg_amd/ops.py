@@ -11,6 +11,7 @@ Reference citations are file:line under /root/reference.
 from __future__ import annotations
 
 import ctypes
+import os
 import math
 from typing import List, Optional, Sequence, Tuple
 
@@ -100,8 +101,11 @@ def on_wgrad_stream(cx, tensors, fn):
 def gemm_tn(dt, A, lda, Ka, D, ldd, Nd, out, ldo, R, Kv, Nv, offs=((0, 0, 0),), nb2=1, a_bs=0, d_bs=0, o_bs=0,
             alpha=1.0, rsplit=None, wg=None):
     """out[k, n] += alpha * sum_r A[r, k] D[r, n]; offs: (a_off, d_off, o_off) per inner batch (elements).
-    wg=cx: weight gradient -> launched on cx's weight-gradient stream."""
-    if wg is not None and getattr(wg, "wg", None) is not None:
+    wg=cx: weight gradient -> deferred to cx.flush_wgrad() (one grouped launch at the end of the backward
+    pass), or launched on cx's weight-gradient stream when that is enabled."""
+    if wg is not None and getattr(wg, "defer", False):
+        wg = wg.deferred
+    elif wg is not None and getattr(wg, "wg", None) is not None:
         return on_wgrad_stream(wg, (A, D), lambda: gemm_tn(dt, A, lda, Ka, D, ldd, Nd, out, ldo, R, Kv, Nv, offs, nb2, a_bs, d_bs,
                                                              o_bs, alpha, rsplit))
     a = GemmTnArgs()
@@ -120,6 +124,9 @@ def gemm_tn(dt, A, lda, Ka, D, ldd, Nd, out, ldo, R, Kv, Nv, offs=((0, 0, 0),), 
         rsplit = max(1, min((R + 4 * br - 1) // (4 * br), (512 + tiles - 1) // tiles))
     a.rsplit, a.alpha = rsplit, alpha
     a.zeros = _zero_page(A.device if torch.is_tensor(A) else torch.device('cuda', torch.cuda.current_device()))
+    if isinstance(wg, list):
+        wg.append((a, A, D))         # operands stay referenced (hence allocated and unmodified) until the flush
+        return
     _lib.call("cmpc_gemm_tn", ctypes.byref(a), _st())
 
 
@@ -172,6 +179,25 @@ class Ctx:
         self.spatial = sp.repeat(B, 1).to(self.dev).to(tdt(vis_dt)).contiguous()
         self.anchor = torch.zeros((), device=self.dev, requires_grad=True)
         self.wg = None              # weight-gradient stream (set by LSTM_model.set_streams)
+        # weight-gradient products have no consumer before the optimizer: they are collected during the
+        # backward pass and issued as a few grouped launches by flush_wgrad() (CMPC_WGRAD_DEFER=0: in place)
+        self.defer = os.environ.get("CMPC_WGRAD_DEFER", "1") != "0"
+        self.deferred = []
+
+    def flush_wgrad(self):
+        """Launch the deferred weight-gradient products on the current stream (which must be ordered after
+        every stream that produced their operands)."""
+        items, self.deferred = self.deferred, []
+        if not items:
+            return
+        arr = (GemmTnArgs * len(items))()
+        for i, (a, _A, _D) in enumerate(items):
+            ctypes.memmove(ctypes.byref(arr[i]), ctypes.byref(a), ctypes.sizeof(GemmTnArgs))
+        _lib.call("cmpc_gemm_tn_grouped", arr, len(items), _st())
+        for _a, A, D in items:        # the caching allocator must not recycle the operands before the launch has run
+            for t in (A, D):
+                if torch.is_tensor(t):
+                    t.record_stream(torch.cuda.current_stream(t.device))
 
     def op(self, key):
         return self.ps.ops[key]

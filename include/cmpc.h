@@ -63,6 +63,10 @@ typedef struct {
     const void* zeros;                  /* optional: >= 256 B of device zeros (enables the LDS-DMA pipeline for bf16) */
 } cmpc_gemm_tn_args;
 int cmpc_gemm_tn(const cmpc_gemm_tn_args* a, void* stream);
+/* n independent products in as few launches as possible (weight gradients deferred to the end of the backward
+ * pass: tf.gradients' dW ops of CMPC_model.py:447-456 have no consumer before the optimizer).  `rsplit` of
+ * the entries is ignored: the split of each reduction is chosen for the group as a whole. */
+int cmpc_gemm_tn_grouped(const cmpc_gemm_tn_args* args, int n, void* stream);
 
 /* ---- backbone convolutions as implicit GEMM (deeplab_resnet/model.py:19-401; network.py:105-188 conv /
  *      atrous_conv 'SAME', :260-270 frozen batch_norm folded into Wt and bias, :194-201,233-235 relu / add).

@@ -8,10 +8,16 @@ from importlib import import_module
 U.pkg()
 ops = import_module("cmpc-refseg_amd.ops"); L = import_module("cmpc-refseg_amd._lib")
 M, N, K = (int(x) for x in sys.argv[1:4])
+kind = sys.argv[4] if len(sys.argv) > 4 else "nt"
 dev = torch.device("cuda:0")
-A = torch.randn(M, K, device=dev).bfloat16(); Bt = torch.randn(N, K, device=dev).bfloat16(); Cc = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
-for _ in range(5):
-    ops.gemm_nt(1, [(A, K, Bt, K, K)], Cc, N, M, N)
+if kind == "nt":
+    A = torch.randn(M, K, device=dev).bfloat16(); Bt = torch.randn(N, K, device=dev).bfloat16(); Cc = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
+    for _ in range(5):
+        ops.gemm_nt(1, [(A, K, Bt, K, K)], Cc, N, M, N)
+else:           # tn: M = R (rows reduced over), out [K, N]
+    A = torch.randn(M, K, device=dev).bfloat16(); D = torch.randn(M, N, device=dev).bfloat16(); out = torch.zeros(K, N, device=dev)
+    for _ in range(5):
+        ops.gemm_tn(1, A, K, K, D, N, N, out, N, M, K, N)
 torch.cuda.synchronize()
 lib = L.load()
 n = 8 * 4096
@@ -23,7 +29,7 @@ nwg = int((t[:, 0] != 0).sum())
 t = t[:nwg]
 t0 = t[:, 0].min()
 us = (t[:, :6] - t0) / 100.0
-print(f"M={M} N={N} K={K}: {nwg} workgroups; kernel span {us[:,5].max():.2f} us")
+print(f"{kind} M={M} N={N} K={K}: {nwg} workgroups; kernel span {us[:,5].max():.2f} us")
 names = ["start", "first tile landed", "main loop done", "slab written", "stores issued", "stores done"]
 for i, nm in enumerate(names):
     print(f"  {nm:18s} min {us[:,i].min():7.2f}  median {np.median(us[:,i]):7.2f}  max {us[:,i].max():7.2f}")

@@ -4,8 +4,9 @@ import torch, importlib
 from bench import synth_batch
 pkg = importlib.import_module("cmpc-refseg_amd")
 dev = torch.device("cuda:0")
-m = pkg.LSTM_model(batch_size=8, mode="train", dtype="bf16")
-w, im, sl, tg = synth_batch(8, 20, 320, 320, m.cfg.vocab_size, 0)
+HW = int(sys.argv[1]) if len(sys.argv) > 1 else 320      # 64: GPU work is negligible, the step time is the host enqueue time
+m = pkg.LSTM_model(batch_size=8, mode="train", dtype="bf16", H=HW, W=HW, vf_h=HW // 8, vf_w=HW // 8)
+w, im, sl, tg = synth_batch(8, 20, HW, HW, m.cfg.vocab_size, 0)
 w, im, sl, tg = [torch.from_numpy(x).to(dev) for x in (w, im, sl, tg)]
 for _ in range(5): m.train_step(w, im, tg, sl)
 torch.cuda.synchronize()
