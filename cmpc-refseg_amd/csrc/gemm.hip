@@ -373,12 +373,11 @@ __global__ __launch_bounds__(512) void gemm_nt_v2_kernel(const cmpc_gemm_nt_args
 //    of the current one (phase trace of v2: 1.05 us per k-tile against 0.43 us of MFMA time, both
 //    waves of a SIMD exposing their LDS-read latency twice per k-tile in lockstep);
 //  * three k-tiles of loads in flight (the barrier that publishes tile t+1 also retires tile t);
-//  * MFMA operand roles swapped (weights as "A"): a lane then holds 4 CONSECUTIVE output columns of one
-//    row, so the epilogue stores straight from registers (8-B bf16 / 16-B fp32 per lane; the 4 tiles of a
-//    wave complete each 128-B line) -- no fp32 slab round trip through LDS (5 us per tile in v2).
+//  * the last k-tile peeled out of the loop (see the loop);
+//  * v2's epilogue (a register-direct epilogue with 8-byte stores was measured slower: 7.3 vs 5.5 us per tile).
 // ------------------------------------------------------------------------------------------
 template <typename T, int BM>
-__global__ __launch_bounds__(512) void gemm_nt_v4_kernel(const cmpc_gemm_nt_args p) {
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void gemm_nt_v4_kernel(const cmpc_gemm_nt_args p) {
     constexpr int BN = 128;
     constexpr int EPC = 16 / (int)sizeof(T);
     constexpr int BK = BKB / (int)sizeof(T);
@@ -411,27 +410,49 @@ __global__ __launch_bounds__(512) void gemm_nt_v4_kernel(const cmpc_gemm_nt_args
 
     const int r8 = lane >> 3, slot = lane & 7;
     const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
-    auto issue = [&](int tile, int buf) {
-        int s = 0, t = tile;
-        if (t >= ntile[0]) { t -= ntile[0]; s = 1; if (t >= ntile[1]) { t -= ntile[1]; s = 2; } }
-        const T* Ap = reinterpret_cast<const T*>(p.A[s]) + bz * p.sA[s];
-        const T* Bp = reinterpret_cast<const T*>(p.Bt[s]) + bz * p.sB[s];
-        const long lda = p.lda[s], ldb = p.ldb[s];
-        const int k0 = t * BK;
-        const uint32_t base = lds0 + buf * STAGE;
+    // Issue cursor: per-lane row pointers of the CURRENT K-segment live in registers (recomputed only when the
+    // segment changes), so that an issue is one 64-bit add per piece -- no kernarg (SMEM) loads and their
+    // lgkmcnt(0) in the k-loop.
+    const T* pa[APW];
+    const T* pb[BPW];
+    int iseg = 0, itile = 0, seg_left = ntile[0];
+    auto load_seg = [&](const int sg) {      // sg is a literal at every call site: kernarg reads stay scalar loads
+        const T* Ap = reinterpret_cast<const T*>(p.A[sg]) + bz * p.sA[sg];
+        const T* Bp = reinterpret_cast<const T*>(p.Bt[sg]) + bz * p.sB[sg];
+        const long lda = p.lda[sg], ldb = p.ldb[sg];
 #pragma unroll
         for (int j = 0; j < APW; ++j) {
-            const int blk = wid * APW + j, row = blk * 8 + r8;
-            const int c = slot ^ ((row >> 1) & 7);
-            const int gm = min(m0 + row, p.M - 1);
-            glds16(Ap + gm * lda + k0 + c * EPC, __builtin_amdgcn_readfirstlane(base + blk * 1024));
+            const int row = (wid * APW + j) * 8 + r8;
+            const int gm = min(m0 + row, p.M - 1);           // rows past M: any valid address (never stored)
+            pa[j] = Ap + gm * lda + (slot ^ ((row >> 1) & 7)) * EPC;
         }
 #pragma unroll
         for (int j = 0; j < BPW; ++j) {
-            const int blk = wid * BPW + j, row = blk * 8 + r8;
-            const int c = slot ^ ((row >> 1) & 7);
+            const int row = (wid * BPW + j) * 8 + r8;
             const int gn = min(n0 + row, p.N - 1);
-            glds16(Bp + gn * ldb + k0 + c * EPC, __builtin_amdgcn_readfirstlane(base + BM * BKB + blk * 1024));
+            pb[j] = Bp + gn * ldb + (slot ^ ((row >> 1) & 7)) * EPC;
+        }
+    };
+    load_seg(0);
+    auto issue_next = [&](int buf) {
+        const int k0 = itile * BK;
+        const uint32_t base = lds0 + buf * STAGE;
+#ifndef V4_NO_LOADS          // (study builds: -DV4_NO_LOADS / -DV4_NO_MFMA isolate the two halves of the loop)
+#pragma unroll
+        for (int j = 0; j < APW; ++j)
+            glds16(pa[j] + k0, __builtin_amdgcn_readfirstlane(base + (wid * APW + j) * 1024));
+#pragma unroll
+        for (int j = 0; j < BPW; ++j)
+            glds16(pb[j] + k0, __builtin_amdgcn_readfirstlane(base + BM * BKB + (wid * BPW + j) * 1024));
+#else
+        (void)k0; (void)base;
+#endif
+        ++itile;
+        if (--seg_left == 0) {
+            itile = 0;
+            ++iseg;
+            if (iseg == 1 && p.nseg > 1) { seg_left = ntile[1]; load_seg(1); }
+            else if (iseg == 2 && p.nseg > 2) { seg_left = ntile[2]; load_seg(2); }
         }
     };
     const int fr = lane & 15, fq = lane >> 4;
@@ -449,82 +470,198 @@ __global__ __launch_bounds__(512) void gemm_nt_v4_kernel(const cmpc_gemm_nt_args
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
-            for (int j = 0; j < TN; ++j) acc[i][j] = Mma<T>::run(b[j], a[i], acc[i][j]);     // D[n][m]: lane = (m = fr, n = 4 fq + r)
+#ifndef V4_NO_MFMA
+            for (int j = 0; j < TN; ++j) acc[i][j] = Mma<T>::run(a[i], b[j], acc[i][j]);
+#else
+            for (int j = 0; j < TN; ++j) acc[i][j][0] += __uint_as_float(a[i].x ^ b[j].x);
+#endif
+    };
+
+    if (ntot > 0) issue_next(0);
+    if (ntot > 1) issue_next(1);
+    if (ntot > 2) issue_next(2);
+    if (ntot > 2) wait_vmcnt<2 * LPT>(); else if (ntot > 1) wait_vmcnt<LPT>(); else wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();
+    TRACE_MARK(1);
+#ifdef CMPC_GEMM_TRACE
+    if (threadIdx.x == 0 && blockIdx.x < 4096) g_gemm_trace[blockIdx.x * 8 + 6] = clock64();
+#endif
+    uint4 a0[TM], b0[TN], a1[TM], b1[TN];
+    if (ntot > 0) read_frags(0, 0, a0, b0);
+    int cur = 0;
+    // The last k-tile is peeled: a conditional skip inside the loop body makes hipcc merge the two paths'
+    // LDS counters and wait for the NEXT half's reads in front of the first MFMA of every half.
+    for (int kt = 0; kt + 1 < ntot; ++kt) {
+        read_frags(cur, 1, a1, b1);
+        __builtin_amdgcn_sched_barrier(0);       // keep the reads of the next half IN FRONT of this half's MFMAs
+        mma_all(a0, b0);
+        __builtin_amdgcn_sched_barrier(0);
+        const int nxt = (cur == 2) ? 0 : cur + 1;
+        // every read of tile kt has landed in registers before the barrier lets another wave's DMA reuse its buffer
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (kt + 2 < ntot) wait_vmcnt<LPT>(); else wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();
+        if (kt + 3 < ntot) issue_next(cur);
+        read_frags(nxt, 0, a0, b0);
+        __builtin_amdgcn_sched_barrier(0);
+        mma_all(a1, b1);
+        __builtin_amdgcn_sched_barrier(0);
+        cur = nxt;
+    }
+    if (ntot > 0) {
+        read_frags(cur, 1, a1, b1);
+        mma_all(a0, b0);
+        mma_all(a1, b1);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    TRACE_MARK(2);
+#ifdef CMPC_GEMM_TRACE
+    if (threadIdx.x == 0 && blockIdx.x < 4096) g_gemm_trace[blockIdx.x * 8 + 7] = clock64();
+#endif
+
+    constexpr int WR = TM * 16, WC = TN * 16;
+    float* slab = reinterpret_cast<float*>(smem) + wid * (WR * WC);
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = i * 16 + fq * 4 + r, col = j * 16 + fr;
+                slab[row * WC + (col ^ (((row >> 2) & 3) << 4))] = acc[i][j][r];
+            }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+    TRACE_MARK(3);
+    gemm_nt_epilogue<T, WR, WC>(p, slab, lane, m0 + wm * WR, n0 + wn * WC, bz);
+    TRACE_MARK(4);
+#ifdef CMPC_GEMM_TRACE
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    TRACE_MARK(5);
+#endif
+}
+
+// ------------------------------------------------------------------------------------------
+// gemm_nt v5: 256 x 256 tile.  The phase trace of v2/v4 shows the main loop bound by what a CU can take in
+// (about 50 GB/s of LDS-DMA per CU, 48 KB per 64-deep k-tile of a 256 x 128 tile), not by MFMA or LDS: a
+// 256 x 256 tile needs 1.5x fewer operand bytes per flop.  K-step 32 (64-byte LDS rows) so that FOUR stages
+// of 32 KiB fit (three k-tiles of loads in flight); 8 waves as 2 (M) x 4 (N), 128 x 64 per wave = 32 MFMA
+// 16x16x32 per k-tile and wave from 12 ds_read_b128.  LDS image: row r at 64 r bytes, 16-B chunk c stored at
+// chunk c ^ g((r >> 2) & 3), g = {0,3,2,1}: each 16-lane group of a ds_read_b128 (lane groups of
+// MI355X_MICROARCH.md, LDS table) then covers all 64 banks once.  The XOR is applied to the per-lane SOURCE
+// chunk of the LDS-DMA (linear destination).  Epilogue: the fp32 slab of v2 in two halves of 64 rows per wave.
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ int v5_g(int row) { return (4 - ((row >> 2) & 3)) & 3; }
+__device__ __forceinline__ int v5_lds_off(int row, int c) { return row * 64 + ((c ^ v5_g(row)) << 4); }
+
+template <typename T>
+__global__ __launch_bounds__(512) void gemm_nt_v5_kernel(const cmpc_gemm_nt_args p) {
+    constexpr int BM = 256, BN = 256, ROWB = 64;
+    constexpr int EPC = 16 / (int)sizeof(T);
+    constexpr int BK = ROWB / (int)sizeof(T);              // 32 bf16
+    constexpr int WAVES_N = 4;
+    constexpr int TM = 8, TN = 4;                          // 128 x 64 per wave
+    constexpr int STAGE = (BM + BN) * ROWB;                // 32 KiB
+    constexpr int NST = 4;
+    constexpr int APW = BM / 16 / 8, BPW = BN / 16 / 8;    // 1-KiB pieces (16 rows x 64 B) per wave and stage: 2 + 2
+    constexpr int LPT = APW + BPW;
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    TRACE_MARK(0);
+    const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wid / WAVES_N, wn = wid % WAVES_N;
+    const int gx = (p.N + BN - 1) / BN, nwg = gridDim.x;
+    const int xq = nwg >> 3, xr = nwg & 7, xcd = blockIdx.x & 7, xi = blockIdx.x >> 3;
+    const int tix = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + xi;
+    const int m0 = (tix / gx) * BM, n0 = (tix % gx) * BN;
+    const long bz = blockIdx.z;
+
+    int ntile[3], ntot = 0;
+#pragma unroll
+    for (int s = 0; s < 3; ++s) { ntile[s] = (s < p.nseg) ? p.K[s] / BK : 0; ntot += ntile[s]; }
+
+    f4 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = f4{0.f, 0.f, 0.f, 0.f};
+
+    const int r16 = lane >> 2, slot = lane & 3;
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+    auto issue = [&](int tile, int buf) {
+        int s = 0, t = tile;
+        if (t >= ntile[0]) { t -= ntile[0]; s = 1; if (t >= ntile[1]) { t -= ntile[1]; s = 2; } }
+        const T* Ap = reinterpret_cast<const T*>(p.A[s]) + bz * p.sA[s];
+        const T* Bp = reinterpret_cast<const T*>(p.Bt[s]) + bz * p.sB[s];
+        const long lda = p.lda[s], ldb = p.ldb[s];
+        const int k0 = t * BK;
+        const uint32_t base = lds0 + buf * STAGE;
+#pragma unroll
+        for (int j = 0; j < APW; ++j) {
+            const int blk = wid * APW + j, row = blk * 16 + r16;
+            const int c = slot ^ v5_g(row);
+            const int gm = min(m0 + row, p.M - 1);           // rows past M: any valid address (never stored)
+            glds16(Ap + gm * lda + k0 + c * EPC, __builtin_amdgcn_readfirstlane(base + blk * 1024));
+        }
+#pragma unroll
+        for (int j = 0; j < BPW; ++j) {
+            const int blk = wid * BPW + j, row = blk * 16 + r16;
+            const int c = slot ^ v5_g(row);
+            const int gn = min(n0 + row, p.N - 1);
+            glds16(Bp + gn * ldb + k0 + c * EPC, __builtin_amdgcn_readfirstlane(base + BM * ROWB + blk * 1024));
+        }
     };
 
     if (ntot > 0) issue(0, 0);
     if (ntot > 1) issue(1, 1);
     if (ntot > 2) issue(2, 2);
-    if (ntot > 2) wait_vmcnt<2 * LPT>(); else if (ntot > 1) wait_vmcnt<LPT>(); else wait_vmcnt<0>();
-    __builtin_amdgcn_s_barrier();
-    TRACE_MARK(1);
-    uint4 a0[TM], b0[TN], a1[TM], b1[TN];
-    if (ntot > 0) read_frags(0, 0, a0, b0);
+    const int fr = lane & 15, fq = lane >> 4;
     int cur = 0;
     for (int kt = 0; kt < ntot; ++kt) {
-        read_frags(cur, 1, a1, b1);
-        mma_all(a0, b0);
-        const int nxt = (cur == 2) ? 0 : cur + 1;
-        if (kt + 1 < ntot) {
-            // every read of tile kt has landed in registers before the barrier lets another wave's DMA reuse its buffer
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            if (kt + 2 < ntot) wait_vmcnt<LPT>(); else wait_vmcnt<0>();
-            __builtin_amdgcn_s_barrier();
-            if (kt + 3 < ntot) issue(kt + 3, cur);
-            read_frags(nxt, 0, a0, b0);
-        }
-        mma_all(a1, b1);
-        cur = nxt;
+        // tile kt must have landed; the (up to) two younger ones stay in flight
+        if (kt + 2 < ntot) wait_vmcnt<2 * LPT>(); else if (kt + 1 < ntot) wait_vmcnt<LPT>(); else wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();
+        if (kt == 0) TRACE_MARK(1);
+        if (kt + 3 < ntot) issue(kt + 3, (cur + 3) & 3);      // the buffer of tile kt-1: every wave is past its reads
+        const char* sA = smem + cur * STAGE;
+        const char* sB = sA + BM * ROWB;
+        uint4 a[TM], b[TN];
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+            b[j] = *reinterpret_cast<const uint4*>(sB + v5_lds_off(wn * (TN * 16) + j * 16 + fr, fq));
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+            a[i] = *reinterpret_cast<const uint4*>(sA + v5_lds_off(wm * (TM * 16) + i * 16 + fr, fq));
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) acc[i][j] = Mma<T>::run(a[i], b[j], acc[i][j]);
+        cur = (cur + 1) & 3;
     }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
     TRACE_MARK(2);
-    TRACE_MARK(3);
 
-    // ---- epilogue straight from the accumulators ----
-    T* Ct = reinterpret_cast<T*>(p.C) + bz * p.sC;
-    float* Cf = reinterpret_cast<float*>(p.C) + bz * p.sC;
-    const int rps = p.rows_per_sample > 0 ? p.rows_per_sample : 1;
-    const int col0 = n0 + wn * (TN * 16) + 4 * fq, row0 = m0 + wm * (TM * 16) + fr;
-    float4 bj[TN];
+    constexpr int WR = 64, WC = TN * 16;                   // slab = half of the wave's rows
+    float* slab = reinterpret_cast<float*>(smem) + wid * (WR * WC);
 #pragma unroll
-    for (int j = 0; j < TN; ++j) {
-        const int gn = col0 + j * 16;
-        bj[j] = (p.bias && gn < p.N) ? *reinterpret_cast<const float4*>(p.bias + gn) : make_float4(0.f, 0.f, 0.f, 0.f);
-    }
+    for (int half = 0; half < 2; ++half) {
 #pragma unroll
-    for (int i = 0; i < TM; ++i) {
-        const int gm = row0 + i * 16;
-        if (gm >= p.M) continue;
-        const long bm = bz * (long)p.M + gm;
-        const float* sb = p.sbias ? p.sbias + (bm / rps) * (long)p.ld_sbias : nullptr;
-        const float* pb = p.pbias ? p.pbias + (bm % rps) * (long)p.ld_pbias : nullptr;
+        for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            const int gn = col0 + j * 16;
-            if (gn >= p.N) continue;
-            float4 bv = bj[j];
-            if (sb) { const float4 t = *reinterpret_cast<const float4*>(sb + gn); bv.x += t.x; bv.y += t.y; bv.z += t.z; bv.w += t.w; }
-            if (pb) { const float4 t = *reinterpret_cast<const float4*>(pb + gn); bv.x += t.x; bv.y += t.y; bv.z += t.z; bv.w += t.w; }
-            float v[4] = {acc[i][j][0] * p.alpha + bv.x, acc[i][j][1] * p.alpha + bv.y, acc[i][j][2] * p.alpha + bv.z, acc[i][j][3] * p.alpha + bv.w};
+            for (int j = 0; j < TN; ++j)
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = (gn + e < p.n_valid) ? act_apply(v[e], p.act) : 0.0f;     // pad columns stay exactly zero
-            const long off = (long)gm * p.ldc + gn;
-            if (p.c_f32 || sizeof(T) == 4) {
-                float* Cp = p.c_f32 ? Cf + off : reinterpret_cast<float*>(Ct) + off;
-                if (p.accumulate) { const float4 o = *reinterpret_cast<const float4*>(Cp); v[0] += o.x; v[1] += o.y; v[2] += o.z; v[3] += o.w; }
-                *reinterpret_cast<float4*>(Cp) = make_float4(v[0], v[1], v[2], v[3]);
-            } else {
-                bf16_t* Cb = reinterpret_cast<bf16_t*>(Ct) + off;
-                if (p.accumulate) {
-                    const uint2 o = *reinterpret_cast<const uint2*>(Cb);
-                    v[0] += __uint_as_float(o.x << 16); v[1] += __uint_as_float(o.x & 0xffff0000u);
-                    v[2] += __uint_as_float(o.y << 16); v[3] += __uint_as_float(o.y & 0xffff0000u);
+                for (int r = 0; r < 4; ++r) {
+                    const int row = i * 16 + fq * 4 + r, col = j * 16 + fr;
+                    slab[row * WC + (col ^ (((row >> 2) & 3) << 4))] = acc[half * 4 + i][j][r];
                 }
-                uint2 o;
-                o.x = (uint32_t)f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16);
-                o.y = (uint32_t)f2bf(v[2]) | ((uint32_t)f2bf(v[3]) << 16);
-                *reinterpret_cast<uint2*>(Cb) = o;
-            }
-        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+        if (half == 0) TRACE_MARK(3);
+        gemm_nt_epilogue<T, WR, WC>(p, slab, lane, m0 + wm * (TM * 16) + half * 64, n0 + wn * WC, bz);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // slab reads of this half are done before it is overwritten
+        __builtin_amdgcn_wave_barrier();
     }
     TRACE_MARK(4);
 #ifdef CMPC_GEMM_TRACE
@@ -1172,7 +1309,25 @@ extern "C" int cmpc_gemm_nt(const cmpc_gemm_nt_args* a, void* stream) {
         int ktot = 0;
         for (int s2 = 0; s2 < a->nseg; ++s2) ktot += a->K[s2];      // long K: producer/consumer waves (v3) win; short K: v2
         const bool big = (long)((a->M + 255) / 256) * gn * a->batch >= 384 || getenv("CMPC_GEMM_BM256");
-        const bool v4 = getenv("CMPC_GEMM_V4") != nullptr;   // register-epilogue variant: not faster end to end (8-B stores), kept for study
+        // v4 (fragment double buffering, hoisted row pointers) wins for short and medium K, v3 (producer /
+        // consumer waves) for long K (scripts/gemm_ksweep.py); v2 is kept as the plain reference structure.
+        const char* e4 = getenv("CMPC_GEMM_V4");
+        const bool v4 = e4 ? atoi(e4) != 0 : (!getenv("CMPC_GEMM_V2") && !getenv("CMPC_GEMM_V3") && (ktot < 2048 || (ktot < 4096 && a->N >= 1024)));
+        {
+            // 256 x 256 tiles when they still give the chip enough workgroups (>= 96) -- see the kernel's header
+            const long t256 = (long)((a->M + 255) / 256) * ((a->N + 255) / 256) * a->batch;
+            bool k32 = true;
+            for (int s2 = 0; s2 < a->nseg; ++s2) k32 = k32 && (a->K[s2] % 32 == 0);
+            const char* e5 = getenv("CMPC_GEMM_V5");
+            const bool use5 = e5 ? atoi(e5) != 0 : false;       // 256 x 256 study kernel: 0-9 % faster for N >= 1024, slower below
+            if (use5 && k32 && !v4) {
+                static bool attr5 = false;
+                if (!attr5) { (void)hipFuncSetAttribute((const void*)gemm_nt_v5_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 512 * 64); attr5 = true; }
+                dim3 grid((unsigned)(((a->M + 255) / 256) * ((a->N + 255) / 256)), 1, a->batch);
+                hipLaunchKernelGGL((gemm_nt_v5_kernel<bf16_t>), grid, dim3(512), 4 * 512 * 64, st, *a);
+                return cmpc_check_launch("gemm_nt(v5)");
+            }
+        }   // register-epilogue variant: not faster end to end (8-B stores), kept for study
         if (big) {
             dim3 grid(((a->M + 255) / 256) * gn, 1, a->batch);
             static bool attr256 = false;

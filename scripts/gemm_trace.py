@@ -36,6 +36,9 @@ for i, nm in enumerate(names):
 d = np.diff(us, axis=1)
 for i, nm in enumerate(["prologue", "main loop", "slab", "epilogue issue", "store drain"]):
     print(f"  d {nm:16s} median {np.median(d[:,i]):7.2f}  p90 {np.percentile(d[:,i],90):7.2f} max {d[:,i].max():7.2f}")
+if (t[:, 7] > t[:, 6]).all() and (t[:, 6] > 1 << 20).all():      # v4 trace build: shader-clock stamps around the main loop
+    ghz = (t[:, 7] - t[:, 6]) / ((t[:, 2] - t[:, 1]) * 10.0)
+    print(f"  shader clock during the main loop: median {np.median(ghz):.3f} GHz (min {ghz.min():.3f}, max {ghz.max():.3f})")
 order = np.argsort(us[:, 0])
 print("  start times of workgroups (sorted, every 32nd):", np.round(us[order, 0][::32], 2).tolist())
 late = us[:, 0] > np.median(us[:, 5]) * 0.5
