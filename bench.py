@@ -71,12 +71,14 @@ class GemmTimer:
             e0.record()
             orig(dt, segs, C, ldc, M, N, n_valid=n_valid, batch=batch, **kw)
             e1.record()
-            me.rec.append((e0, e1, 2.0 * M * batch * nv * k_alg))
+            # algorithmic bytes of the launch: A [M, K] and C [M, N] once per batch entry, the weight [N, K] once (bf16)
+            me.rec.append((e0, e1, 2.0 * M * batch * nv * k_alg, 2.0 * (M * batch * (k_alg + nv) + nv * k_alg)))
         ops.gemm_nt = timed
 
     def summary(self):
-        t = sum(e0.elapsed_time(e1) for e0, e1, _ in self.rec) * 1e-3
-        f = sum(fl for _, _, fl in self.rec)
+        t = sum(r[0].elapsed_time(r[1]) for r in self.rec) * 1e-3
+        f = sum(r[2] for r in self.rec)
+        self.alg_bytes = sum(r[3] for r in self.rec)
         return t, f, len(self.rec)
 
 
@@ -192,6 +194,15 @@ def main():
         timer.on = False
         model.set_streams(int(os.environ.get("CMPC_STREAMS", "3")))
         model.use_graph = os.environ.get("CMPC_GRAPH", "0") != "0"
+    # forward-only rate (SURVEY 8d reports both): sess.run([pred, up, sigm]) on the same batch, same K
+    for _ in range(2):
+        model.forward(words, im, seq_len)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        model.forward(words, im, seq_len)
+    barrier()
+    dt_fwd = time.perf_counter() - t0
     tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
     if world > 1:
         torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
@@ -208,14 +219,23 @@ def main():
             "config": {"workload": f"CMPC_model 320x320 B={B}/gpu L=20 {args.dtype}, ResNet-101 backbone (frozen), random-init weights",
                        "global_batch": B * world, "parallelism": f"dp{world}"},
             "final_loss": loss,
+            "forward_only": {"images_per_sec": B * world * args.steps / dt_fwd, "ms_per_step": 1e3 * dt_fwd / args.steps,
+                             "what": "model.forward: backbone + head forward -> pred, up, sigm (rank-0 clock)"},
         }
         if not args.no_kernel_timing and timer.rec:
             t, f, n = timer.summary()
             peak = 2500.0 if args.dtype == "bf16" else 157.3
+            # HBM-side bytes per launch from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE on this
+            # same command, scripts/pmc_traffic.py); bench.py cannot run the profiler on itself
+            traffic = None
+            tp = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_gemm_nt_traffic.json")
+            if args.dtype == "bf16" and B == 8 and os.path.exists(tp):
+                traffic = json.load(open(tp))["hbm_bytes_per_launch"]
             out["roofline"] = {"bound": "mfma", "achieved": f / t / 1e12, "peak": peak, "unit": "TFLOP/s",
-                               "frac": f / t / 1e12 / peak, "traffic": None,
-                               "kernel": "gemm_nt_v2_kernel<bf16> (all 1x1-conv / dX products of the head)",
-                               "measured": "event pairs around every launch over the same K steps re-run eagerly on one stream (the timed region replays a 4-stream HIP graph)",
+                               "frac": f / t / 1e12 / peak, "traffic": traffic,
+                               "algorithmic_bytes_per_launch": timer.alg_bytes / n,
+                               "kernel": "gemm_nt_v4/v3_kernel<bf16> (all 1x1-conv / dX products of the head)",
+                               "measured": "event pairs around every launch over the same K steps re-run on ONE stream (in the timed region 4 streams overlap, so a start->end interval there also contains other streams' kernels)",
                                "launches_per_step": n / args.steps, "ms_per_step_in_kernel": 1e3 * t / args.steps}
         if world == 1 and not args.no_cpu_baseline:
             log("cpu baseline (oracle on host cores)")
