@@ -105,6 +105,72 @@ def test_gemm_tn_against_torch(dt, tdt, tol):
                 d_bs=R * 2 * N, o_bs=K * 2 * N, alpha=2.0)
     assert U.rel_err(out.cpu(), (2.0 * torch.bmm(A.float().transpose(1, 2), D.float())).cpu()) < tol
 
+def test_gemm_tn_grouped_against_torch():
+    """cmpc_gemm_tn_grouped: a mixed bag of deferred products (bf16 and fp32, inner-batch offsets, an outer batch
+    accumulating into one output, two products adding into the SAME output, an empty reduction) in few launches."""
+    P, ops, dev = U.pkg(), _ops(), torch.device("cuda:0")
+    torch.manual_seed(3)
+
+    class Cx:                      # the two attributes gemm_tn(..., wg=cx) looks at
+        defer, deferred = True, []
+    cx, refs, outs = Cx(), [], []
+    for i, (dt, R, K, N) in enumerate(((1, 1500, 256, 128), (1, 4000, 128, 384), (0, 160, 72, 40), (1, 64, 8, 24), (0, 8, 128, 128),
+                                       (1, 700, 512, 512), (0, 0, 8, 8), (1, 2500, 64, 1024), (0, 300, 200, 16), (1, 1000, 128, 128),
+                                       (1, 999, 136, 264), (1, 130, 128, 64))):
+        tdt = torch.bfloat16 if dt == 1 else torch.float32
+        Kp, Np = (K + 7) // 8 * 8, (N + 7) // 8 * 8
+        A = torch.randn(R, Kp, device=dev).to(tdt); D = torch.randn(R, Np, device=dev).to(tdt)
+        out = torch.randn(K, N, device=dev); out0 = out.clone()
+        ops.gemm_tn(dt, A, Kp, Kp, D, Np, Np, out, N, R, K, N, alpha=0.5, wg=cx)
+        outs.append(out); refs.append(out0 + 0.5 * (A.float().t() @ D.float())[:K, :N])
+    # two products into one output + an outer batch with o_bs = 0 (all batches accumulate into the same block)
+    A1 = torch.randn(600, 128, device=dev).bfloat16(); A2 = torch.randn(900, 128, device=dev).bfloat16()
+    D1 = torch.randn(600, 256, device=dev).bfloat16(); D2 = torch.randn(900, 256, device=dev).bfloat16()
+    shared = torch.zeros(128, 256, device=dev)
+    ops.gemm_tn(1, A1, 128, 128, D1, 256, 256, shared, 256, 600, 128, 256, wg=cx)
+    ops.gemm_tn(1, A2, 128, 128, D2, 256, 256, shared, 256, 900, 128, 256, wg=cx)
+    outs.append(shared); refs.append(A1.float().t() @ D1.float() + A2.float().t() @ D2.float())
+    Ab = torch.randn(3, 40, 64, device=dev); Db = torch.randn(3, 40, 128, device=dev); ob = torch.zeros(64, 128, device=dev)
+    ops.gemm_tn(0, Ab, 64, 64, Db, 128, 64, ob, 128, 40, 64, 64, offs=((0, 0, 0), (0, 64, 64)), nb2=3, a_bs=40 * 64, d_bs=40 * 128, o_bs=0, wg=cx)
+    outs.append(ob); refs.append(torch.einsum("brk,brn->kn", Ab, Db))
+    assert len(cx.deferred) == 15 and all(torch.equal(o, o) for o in outs)
+    arr = (P._lib.GemmTnArgs * len(cx.deferred))()
+    import ctypes
+    for i, (a, _A, _D) in enumerate(cx.deferred):
+        ctypes.memmove(ctypes.byref(arr[i]), ctypes.byref(a), ctypes.sizeof(P._lib.GemmTnArgs))
+    P._lib.call("cmpc_gemm_tn_grouped", arr, len(cx.deferred), ops._st())
+    torch.cuda.synchronize()
+    for i, (o, r) in enumerate(zip(outs, refs)):
+        assert float((o - r).abs().max()) <= 2e-5 * max(1.0, float(r.abs().max())), i
+
+
+@pytest.mark.parametrize("env", ["CMPC_GEMM_V2", "CMPC_GEMM_V3", "CMPC_GEMM_V4", "CMPC_GEMM_V5", "CMPC_GEMM_V1"])
+def test_gemm_nt_kernel_variants_agree(env, monkeypatch):
+    """Every bf16 gemm_nt kernel variant (forced by its switch) against torch on shapes that reach the tiled
+    pipelines: ragged M and N, three K-segments, per-sample bias, activation, pad-column zeroing, accumulate."""
+    ops, dev = _ops(), torch.device("cuda:0")
+    monkeypatch.setenv(env, "1")
+    torch.manual_seed(5)
+    for (M, N, Ks, nv) in ((3000, 640, (256,), 640), (1111, 1024, (64, 128, 64), 1000), (12800, 512, (512,), 500), (700, 264, (2048, 64), 264)):
+        K = sum(Ks)
+        A = [torch.randn(M, k, device=dev).bfloat16() for k in Ks]
+        Bt = torch.randn(N, K, device=dev).bfloat16()
+        bias = torch.randn(N, device=dev); rps = 100 if M % 100 == 0 else M
+        sb = torch.randn(M // rps, N, device=dev)
+        C = torch.randn(M, N, device=dev).bfloat16(); C0 = C.clone()
+        segs, off = [], 0
+        for a, k in zip(A, Ks):
+            segs.append((a, k, Bt.data_ptr() + 2 * off, K, k)); off += k
+        ops.gemm_nt(1, segs, C, N, M, N, n_valid=nv, bias=bias, sbias=sb, ld_sbias=N, rows_per_sample=rps, act=1, accumulate=True)
+        ref = torch.relu(torch.cat(A, 1).float() @ Bt.float().t() + bias + sb.repeat_interleave(rps, 0))
+        ref[:, nv:] = 0
+        ref = (ref + C0.float()).bfloat16().float()
+        torch.cuda.synchronize()
+        assert U.rel_err(C.float().cpu(), ref.cpu()) < 1e-2, (env, M, N, Ks)
+        if nv < N:      # pad columns: the product contributes exact zeros
+            assert torch.equal(C[:, nv:], C0[:, nv:])
+
+
 
 def test_head_forward_backward_fp32_matches_oracle(case):
     m = _model(case, "f32")
