@@ -111,12 +111,15 @@ class LSTM_model(object):
             if key + "/opt" not in LSTM_model._SIDE_STREAMS:
                 LSTM_model._SIDE_STREAMS[key + "/opt"] = torch.cuda.Stream(device=self.device)
             self.opt_stream = LSTM_model._SIDE_STREAMS[key + "/opt"]
+            early = os.environ.get("CMPC_WGRAD_OVERLAP", "1") != "0"
+            self.cx.flush_stream, self.cx.lanes = (self.side[1] if early else None), tuple(self.side)
             if key + "/wg" not in LSTM_model._SIDE_STREAMS:
                 LSTM_model._SIDE_STREAMS[key + "/wg"] = torch.cuda.Stream(device=self.device)
             self.cx.wg = LSTM_model._SIDE_STREAMS[key + "/wg"] if os.environ.get("CMPC_WGRAD_STREAM", "0") != "0" else None
         else:
             self.side = None
             self.opt_stream = None
+            self.cx.flush_stream, self.cx.lanes = None, ()
             self.cx.wg = None
 
     # ------------------------------------------------------------------------------------------

@@ -183,21 +183,36 @@ class Ctx:
         # backward pass and issued as a few grouped launches by flush_wgrad() (CMPC_WGRAD_DEFER=0: in place)
         self.defer = os.environ.get("CMPC_WGRAD_DEFER", "1") != "0"
         self.deferred = []
+        self.flush_stream, self.lanes = None, ()      # set by LSTM_model.set_streams
 
-    def flush_wgrad(self):
-        """Launch the deferred weight-gradient products on the current stream (which must be ordered after
-        every stream that produced their operands)."""
+    def flush_wgrad(self, early=False):
+        """Launch the deferred weight-gradient products.  early=False: on the current stream (which must be
+        ordered after every stream that produced their operands).  early=True (called when the text encoder's
+        backward starts -- the last stage of the backward pass, a serial chain of ~100 small kernels): on the
+        flush stream, after everything queued so far on the current stream and on the lanes, so that the
+        products run beside that chain (the grouped kernel is persistent, so it leaves the dispatcher free)."""
+        st = self.flush_stream if early else None
+        if early and st is None:
+            return
         items, self.deferred = self.deferred, []
         if not items:
             return
         arr = (GemmTnArgs * len(items))()
         for i, (a, _A, _D) in enumerate(items):
             ctypes.memmove(ctypes.byref(arr[i]), ctypes.byref(a), ctypes.sizeof(GemmTnArgs))
-        _lib.call("cmpc_gemm_tn_grouped", arr, len(items), _st())
+        cur = torch.cuda.current_stream(self.dev)
+        if st is not None:
+            st.wait_stream(cur)
+            for ln in self.lanes:
+                if ln is not st:
+                    st.wait_stream(ln)
+        run = st if st is not None else cur
+        with torch.cuda.stream(run):
+            _lib.call("cmpc_gemm_tn_grouped", arr, len(items), _st())
         for _a, A, D in items:        # the caching allocator must not recycle the operands before the launch has run
             for t in (A, D):
                 if torch.is_tensor(t):
-                    t.record_stream(torch.cuda.current_stream(t.device))
+                    t.record_stream(run)
 
     def op(self, key):
         return self.ps.ops[key]
@@ -245,6 +260,7 @@ class TextEncoder(torch.autograd.Function):
         words_tb, seq_len, emb, gates, h_all, c_all, wf, rstd = ctx.saved
         B, T, R, G = cfg.batch_size, cfg.num_steps, cfg.rnn_size, cfg.glove_dim
         Cp, Gp = cfg.Cp, cfg.Gp
+        cx.flush_wgrad(early=True)       # every other stage's weight gradients run beside this serial chain
         dwf = dwf.contiguous()
         douts = empty((B * T, Cp), F32, dev)
         _lib.call("cmpc_l2norm_rows_bwd", F32, _p(dwf), _p(wf), _p(rstd), _p(douts), B * T, Cp, R, 0, _st())
