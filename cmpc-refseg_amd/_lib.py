@@ -140,6 +140,7 @@ SIGNATURES = {
     "cmpc_lang_pool_fwd": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     "cmpc_lang_pool_bwd": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     "cmpc_pack_weights": [_P, _P, _P, _P, _I, _I, _P],
+    "cmpc_pack_weights_range": [_P, _P, _P, _P, _P, _I, _I, _I, _P],
     "cmpc_adam_step": [_P, _P, _P, _P, _P, _I, _F, _F, _F, _F, _F, _P],
 }
 

@@ -149,29 +149,41 @@ __global__ __launch_bounds__(256) void lang_pool_bwd_kernel(const float* __restr
 // pack: padded operand (k, n) <- master[src_row(k), src_col(n)] through a 32x32 LDS tile so that
 // both the read (n contiguous) and the transposed write (k contiguous) are coalesced.
 // ------------------------------------------------------------------------------------------
-__device__ __forceinline__ int seg_map(int x, int ns, const int* src, const int* len, const int* dst) {
-    for (int s = 0; s < ns; ++s) if (x >= dst[s] && x < dst[s] + len[s]) return src[s] + (x - dst[s]);
-    return -1;
+template <int N>
+__device__ __forceinline__ int seg_map(int x, int ns, const int (&src)[N], const int (&len)[N], const int (&dst)[N]) {
+    // fully unrolled with static indices: a runtime-indexed loop made hipcc keep the whole descriptor in scratch
+    // (168 B per lane written and re-read by every block: more traffic than the tile itself)
+    int r = -1;
+#pragma unroll
+    for (int s = 0; s < N; ++s) if (s < ns && x >= dst[s] && x < dst[s] + len[s]) r = src[s] + (x - dst[s]);
+    return r;
 }
 
 __global__ __launch_bounds__(256) void pack_kernel(const float* __restrict__ master, char* __restrict__ arena, const cmpc_pack_desc* __restrict__ descs,
-                                                  const int* __restrict__ tile_prefix, int ndesc) {
-    // tile = 32 (k) x 128 (n): float4 reads along n (every segment boundary is a multiple of 4),
-    // 8/16-byte writes along n (natural) or along k through LDS (transposed).
-    __shared__ float tile[32][132];
+                                                  const int* __restrict__ tile_prefix, int ndesc, int tile_begin,
+                                                  const int* __restrict__ tile_desc) {
+    // tile = 64 (k) x 128 (n): float4 reads along n (every segment boundary is a multiple of 4); writes along n
+    // (natural, 8 / 16 B per lane) or along k through LDS (transposed: 8 k-values = one 16-B bf16 store per lane, a
+    // full 128-B line per destination row).  LDS rows are 129 floats: both the scalar stores (element order rotated
+    // per 8-lane group) and the column reads (lane -> 4 k-groups x 8 rows per half wave) are bank-conflict free.
+    __shared__ float tile[64][129];
     int lo = 0, hi = ndesc;
-    while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (tile_prefix[mid] <= (int)blockIdx.x) lo = mid; else hi = mid; }
+    const int gt = (int)blockIdx.x + tile_begin;
+    // tile -> descriptor: one table lookup instead of a binary search (~9 dependent global loads)
+    if (tile_desc) lo = tile_desc[gt];
+    else while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (tile_prefix[mid] <= gt) lo = mid; else hi = mid; }
     const cmpc_pack_desc d = descs[lo];
-    const int t = blockIdx.x - tile_prefix[lo];
+    const int t = gt - tile_prefix[lo];
     const int Kp = d.transpose ? d.cols : d.rows, Np = d.transpose ? d.rows : d.cols;
     const int tn = (Np + 127) / 128;
-    const int k0 = (t / tn) * 32, n0 = (t % tn) * 128;
+    const int k0 = (t / tn) * 64, n0 = (t % tn) * 128;
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
     char* dst = arena + d.dst_off;
     const int n = n0 + 4 * tx;
     const int sc = (n < Np) ? seg_map(n, d.nns, d.ns_src, d.ns_len, d.ns_dst) : -1;
+    const int rot = tx >> 3;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < 8; ++i) {
         const int kk = ty + 8 * i, k = k0 + kk;
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
         if (k < Kp && sc >= 0) {
@@ -190,26 +202,30 @@ __global__ __launch_bounds__(256) void pack_kernel(const float* __restrict__ mas
                 }
             }
         } else {
-            tile[kk][4 * tx] = v.x; tile[kk][4 * tx + 1] = v.y; tile[kk][4 * tx + 2] = v.z; tile[kk][4 * tx + 3] = v.w;
+            const float e[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const int cc = (c + rot) & 3;          // 8-lane groups start at different elements: 32 distinct banks
+                tile[kk][4 * tx + cc] = e[cc];
+            }
         }
     }
     if (!d.transpose) return;
     __syncthreads();
-    // transposed write: row n of the destination holds k contiguous; 8 threads x 4 k-values per row
-    const int kq = (threadIdx.x & 7) * 4;
+    // transposed write: row n of the destination holds k contiguous; a lane owns 8 consecutive k of one row
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int kq = ((lane & 3) + 4 * (lane >> 5)) * 8, nsub = (lane >> 2) & 7;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-        const int nl = (threadIdx.x >> 3) + 32 * j, nn = n0 + nl, k = k0 + kq;
+        const int nl = nsub + 8 * wv + 32 * j, nn = n0 + nl, k = k0 + kq;
         if (nn < Np && k < Kp) {
+            float a[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) a[e] = tile[kq + e][nl];
             const long o = (long)nn * d.ld_dst + k;
-            const float a0 = tile[kq][nl], a1 = tile[kq + 1][nl], a2 = tile[kq + 2][nl], a3 = tile[kq + 3][nl];
-            if (d.dst_dt == DT_F32) *reinterpret_cast<float4*>(reinterpret_cast<float*>(dst) + o) = make_float4(a0, a1, a2, a3);
-            else {
-                uint2 u;
-                u.x = (uint32_t)f2bf(a0) | ((uint32_t)f2bf(a1) << 16);
-                u.y = (uint32_t)f2bf(a2) | ((uint32_t)f2bf(a3) << 16);
-                *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(dst) + o) = u;
-            }
+            // rows of a destination operand are padded to multiples of 64 elements, so k..k+7 stay inside the row
+            if (d.dst_dt == DT_F32) st8<float>(reinterpret_cast<float*>(dst) + o, a);
+            else st8<bf16_t>(reinterpret_cast<bf16_t*>(dst) + o, a);
         }
     }
 }
@@ -274,11 +290,17 @@ extern "C" int cmpc_lang_pool_bwd(const float* dv, const float* v, const float* 
     return cmpc_check_launch("lang_pool_bwd");
 }
 
+extern "C" int cmpc_pack_weights_range(const float* master, void* arena, const cmpc_pack_desc* descs_dev, const int* tile_prefix_dev,
+                                       const int* tile_desc_dev, int ndesc, int tile_begin, int tile_end, void* stream) {
+    if (ndesc <= 0 || tile_end <= tile_begin) return CMPC_OK;
+    if (tile_begin < 0) { cmpc_set_error("pack_weights: bad tile range"); return CMPC_EINVAL; }
+    hipLaunchKernelGGL(pack_kernel, dim3(tile_end - tile_begin), dim3(256), 0, ST, master, (char*)arena, descs_dev, tile_prefix_dev, ndesc, tile_begin, tile_desc_dev);
+    return cmpc_check_launch("pack_weights");
+}
+
 extern "C" int cmpc_pack_weights(const float* master, void* arena, const cmpc_pack_desc* descs_dev, const int* tile_prefix_dev,
                                  int ndesc, int total_tiles, void* stream) {
-    if (ndesc <= 0 || total_tiles <= 0) return CMPC_OK;
-    hipLaunchKernelGGL(pack_kernel, dim3(total_tiles), dim3(256), 0, ST, master, (char*)arena, descs_dev, tile_prefix_dev, ndesc);
-    return cmpc_check_launch("pack_weights");
+    return cmpc_pack_weights_range(master, arena, descs_dev, tile_prefix_dev, nullptr, ndesc, 0, total_tiles, stream);
 }
 
 extern "C" int cmpc_adam_step(float* params, const float* grads, float* m, float* v, const cmpc_adam_seg* segs_dev, int nseg,

@@ -28,12 +28,17 @@ class _OnMain(torch.autograd.Function):
     stream of its forward, so with this node every cross-lane gradient goes lane -> main -> lane; direct
     lane -> lane event edges inside a stream capture crash hipStreamEndCapture on ROCm 7.2."""
     @staticmethod
-    def forward(ctx, x):
+    def forward(ctx, x, model=None, tag=None):
+        ctx.model, ctx.tag = model, tag
+        if model is not None:
+            model._mark(tag + ":fwd")
         return x.view_as(x)
 
     @staticmethod
     def backward(ctx, g):
-        return g
+        if ctx.model is not None:
+            ctx.model._mark(ctx.tag + ":bwd")
+        return g, None, None
 
 
 class LSTM_model(object):
@@ -92,6 +97,8 @@ class LSTM_model(object):
         self.use_graph = os.environ.get("CMPC_GRAPH", "0") != "0"
         self._graph, self._gin, self._gout, self._eager_steps = None, None, None, 0
         self._opt_pending = False
+        self._opt_stage0 = None
+        self.marks = [] if os.environ.get("CMPC_MARKS") else None
         # the three pyramid levels (and the three exchange modules of a round) are independent: each gets
         # its own HIP stream so HBM-bound stage kernels of one level overlap MFMA-bound GEMMs of another.
         # autograd replays every backward on the stream of its forward, so the backward overlaps too.
@@ -143,11 +150,24 @@ class LSTM_model(object):
         """backbone taps (c3, c4, c5), NHWC, head dtype (CMPC_model.py:73-76)."""
         return self.backbone(self._dev(im, torch.float32))
 
-    def _params_ready(self):
+    def _mark(self, name):
+        """CMPC_MARKS=1: timing events at the phase boundaries of a step (scripts/step_timeline.py)."""
+        if self.marks is not None:
+            ev = torch.cuda.Event(enable_timing=True)
+            ev.record(torch.cuda.current_stream(self.device))
+            self.marks.append((name, ev))
+
+    def _params_ready(self, stage=1):
         """The optimizer of the previous train_step runs on its own stream (it overlaps the next step's frozen
-        backbone); everything that touches parameters, packed operands or the gradient buffer waits for it here."""
+        backbone); everything that touches parameters, packed operands or the gradient buffer waits for it here.
+        stage 0: Adam done and the text encoder's / parser's operands repacked (all the LSTM needs, so it runs
+        while the level weights are still being packed); stage 1: everything."""
         if self._opt_pending:
-            torch.cuda.current_stream(self.device).wait_stream(self.opt_stream)
+            cur = torch.cuda.current_stream(self.device)
+            if stage == 0 and self._opt_stage0 is not None:
+                cur.wait_event(self._opt_stage0)
+                return
+            cur.wait_stream(self.opt_stream)
             self._opt_pending = False
 
     def features_async(self, im, ready=None):
@@ -169,6 +189,7 @@ class LSTM_model(object):
             st.wait_stream(main)
         with torch.cuda.stream(st):
             feats = self.backbone(im)
+            self._mark("backbone")
         for f in feats:
             f.record_stream(main)
             for s2 in self.side:
@@ -181,7 +202,7 @@ class LSTM_model(object):
         `after`: stream that produces `feats` (waited for once the text encoder has been queued)."""
         cfg, cx, O = self.cfg, self.cx, ops
         B, T, N = cfg.batch_size, cfg.num_steps, cfg.N
-        self._params_ready()
+        self._params_ready(0)
         if after is None:
             c3, c4, c5 = [f.to(ops.tdt(self.dt)).contiguous() for f in feats]
         words = self._dev(words, torch.int32).view(-1)
@@ -189,8 +210,12 @@ class LSTM_model(object):
         tgt = self._dev(target, torch.float32) if target is not None else None
         a = cx.anchor
         wf, mask = O.TextEncoder.apply(a, words, seq_len, cx)
+        if self.marks is not None:
+            wf = _OnMain.apply(wf, self, "text")
         parse = O.LangParser.apply(wf, mask, cx)
         vl = O.LangPool.apply(parse, wf, 2, cx)                 # valid_lang: entity + attribute
+        self._mark("text_fwd_done")
+        self._params_ready(1)
         out = {"words_feat": wf, "seq_mask": mask, "words_parse": parse}
         fus, losses = {}, {}
         main = torch.cuda.current_stream(self.device)
@@ -225,7 +250,7 @@ class LSTM_model(object):
                 l, sc, up, _s, _iu = O.ScoreHead.apply(fus[lv], f"score_{lv}", tgt, 0.1, cx)
                 out[f"score_{lv}"], out[f"up_{lv}"], losses[lv] = sc, up, l
         join()
-        fus = {k: _OnMain.apply(v) for k, v in fus.items()}
+        fus = {k: _OnMain.apply(v, self if self.marks is not None and k == "c5" else None, "levels") for k, v in fus.items()}
         phase[0] = 1
         nec = O.LangPool.apply(parse, wf, 3, cx)                # nec_lang: entity + attribute + relation
         out["nec_lang"] = nec
@@ -236,17 +261,19 @@ class LSTM_model(object):
                 ex[nm] = O.Exchange.apply(fa, fb, fc, nec, nm, cx)
         join()
         phase[0] = 2
-        e3, e4, e5 = (_OnMain.apply(ex[k]) for k in ("c3", "c4", "c5"))
+        e3, e4, e5 = (_OnMain.apply(ex[k], self if self.marks is not None and k == "c5" else None, "exch1") for k in ("c3", "c4", "c5"))
         for i, (nm, fa, fb, fc) in enumerate((("c3_2", e3, e4, e5), ("c4_2", e4, e3, e5), ("c5_2", e5, e3, e4))):
             with torch.cuda.stream(fork(i)):
                 ex[nm] = O.Exchange.apply(fa, fb, fc, nec, nm, cx)
         join()
         e32, e42, e52 = ex["c3_2"], ex["c4_2"], ex["c5_2"]
         out.update(exg_c3=e3, exg_c4=e4, exg_c5=e5, exg_c3_2=e32, exg_c4_2=e42, exg_c5_2=e52)
+        self._mark("exch2_done")
         fused = O.ConvLSTM.apply(e32, e42, e52, cx)
         out["fused"] = fused
         l, pred, up, sigm, iu = O.ScoreHead.apply(fused, "score", tgt, 0.7, cx)
         out.update(pred=pred, up=up, sigm=sigm, iu=iu)
+        self._mark("fwd_done")
         if tgt is not None:
             # cls_loss_all = 0.7 L + 0.1 (L_c5 + L_c4 + L_c3), CMPC_model.py:444-445 (scalar bookkeeping only)
             out["loss_last"], out["loss_c5"], out["loss_c4"], out["loss_c3"] = l.mean(), losses["c5"].mean(), losses["c4"].mean(), losses["c3"].mean()
@@ -275,7 +302,7 @@ class LSTM_model(object):
     def loss_and_grads(self, feats, words, target_fine, seq_len, after=None):
         """forward + backward of `cost` (CMPC_model.py:447) into the flat gradient buffer (L2 and the
         x2 bias multiplier are applied inside the Adam kernel)."""
-        self._params_ready()
+        self._params_ready(0)          # Adam has consumed the gradient buffer
         self.store.zero_grads()
         o = self.head(feats, words, seq_len, target_fine, after=after)
         o["loss_all"].backward()
@@ -287,7 +314,9 @@ class LSTM_model(object):
                 main.wait_stream(st)
             if self.cx.wg is not None:
                 main.wait_stream(self.cx.wg)
+        self._mark("bwd_done")
         self.cx.flush_wgrad()
+        self._mark("dW_done")
         return o
 
     _SCALARS = ("loss_all", "loss_c3", "loss_c4", "loss_c5", "loss_last", "mIoU")
@@ -342,6 +371,7 @@ class LSTM_model(object):
         if self.mode != 'train':
             raise RuntimeError("model was built with mode='eval' (CMPC_model.py:85-86)")
         self._check_feeds(words, im, seq_len, target_fine)
+        self._mark("step_start")
         if self.use_graph:
             sv = self._fwd_bwd_graphed(words, im, target_fine, seq_len)
         else:
@@ -350,8 +380,11 @@ class LSTM_model(object):
         if self.opt_stream is not None:
             # Adam + repack on the optimizer stream: the next step's backbone does not depend on them
             self.opt_stream.wait_stream(torch.cuda.current_stream(self.device))
+            ev0 = torch.cuda.Event()
             with torch.cuda.stream(self.opt_stream):
-                lr = self.store.adam_step(gscale)
+                lr = self.store.adam_step(gscale, on_stage0=lambda: ev0.record(self.opt_stream))
+                self._mark("adam_done")
+            self._opt_stage0 = ev0
             self._opt_pending = True
         else:
             lr = self.store.adam_step(gscale)

@@ -292,10 +292,12 @@ class ParamStore:
                      ks=[(0, G, 0), (G, R, Gp)], ns=gate_ns)
         ob = self._new_operand("lstm.b", L, 1, 4 * Cp)       # bias re-blocked to the padded gate layout
         self._add_desc(ob, "rnn/lstm_cell/bias", 4 * R, 0, 0, 0, 1, 4 * Cp, [(0, 1, 0)], gate_ns)
-        for lv, cin in (("c5", c.vf_dim), ("c4", c.c4_dim), ("c3", c.c3_dim)):
-            self._linear(f"lat_{lv}", f"{lv}_lateral/DW", V, cin, C, pad64(cin), Cp, bwd=False)
         self._linear("parse1", "words_parse_1/DW", L, R, P, Cp, Pp)
         self._linear("parse2", "words_parse_2/DW", L, P, 4, Pp, 64)
+        # everything above is what the text encoder + parser read: packed (and published) first, see pack()
+        self.stage0_ndesc = len(self._descs)
+        for lv, cin in (("c5", c.vf_dim), ("c4", c.c4_dim), ("c3", c.c3_dim)):
+            self._linear(f"lat_{lv}", f"{lv}_lateral/DW", V, cin, C, pad64(cin), Cp, bwd=False)
         for lv in LEVELS:
             # mutan: five heads side by side.  forward operand [5Cp][Cp+64] (k: C visual rows then 8 spatial rows)
             opt = self._new_operand(f"mutan_{lv}.t", V, 5 * Cp, Cp + 64)
@@ -340,9 +342,11 @@ class ParamStore:
         pref = np.zeros(n + 1, dtype=np.int32)
         for i, d in enumerate(self._descs):
             kp, np_ = (d.cols, d.rows) if d.transpose else (d.rows, d.cols)
-            pref[i + 1] = pref[i] + ((kp + 31) // 32) * ((np_ + 127) // 128)
+            pref[i + 1] = pref[i] + ((kp + 63) // 64) * ((np_ + 127) // 128)
         self.tile_prefix = torch.from_numpy(pref).to(self.device)
         self.total_tiles = int(pref[-1])
+        self.tile_desc = torch.from_numpy(np.repeat(np.arange(n, dtype=np.int32), np.diff(pref))).to(self.device)
+        self.stage0_tiles = int(pref[self.stage0_ndesc])
         # Adam segments: <= 8192 elements each, inside one parameter
         segs = []
         for name, shape, _, flags in self.specs:
@@ -360,9 +364,13 @@ class ParamStore:
     def _stream(self):
         return ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
 
-    def pack(self):
-        _lib.call("cmpc_pack_weights", self.params.data_ptr(), self.arena.data_ptr(), self.descs_dev.data_ptr(),
-                  self.tile_prefix.data_ptr(), self.ndesc, self.total_tiles, self._stream())
+    def pack(self, part=None):
+        """master -> packed operands.  part=0: the text encoder's and parser's operands only; part=1: the rest;
+        None: everything (one launch)."""
+        lo = 0 if part in (None, 0) else self.stage0_tiles
+        hi = self.total_tiles if part in (None, 1) else self.stage0_tiles
+        _lib.call("cmpc_pack_weights_range", self.params.data_ptr(), self.arena.data_ptr(), self.descs_dev.data_ptr(),
+                  self.tile_prefix.data_ptr(), self.tile_desc.data_ptr(), self.ndesc, lo, hi, self._stream())
 
     def zero_grads(self):
         self.grads.zero_()
@@ -373,8 +381,9 @@ class ParamStore:
         gs = min(self.step, c.lr_decay_step)
         return (c.start_lr - c.end_lr) * (1 - gs / c.lr_decay_step) ** c.lr_power + c.end_lr
 
-    def adam_step(self, gscale: float = 1.0):
-        """TF AdamOptimizer.apply_gradients (CMPC_model.py:456,478) over the whole flat buffer, then repack."""
+    def adam_step(self, gscale: float = 1.0, on_stage0=None):
+        """TF AdamOptimizer.apply_gradients (CMPC_model.py:456,478) over the whole flat buffer, then repack.
+        on_stage0: called between the two pack launches (the text encoder's operands are final there)."""
         lr = self.lr()
         t = self.step + 1
         b1, b2 = 0.9, 0.999
@@ -382,5 +391,10 @@ class ParamStore:
         _lib.call("cmpc_adam_step", self.params.data_ptr(), self.grads.data_ptr(), self.m.data_ptr(), self.v.data_ptr(),
                   self.segs_dev.data_ptr(), self.nseg, lr_t, b1, b2, 1e-8, gscale, self._stream())
         self.step = t
-        self.pack()
+        if on_stage0 is None:
+            self.pack()
+        else:
+            self.pack(0)
+            on_stage0()
+            self.pack(1)
         return lr

@@ -231,11 +231,16 @@ typedef struct {
     int nks; int ks_src[4], ks_len[4], ks_dst[4];   /* K segments: src row range -> dst k offset */
     int nns; int ns_src[5], ns_len[5], ns_dst[5];   /* N blocks:   src col range -> dst n offset */
 } cmpc_pack_desc;
-/* tile_prefix_dev[i] = number of 32(k) x 128(n) tiles of descriptors 0..i-1 (exclusive prefix sum, ndesc+1
- * entries; tile count = ceil(K/32)*ceil(N/128) of each padded block); total_tiles = tile_prefix[ndesc].
+/* tile_prefix_dev[i] = number of 64(k) x 128(n) tiles of descriptors 0..i-1 (exclusive prefix sum, ndesc+1
+ * entries; tile count = ceil(K/64)*ceil(N/128) of each padded block); total_tiles = tile_prefix[ndesc].
  * Every K/N segment boundary, ld_src and src_off must be a multiple of 4 (float4 reads). */
 int cmpc_pack_weights(const float* master, void* arena, const cmpc_pack_desc* descs_dev, const int* tile_prefix_dev,
                       int ndesc, int total_tiles, void* stream);
+/* the tiles [tile_begin, tile_end) only: lets the text encoder's operands (planned first) be published before the
+ * rest, so that the next step's LSTM starts while the level weights are still being packed */
+int cmpc_pack_weights_range(const float* master, void* arena, const cmpc_pack_desc* descs_dev, const int* tile_prefix_dev,
+                            const int* tile_desc_dev /* optional: descriptor index of every tile */,
+                            int ndesc, int tile_begin, int tile_end, void* stream);
 
 typedef struct { int64_t off; int count; float wd; float gmult; } cmpc_adam_seg;
 int cmpc_adam_step(float* params, const float* grads, float* m, float* v, const cmpc_adam_seg* segs_dev, int nseg,
