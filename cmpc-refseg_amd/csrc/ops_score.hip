@@ -92,6 +92,89 @@ __global__ __launch_bounds__(256) void score_conv_bwd_data_kernel(const float* _
     }
 }
 
+// ---- row-based forms (ld <= 512): one workgroup per image row, each of its 4 waves walks a run of consecutive
+// pixels.  The 72 filter taps of a lane are loaded once per run (the per-pixel kernels above reload 18 KB of taps
+// for every 1-2 pixels: 83 us for a 13 MB map), and forward keeps a sliding window of three neighbour columns in
+// registers (3 new 16-B loads per pixel instead of 9, the column after next already in flight).
+template <typename T>
+__global__ __launch_bounds__(256) void score_conv_fwd_row_kernel(const T* __restrict__ feat, const float* __restrict__ Wk, const float* __restrict__ bias,
+                                                                float* __restrict__ score, int h, int w, int ld, int M) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int b = blockIdx.x / h, y = blockIdx.x % h;
+    const int per = (w + WPB - 1) / WPB, x0 = wv * per, x1 = min(w, x0 + per);
+    if (x0 >= x1) return;
+    const int c0 = lane * 8;
+    const bool act = c0 < ld;
+    float wk[9][8];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { const int c = c0 + e; wk[t][e] = (c < M) ? Wk[t * M + c] : 0.f; }
+    auto load_col = [&](int xx, float (&c)[3][8]) {
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            const int yy = y + r - 1;
+            if (act && yy >= 0 && yy < h && xx >= 0 && xx < w) ld8<T>(feat + ((long)(b * h + yy) * w + xx) * ld + c0, c[r]);
+            else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) c[r][e] = 0.f;
+            }
+        }
+    };
+    float cL[3][8], cM[3][8], cR[3][8], cN[3][8];
+    load_col(x0 - 1, cL); load_col(x0, cM); load_col(x0 + 1, cR);
+    const float bs = bias[0];
+    for (int x = x0; x < x1; ++x) {
+        load_col(x + 2, cN);
+        float acc = 0.f;
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+                acc += cL[r][e] * wk[r * 3][e] + cM[r][e] * wk[r * 3 + 1][e] + cR[r][e] * wk[r * 3 + 2][e];
+        acc = wave_sum(acc);
+        if (lane == 0) score[(b * h + y) * w + x] = acc + bs;
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { cL[r][e] = cM[r][e]; cM[r][e] = cR[r][e]; cR[r][e] = cN[r][e]; }
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void score_conv_bwd_data_row_kernel(const float* __restrict__ dscore, const float* __restrict__ Wk, T* __restrict__ dfeat,
+                                                                     int accumulate, int h, int w, int ld, int M) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int b = blockIdx.x / h, y = blockIdx.x % h;
+    const int per = (w + WPB - 1) / WPB, x0 = wv * per, x1 = min(w, x0 + per);
+    const int c0 = lane * 8;
+    if (x0 >= x1 || c0 >= ld) return;
+    float wk[9][8];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { const int c = c0 + e; wk[t][e] = (c < M) ? Wk[t * M + c] : 0.f; }
+    for (int x = x0; x < x1; ++x) {
+        float ds[9];
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const int yy = y - (t / 3 - 1), xx = x - (t % 3 - 1);
+            ds[t] = (yy >= 0 && yy < h && xx >= 0 && xx < w) ? dscore[(b * h + yy) * w + xx] : 0.f;
+        }
+        T* d = dfeat + ((long)(b * h + y) * w + x) * ld + c0;
+        float o[8];
+        if (accumulate) ld8<T>(d, o);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            float v = 0.f;
+#pragma unroll
+            for (int t = 0; t < 9; ++t) v += ds[t] * wk[t][e];
+            o[e] = accumulate ? o[e] + v : v;
+        }
+        st8<T>(d, o);
+    }
+}
+
 // dW[tap,m] += sum_pixels dscore[b, y-dy, x-dx] * feat[b,y,x,m];  dbias += sum dscore
 template <typename T>
 __global__ __launch_bounds__(256) void score_conv_bwd_w_kernel(const float* __restrict__ dscore, const T* __restrict__ feat, float* part, float* dbias,
@@ -193,32 +276,34 @@ __global__ __launch_bounds__(256) void upsample_fwd_kernel(const float* __restri
     }
 }
 
+// One WAVE per low-resolution pixel: its lanes share the (at most ~20 x 20) window of high-resolution pixels whose
+// legacy-bilinear footprint can touch it (consecutive lanes = consecutive X: coalesced reads), then one wave
+// reduction.  (One THREAD per pixel walked that window alone with scattered reads: 50 workgroups, 73 us.)
 __global__ __launch_bounds__(256) void upsample_loss_bwd_kernel(const float* __restrict__ up, const float* __restrict__ target, float* __restrict__ dscore,
                                                                float wscale, int B, int h, int w, int H, int W) {
-    const int p = blockIdx.x * 256 + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    const int p = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (p >= B * h * w) return;
     const int b = p / (h * w), y = (p / w) % h, x = p % w;
     const float sy = (float)h / (float)H, sx = (float)w / (float)W;
     const int Ylo = max(0, (int)floorf((float)(y - 1) / sy) - 1), Yhi = min(H - 1, (int)ceilf((float)(y + 1) / sy) + 1);
     const int Xlo = max(0, (int)floorf((float)(x - 1) / sx) - 1), Xhi = min(W - 1, (int)ceilf((float)(x + 1) / sx) + 1);
+    const int nX = Xhi - Xlo + 1, cnt = (Yhi - Ylo + 1) * nX;
     float acc = 0.f;
-    for (int Y = Ylo; Y <= Yhi; ++Y) {
-        int y0, y1; float fy;
+    for (int i = lane; i < cnt; i += 64) {
+        const int Y = Ylo + i / nX, X = Xlo + i % nX;
+        int y0, y1, x0, x1; float fy, fx;
         interp_coef(Y, sy, h, y0, y1, fy);
+        interp_coef(X, sx, w, x0, x1, fx);
         const float wy = (y0 == y ? 1.f - fy : 0.f) + (y1 == y ? fy : 0.f);
-        if (wy == 0.f) continue;
-        for (int X = Xlo; X <= Xhi; ++X) {
-            int x0, x1; float fx;
-            interp_coef(X, sx, w, x0, x1, fx);
-            const float wx = (x0 == x ? 1.f - fx : 0.f) + (x1 == x ? fx : 0.f);
-            if (wx == 0.f) continue;
+        const float wx = (x0 == x ? 1.f - fx : 0.f) + (x1 == x ? fx : 0.f);
+        if (wy != 0.f && wx != 0.f) {
             const long o = ((long)b * H + Y) * W + X;
-            const float u = up[o];
-            const float d = 1.0f / (1.0f + expf(-u)) - target[o];
-            acc += wy * wx * d;
+            acc += wy * wx * (1.0f / (1.0f + expf(-up[o])) - target[o]);
         }
     }
-    dscore[p] = acc * wscale;
+    acc = wave_sum(acc);
+    if (lane == 0) dscore[p] = acc * wscale;
 }
 
 }  // namespace
@@ -230,7 +315,7 @@ extern "C" int cmpc_score_conv_fwd(int dt, const void* feat, const float* Wk, co
     if (ld % 8 || M > ld || ld > MB * 512) { cmpc_set_error("score_conv_fwd: bad ld/M"); return CMPC_EINVAL; }
     const int total = B * h * w, g = (total + 3) / 4 > 2048 ? 2048 : (total + 3) / 4;
     CMPC_DISPATCH_DT(dt, {
-        if (ld <= 512) hipLaunchKernelGGL((score_conv_fwd_kernel<T, 1>), dim3(g), dim3(256), 0, ST, (const T*)feat, Wk, bias, score, B, h, w, ld, M);
+        if (ld <= 512) hipLaunchKernelGGL((score_conv_fwd_row_kernel<T>), dim3(B * h), dim3(256), 0, ST, (const T*)feat, Wk, bias, score, h, w, ld, M);
         else hipLaunchKernelGGL((score_conv_fwd_kernel<T, 2>), dim3(g), dim3(256), 0, ST, (const T*)feat, Wk, bias, score, B, h, w, ld, M);
     });
     return cmpc_check_launch("score_conv_fwd");
@@ -241,7 +326,7 @@ extern "C" int cmpc_score_conv_bwd(int dt, const float* dscore, const void* feat
     if (ld % 8 || M > ld || ld > MB * 512) { cmpc_set_error("score_conv_bwd: bad ld/M"); return CMPC_EINVAL; }
     const int total = B * h * w, g = (total + 3) / 4 > 2048 ? 2048 : (total + 3) / 4;
     CMPC_DISPATCH_DT(dt, {
-        if (dfeat && ld <= 512) hipLaunchKernelGGL((score_conv_bwd_data_kernel<T, 1>), dim3(g), dim3(256), 0, ST, dscore, Wk, (T*)dfeat, accumulate, B, h, w, ld, M);
+        if (dfeat && ld <= 512) hipLaunchKernelGGL((score_conv_bwd_data_row_kernel<T>), dim3(B * h), dim3(256), 0, ST, dscore, Wk, (T*)dfeat, accumulate, h, w, ld, M);
         else if (dfeat) hipLaunchKernelGGL((score_conv_bwd_data_kernel<T, 2>), dim3(g), dim3(256), 0, ST, dscore, Wk, (T*)dfeat, accumulate, B, h, w, ld, M);
     });
     if (dWk) {
@@ -265,6 +350,6 @@ extern "C" int cmpc_upsample_fwd(const float* score, float* up, float* sigm, con
 
 extern "C" int cmpc_upsample_loss_bwd(const float* up, const float* target, float* dscore, float wscale,
                                       int B, int h, int w, int H, int W, void* stream) {
-    hipLaunchKernelGGL(upsample_loss_bwd_kernel, dim3((B * h * w + 255) / 256), dim3(256), 0, ST, up, target, dscore, wscale, B, h, w, H, W);
+    hipLaunchKernelGGL(upsample_loss_bwd_kernel, dim3((B * h * w + 3) / 4), dim3(256), 0, ST, up, target, dscore, wscale, B, h, w, H, W);
     return cmpc_check_launch("upsample_loss_bwd");
 }
