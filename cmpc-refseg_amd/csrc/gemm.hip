@@ -12,6 +12,7 @@
 // one bf16 fragment (8 k-values) or four f32 k-values consumed by four MFMA steps.
 #include "cmpc_common.h"
 #include <algorithm>
+#include <vector>
 #include "../../include/cmpc.h"
 #include <stdlib.h>
 
@@ -563,7 +564,6 @@ __global__ __launch_bounds__(512) void gemm_nt_v5_kernel(const cmpc_gemm_nt_args
     constexpr int WAVES_N = 4;
     constexpr int TM = 8, TN = 4;                          // 128 x 64 per wave
     constexpr int STAGE = (BM + BN) * ROWB;                // 32 KiB
-    constexpr int NST = 4;
     constexpr int APW = BM / 16 / 8, BPW = BN / 16 / 8;    // 1-KiB pieces (16 rows x 64 B) per wave and stage: 2 + 2
     constexpr int LPT = APW + BPW;
 
@@ -1090,33 +1090,41 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const cmpc_gemm_tn_args p)
     gemm_tn_body<T>(p, blockIdx.x, blockIdx.y, blockIdx.z);
 }
 
-// Grouped form: up to TN_GROUP independent products in ONE launch (the deferred weight gradients of a
-// backward pass).  Each product keeps its own tiling; workgroup w serves product g with
-// wg_begin[g] <= w < wg_begin[g+1].  With many products in flight no product needs a deep split of its
-// reduction, so the fp32-atomic epilogue (8-20 us of a 37-57 us stand-alone launch) shrinks to one pass.
-#define TN_GROUP 10
-struct TnGroupArgs {
-    int n;
-    int wg_begin[TN_GROUP + 1];
-    int tiles[TN_GROUP];
-    cmpc_gemm_tn_args a[TN_GROUP];
+// Grouped form: ALL deferred weight-gradient products of a backward pass in ONE persistent launch.  The
+// descriptor table lives in device memory (written by tn_desc_upload_kernel, a few descriptors per launch through
+// the kernel-argument segment); workgroup slot s walks the item list s, s+grid, ... (items = (product, output tile,
+// reduction split, batch) sorted by decreasing length, so the tail of the launch is made of short items).  With
+// every product in flight none needs a deep split of its reduction, so the fp32-atomic epilogue (8-20 us of a
+// 37-57 us stand-alone launch) shrinks to one pass, and there is one launch tail instead of one per group.
+// The grid is at most two workgroups per CU, so the launch does not sit in the workgroup dispatcher for its whole
+// duration (a 4600-workgroup grid starves the small kernels of every other stream: 14 -> 51 ms per step).
+struct TnGroupDesc {
+    cmpc_gemm_tn_args a;
+    int item_begin, tiles;
 };
-template <typename T>
-__global__ __launch_bounds__(256) void gemm_tn_grouped_kernel(const TnGroupArgs ga) {
-    // Persistent: the grid is at most two workgroups per CU and each walks the work list with a stride, so the
-    // launch does not sit in the workgroup dispatcher for its whole duration (a 4600-workgroup grid starves the
-    // small kernels of every other stream: measured 14 -> 51 ms per step when overlapped with the text backward).
-    const int total = ga.wg_begin[TN_GROUP];
+#define TN_UPLOAD 10
+struct TnUploadArgs {
+    int n, base;
+    TnGroupDesc d[TN_UPLOAD];
+};
+__global__ void tn_desc_upload_kernel(const TnUploadArgs ua, TnGroupDesc* table) {
+    constexpr int W = (int)(sizeof(TnGroupDesc) / sizeof(int));
+    const int* src = reinterpret_cast<const int*>(&ua.d[0]);
+    int* dst = reinterpret_cast<int*>(table + ua.base);
+    for (int i = threadIdx.x; i < ua.n * W; i += blockDim.x) dst[i] = src[i];
+}
+
+__global__ __launch_bounds__(256) void gemm_tn_grouped_kernel(const TnGroupDesc* __restrict__ table, int ndesc, int total) {
     for (int w = blockIdx.x; w < total; w += gridDim.x) {
-        int g = 0;
-#pragma unroll
-        for (int i = 1; i < TN_GROUP; ++i) if (i < ga.n && w >= ga.wg_begin[i]) g = i;
-        g = __builtin_amdgcn_readfirstlane(g);
-        const int local = w - ga.wg_begin[g];
-        const int tiles = ga.tiles[g], rs = ga.a[g].rsplit;
+        int lo = 0, hi = ndesc;                       // uniform binary search: scalar loads
+        while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (table[mid].item_begin <= w) lo = mid; else hi = mid; }
+        const TnGroupDesc& d = table[lo];
+        const int local = w - d.item_begin;
+        const int tiles = d.tiles, rs = d.a.rsplit;
         const int bx = local % tiles, rest = local / tiles;
-        gemm_tn_body<T>(ga.a[g], bx, rest % rs, rest / rs);
-        __syncthreads();                  // the next item reuses the LDS stages
+        if (d.a.dtype == DT_F32) gemm_tn_body<float>(d.a, bx, rest % rs, rest / rs);
+        else gemm_tn_body<bf16_t>(d.a, bx, rest % rs, rest / rs);
+        __syncthreads();                              // the next item reuses the LDS stages
     }
 }
 
@@ -1321,8 +1329,7 @@ extern "C" int cmpc_gemm_nt(const cmpc_gemm_nt_args* a, void* stream) {
         const char* e4 = getenv("CMPC_GEMM_V4");
         const bool v4 = e4 ? atoi(e4) != 0 : (!getenv("CMPC_GEMM_V2") && !getenv("CMPC_GEMM_V3") && (ktot < 2048 || (ktot < 4096 && a->N >= 1024)));
         {
-            // 256 x 256 tiles when they still give the chip enough workgroups (>= 96) -- see the kernel's header
-            const long t256 = (long)((a->M + 255) / 256) * ((a->N + 255) / 256) * a->batch;
+            // 256 x 256 tiles: study kernel, only on request -- see the kernel's header
             bool k32 = true;
             for (int s2 = 0; s2 < a->nseg; ++s2) k32 = k32 && (a->K[s2] % 32 == 0);
             const char* e5 = getenv("CMPC_GEMM_V5");
@@ -1432,46 +1439,50 @@ static int tn_validate(const cmpc_gemm_tn_args* a) {
 extern "C" int cmpc_gemm_tn_grouped(const cmpc_gemm_tn_args* args, int n, void* stream) {
     if (n < 0 || (n > 0 && !args)) { cmpc_set_error("gemm_tn_grouped: bad args"); return CMPC_EINVAL; }
     hipStream_t st = (hipStream_t)stream;
-    // products sorted by the work of one workgroup (long ones first: the tail of the launch is made of short ones)
-    int order[2][1024], cnt[2] = {0, 0};
+    std::vector<int> order;
+    long tiles_tot = 0;
     for (int i = 0; i < n; ++i) {
         const int rc = tn_validate(&args[i]);
         if (rc != CMPC_OK) return rc;
         if (args[i].R == 0) continue;
-        const int d = args[i].dtype == DT_F32 ? 0 : 1;
-        if (cnt[d] >= 1024) { cmpc_set_error("gemm_tn_grouped: more than 1024 products"); return CMPC_EINVAL; }
-        order[d][cnt[d]++] = i;
+        order.push_back(i);
+        tiles_tot += (long)((args[i].Kv + 127) / 128) * ((args[i].Nv + 127) / 128) * args[i].nb * args[i].nb2;
     }
-    for (int d = 0; d < 2; ++d) {
-        std::stable_sort(order[d], order[d] + cnt[d], [&](int x, int y) { return args[x].R > args[y].R; });
-        const int br = d == 0 ? TnCfg<float>::BR : TnCfg<bf16_t>::BR;
-        for (int c0 = 0; c0 < cnt[d]; c0 += TN_GROUP) {
-            TnGroupArgs ga;
-            ga.n = std::min(TN_GROUP, cnt[d] - c0);
-            long tot = 0;
-            for (int i = 0; i < ga.n; ++i) {
-                ga.a[i] = args[order[d][c0 + i]];
-                ga.tiles[i] = ((ga.a[i].Kv + 127) / 128) * ((ga.a[i].Nv + 127) / 128);
-                tot += (long)ga.tiles[i] * ga.a[i].nb * ga.a[i].nb2;
-            }
-            // split reductions only as far as needed to put ~1024 workgroups (2 per CU, 2 rounds) in the launch
-            const int want = (int)((1024 + tot - 1) / tot);
-            int wg = 0;
-            for (int i = 0; i < ga.n; ++i) {
-                const int maxs = std::max(1, ga.a[i].R / (4 * br));
-                ga.a[i].rsplit = std::max(1, std::min(want, maxs));
-                ga.wg_begin[i] = wg;
-                wg += ga.tiles[i] * ga.a[i].rsplit * ga.a[i].nb * ga.a[i].nb2;
-            }
-            for (int i = ga.n; i <= TN_GROUP; ++i) ga.wg_begin[i] = wg;
-            const int grid = std::min(wg, 512);
-            if (d == 0) hipLaunchKernelGGL((gemm_tn_grouped_kernel<float>), dim3(grid), dim3(256), 2 * 2 * TnCfg<float>::BR * 128 * 4, st, ga);
-            else hipLaunchKernelGGL((gemm_tn_grouped_kernel<bf16_t>), dim3(grid), dim3(256), 2 * 2 * TnCfg<bf16_t>::BR * 128 * 2, st, ga);
-            const int rc = cmpc_check_launch("gemm_tn_grouped");
-            if (rc != CMPC_OK) return rc;
+    const int m = (int)order.size();
+    if (m == 0) return CMPC_OK;
+    // split reductions only as far as needed to put ~1024 items (2 per CU, 2 rounds) in the launch
+    const int want = (int)((1024 + tiles_tot - 1) / tiles_tot);
+    std::vector<TnGroupDesc> descs(m);
+    std::vector<long> len(m);
+    for (int j = 0; j < m; ++j) {
+        TnGroupDesc& d = descs[j];
+        d.a = args[order[j]];
+        const int br = d.a.dtype == DT_F32 ? TnCfg<float>::BR : TnCfg<bf16_t>::BR;
+        d.a.rsplit = std::max(1, std::min(want, std::max(1, d.a.R / (4 * br))));
+        d.tiles = ((d.a.Kv + 127) / 128) * ((d.a.Nv + 127) / 128);
+        // steps of one item; an fp32 step (32 rows, 16x16x4 MFMA) costs about as much as a bf16 step of 64 rows
+        len[j] = ((d.a.R + d.a.rsplit - 1) / d.a.rsplit + br - 1) / br;
+    }
+    std::vector<int> idx(m);
+    for (int j = 0; j < m; ++j) idx[j] = j;
+    std::stable_sort(idx.begin(), idx.end(), [&](int x, int y) { return len[x] > len[y]; });
+    TnGroupDesc* table = (TnGroupDesc*)cmpc_ws((size_t)m * sizeof(TnGroupDesc), st);
+    if (!table) return CMPC_EHIP;
+    int items = 0;
+    for (int c0 = 0; c0 < m; c0 += TN_UPLOAD) {
+        TnUploadArgs ua;
+        ua.n = std::min(TN_UPLOAD, m - c0);
+        ua.base = c0;
+        for (int i = 0; i < ua.n; ++i) {
+            ua.d[i] = descs[idx[c0 + i]];
+            ua.d[i].item_begin = items;
+            items += ua.d[i].tiles * ua.d[i].a.rsplit * ua.d[i].a.nb * ua.d[i].a.nb2;
         }
+        hipLaunchKernelGGL(tn_desc_upload_kernel, dim3(1), dim3(256), 0, st, ua, table);
     }
-    return CMPC_OK;
+    const int grid = std::min(items, 512);
+    hipLaunchKernelGGL(gemm_tn_grouped_kernel, dim3(grid), dim3(256), 2 * 2 * TnCfg<bf16_t>::BR * 128 * 2, st, table, m, items);
+    return cmpc_check_launch("gemm_tn_grouped");
 }
 
 extern "C" int cmpc_gemm_tn(const cmpc_gemm_tn_args* a, void* stream) {

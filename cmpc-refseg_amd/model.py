@@ -118,7 +118,10 @@ class LSTM_model(object):
             if key + "/opt" not in LSTM_model._SIDE_STREAMS:
                 LSTM_model._SIDE_STREAMS[key + "/opt"] = torch.cuda.Stream(device=self.device)
             self.opt_stream = LSTM_model._SIDE_STREAMS[key + "/opt"]
-            early = os.environ.get("CMPC_WGRAD_OVERLAP", "1") != "0"
+            # CMPC_WGRAD_OVERLAP=1 starts the weight-gradient flush beside the text encoder's backward.  Off by default:
+            # it gains nothing measurable and in about one run out of three the serial chain of small kernels then
+            # crawls behind the long-running grouped kernel (13.5 -> 51 ms per step; hardware-queue scheduling).
+            early = os.environ.get("CMPC_WGRAD_OVERLAP", "0") != "0"
             self.cx.flush_stream, self.cx.lanes = (self.side[1] if early else None), tuple(self.side)
             if key + "/wg" not in LSTM_model._SIDE_STREAMS:
                 LSTM_model._SIDE_STREAMS[key + "/wg"] = torch.cuda.Stream(device=self.device)
