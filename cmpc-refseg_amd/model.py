@@ -309,6 +309,11 @@ class LSTM_model(object):
         self.store.zero_grads()
         o = self.head(feats, words, seq_len, target_fine, after=after)
         o["loss_all"].backward()
+        if self.marks is not None:
+            self._mark("main_bwd_end")
+            for i, st in enumerate(self.side or ()):
+                with torch.cuda.stream(st):
+                    self._mark("lane%d_bwd_end" % i)
         if self.side is not None:
             # parameter gradients are written by the kernels themselves (not autograd leaves): the
             # optimizer on the main stream must wait for every side stream's backward
