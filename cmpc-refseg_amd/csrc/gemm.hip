@@ -47,39 +47,58 @@ template <> struct Mma<float> {
 // (two 16-B LDS reads, 16-B bias loads, ONE 16-B bf16 store or two fp32 stores per lane and pass)
 __device__ __forceinline__ int slab_col(int row, int col, int WC) { return col ^ ((((row >> 2) & 3) << 4) & (WC - 1)); }
 
-template <typename T, int WR, int WC>
-__device__ __forceinline__ void gemm_nt_epilogue(const cmpc_gemm_nt_args& p, const float* slab, int lane, int row0, int col0, long bz) {
-    constexpr int LPR = WC / 8, RPP = 64 / LPR;
+// The activation is dispatched ONCE (template parameter): with a per-element switch on p.act hipcc emitted a scalar
+// branch tree per element (8 per pass, 8 passes: ~5 us of the 24 us a 256x128 tile takes).  Everything that only
+// depends on the lane's 8 columns (bias, the n_valid mask, tail flags) is hoisted out of the pass loop; row indices
+// are 32-bit (a 64-bit division per pass was the other big cost); the pass loop is fully unrolled so that the LDS
+// reads and the per-sample / accumulate loads of all passes are in flight together.
+template <typename T, int WR, int WC, int ACT>
+__device__ __forceinline__ void gemm_nt_epilogue_act(const cmpc_gemm_nt_args& p, const float* slab, int lane, int row0, int col0, long bz) {
+    constexpr int LPR = WC / 8, RPP = 64 / LPR, NPASS = WR / RPP;
+    const int c8 = (lane % LPR) * 8, gn = col0 + c8, rl = lane / LPR;
+    if (gn >= p.N) return;
+    const bool full = gn + 8 <= p.N;               // N is only guaranteed to be a multiple of 4
     T* Ct = reinterpret_cast<T*>(p.C) + bz * p.sC;
     float* Cf = reinterpret_cast<float*>(p.C) + bz * p.sC;
-    const int rps = p.rows_per_sample > 0 ? p.rows_per_sample : 1;
-#pragma unroll 2
-    for (int pass = 0; pass < WR / RPP; ++pass) {
-        const int row = pass * RPP + lane / LPR, c8 = (lane % LPR) * 8;
-        const int gm = row0 + row, gn = col0 + c8;
-        if (gm >= p.M || gn >= p.N) continue;
+    const bool out_f32 = p.c_f32 || sizeof(T) == 4;
+    float bcol[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    auto addv = [&](float (&d)[8], const float* src) {
+        const float4 t0 = *reinterpret_cast<const float4*>(src);
+        d[0] += t0.x; d[1] += t0.y; d[2] += t0.z; d[3] += t0.w;
+        if (full) { const float4 t1 = *reinterpret_cast<const float4*>(src + 4); d[4] += t1.x; d[5] += t1.y; d[6] += t1.z; d[7] += t1.w; }
+    };
+    if (p.bias) addv(bcol, p.bias + gn);
+    bool ok[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) ok[e] = gn + e < p.n_valid;     // pad columns stay exactly zero
+    const unsigned rps = p.rows_per_sample > 0 ? (unsigned)p.rows_per_sample : 1u;
+    const unsigned rbase = (unsigned)(bz * (long)p.M);            // batch * M < 2^31 for every caller
+    const float alpha = p.alpha;
+#pragma unroll
+    for (int pass = 0; pass < NPASS; ++pass) {
+        const int row = pass * RPP + rl, gm = row0 + row;
+        if (gm >= p.M) continue;
         const float4 va = *reinterpret_cast<const float4*>(slab + row * WC + slab_col(row, c8, WC));
         const float4 vb = *reinterpret_cast<const float4*>(slab + row * WC + slab_col(row, c8 + 4, WC));
         float v[8] = {va.x, va.y, va.z, va.w, vb.x, vb.y, vb.z, vb.w};
-        const long bm = bz * (long)p.M + gm;
-        float bv[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        const bool full = gn + 8 <= p.N;            // N is only guaranteed to be a multiple of 4
-        auto addv = [&](const float* src) {
-            const float4 t0 = *reinterpret_cast<const float4*>(src);
-            bv[0] += t0.x; bv[1] += t0.y; bv[2] += t0.z; bv[3] += t0.w;
-            if (full) { const float4 t1 = *reinterpret_cast<const float4*>(src + 4); bv[4] += t1.x; bv[5] += t1.y; bv[6] += t1.z; bv[7] += t1.w; }
-        };
-        if (p.bias) addv(p.bias + gn);
-        if (p.sbias) addv(p.sbias + (bm / rps) * (long)p.ld_sbias + gn);
-        if (p.pbias) addv(p.pbias + (bm % rps) * (long)p.ld_pbias + gn);
+        float bv[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) bv[e] = bcol[e];
+        if (p.sbias || p.pbias) {
+            const unsigned idx = rbase + (unsigned)gm, smp = idx / rps;
+            if (p.sbias) addv(bv, p.sbias + (long)smp * p.ld_sbias + gn);
+            if (p.pbias) addv(bv, p.pbias + (long)(idx - smp * rps) * p.ld_pbias + gn);
+        }
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-            float x = 0.0f;                        // pad columns stay exactly zero
-            if (gn + e < p.n_valid) x = act_apply(v[e] * p.alpha + bv[e], p.act);
-            v[e] = x;
+            float x = v[e] * alpha + bv[e];
+            if (ACT == ACT_RELU) x = fmaxf(x, 0.0f);
+            else if (ACT == ACT_TANH) x = tanhf(x);
+            else if (ACT == ACT_SIGMOID) x = 1.0f / (1.0f + expf(-x));
+            v[e] = ok[e] ? x : 0.0f;
         }
         const long off = (long)gm * p.ldc + gn;
-        if (p.c_f32 || sizeof(T) == 4) {
+        if (out_f32) {
             float* Cp = p.c_f32 ? Cf + off : reinterpret_cast<float*>(Ct) + off;
             if (p.accumulate) {
                 const float4 o0 = *reinterpret_cast<const float4*>(Cp);
@@ -95,11 +114,21 @@ __device__ __forceinline__ void gemm_nt_epilogue(const cmpc_gemm_nt_args& p, con
 #pragma unroll
                     for (int e = 0; e < 8; ++e) v[e] += o[e]; }
                 st8<bf16_t>(Cb, v);
-            } else {
+            } else {                               // ragged right edge / odd ldc: rare
                 const int ne = full ? 8 : 4;
                 for (int e = 0; e < ne; ++e) { float x = v[e]; if (p.accumulate) x += bf2f(Cb[e]); Cb[e] = f2bf(x); }
             }
         }
+    }
+}
+
+template <typename T, int WR, int WC>
+__device__ __forceinline__ void gemm_nt_epilogue(const cmpc_gemm_nt_args& p, const float* slab, int lane, int row0, int col0, long bz) {
+    switch (p.act) {
+        case ACT_RELU: gemm_nt_epilogue_act<T, WR, WC, ACT_RELU>(p, slab, lane, row0, col0, bz); break;
+        case ACT_TANH: gemm_nt_epilogue_act<T, WR, WC, ACT_TANH>(p, slab, lane, row0, col0, bz); break;
+        case ACT_SIGMOID: gemm_nt_epilogue_act<T, WR, WC, ACT_SIGMOID>(p, slab, lane, row0, col0, bz); break;
+        default: gemm_nt_epilogue_act<T, WR, WC, ACT_NONE>(p, slab, lane, row0, col0, bz); break;
     }
 }
 
@@ -557,7 +586,7 @@ __device__ __forceinline__ int v5_g(int row) { return (4 - ((row >> 2) & 3)) & 3
 __device__ __forceinline__ int v5_lds_off(int row, int c) { return row * 64 + ((c ^ v5_g(row)) << 4); }
 
 template <typename T>
-__global__ __launch_bounds__(512) void gemm_nt_v5_kernel(const cmpc_gemm_nt_args p) {
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void gemm_nt_v5_kernel(const cmpc_gemm_nt_args p) {
     constexpr int BM = 256, BN = 256, ROWB = 64;
     constexpr int EPC = 16 / (int)sizeof(T);
     constexpr int BK = ROWB / (int)sizeof(T);              // 32 bf16
@@ -908,23 +937,24 @@ __global__ __launch_bounds__(512) void conv_v2_kernel(const cmpc_conv_args p) {
     constexpr int LPR = WC / 8, RPP = 64 / LPR;      // 8 columns per lane (Cout % 8 == 0)
     T* Y = reinterpret_cast<T*>(p.Y);
     const T* Rs = reinterpret_cast<const T*>(p.res);
-#pragma unroll 2
-    for (int pass = 0; pass < WR / RPP; ++pass) {
-        const int row = pass * RPP + lane / LPR, c8 = (lane % LPR) * 8;
-        const int gm = m0 + wm * WR + row, gn = n0 + wn * WC + c8;
-        if (gm >= M || gn >= N) continue;
+    const int c8 = (lane % LPR) * 8, gn = n0 + wn * WC + c8, rl = lane / LPR;
+    if (gn >= N) return;
+    float bv[8];
+    ld8<float>(p.bias + gn, bv);                     // column terms once, not once per pass
+    const bool relu = p.relu != 0;
+#pragma unroll
+    for (int pass = 0; pass < WR / RPP; ++pass) {    // fully unrolled: the residual loads of all passes go out together
+        const int row = pass * RPP + rl;
+        const int gm = m0 + wm * WR + row;
+        if (gm >= M) continue;
         const float4 va = *reinterpret_cast<const float4*>(slab + row * WC + slab_col(row, c8, WC));
         const float4 vb = *reinterpret_cast<const float4*>(slab + row * WC + slab_col(row, c8 + 4, WC));
         float v[8] = {va.x, va.y, va.z, va.w, vb.x, vb.y, vb.z, vb.w};
         const long off = (long)gm * p.ldy + gn;
-        float bv[8], rv[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        ld8<float>(p.bias + gn, bv);
+        float rv[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
         if (Rs) ld8<T>(Rs + off, rv);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const float x = v[e] + bv[e] + rv[e];
-            v[e] = p.relu ? fmaxf(x, 0.f) : x;
-        }
+        for (int e = 0; e < 8; ++e) { const float x = v[e] + bv[e] + rv[e]; v[e] = relu ? fmaxf(x, 0.f) : x; }
         st8<T>(Y + off, v);
     }
 }
