@@ -959,6 +959,178 @@ __global__ __launch_bounds__(512) void conv_v2_kernel(const cmpc_conv_args p) {
     }
 }
 
+template <typename T, int BM>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv_v3_kernel(const cmpc_conv_args p) {
+    constexpr int BN = 128;
+    constexpr int EPC = 16 / (int)sizeof(T);
+    constexpr int BK = BKB / (int)sizeof(T);
+    constexpr int WAVES_N = 2, WAVES_M = 4;
+    constexpr int TM = BM / WAVES_M / 16, TN = BN / WAVES_N / 16;
+    constexpr int STAGE = (BM + BN) * BKB;
+    constexpr int APW = BM / 8 / 8, BPW = BN / 8 / 8, LPT = APW + BPW;
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wid / WAVES_N, wn = wid % WAVES_N;
+    const int Ho = (p.H + p.stride - 1) / p.stride, Wo = (p.W + p.stride - 1) / p.stride;
+    const int M = p.B * Ho * Wo, N = p.Cout;
+    const int gx = (N + BN - 1) / BN, nwg = gridDim.x;
+    const int xq = nwg >> 3, xr = nwg & 7, xcd = blockIdx.x & 7, xi = blockIdx.x >> 3;
+    const int tix = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + xi;
+    const int m0 = (tix / gx) * BM, n0 = (tix % gx) * BN;
+    const int kpt = p.Cin / BK;                       // K-tiles per tap
+    const int ntot = p.ksize * p.ksize * kpt;
+    // TF SAME: total pad = max((out-1)*stride + (k-1)*dil + 1 - in, 0), before = total / 2
+    const int padh = max((Ho - 1) * p.stride + (p.ksize - 1) * p.dil + 1 - p.H, 0) / 2;
+    const int padw = max((Wo - 1) * p.stride + (p.ksize - 1) * p.dil + 1 - p.W, 0) / 2;
+
+    f4 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = f4{0.f, 0.f, 0.f, 0.f};
+
+    const int r8 = lane >> 3, slot = lane & 7;
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+    // this lane's output pixel for each of the wave's A pieces
+    int pb[APW], py[APW], px[APW], pc[APW];
+#pragma unroll
+    for (int j = 0; j < APW; ++j) {
+        const int blk = wid * APW + j, row = blk * 8 + r8;
+        const int gm = min(m0 + row, M - 1);
+        pb[j] = gm / (Ho * Wo);
+        const int rem = gm - pb[j] * (Ho * Wo);
+        py[j] = (rem / Wo) * p.stride - padh;
+        px[j] = (rem % Wo) * p.stride - padw;
+        pc[j] = (slot ^ ((row >> 1) & 7)) * EPC;
+    }
+    const T* X = reinterpret_cast<const T*>(p.X);
+    const T* Wt = reinterpret_cast<const T*>(p.Wt);
+    const T* Z = reinterpret_cast<const T*>(p.zeros);
+    // Issue cursor (tap, k0): the per-lane source pointers of the current tap live in registers and are recomputed
+    // only when the tap changes (out-of-image taps point at the zero page and do not advance with k0).
+    const T* pa[APW];
+    const T* pw[BPW];
+    int kadv[APW];
+    int tap = 0, k0 = 0;
+    auto load_tap = [&]() {
+        const int dy = (tap / p.ksize) * p.dil, dx = (tap % p.ksize) * p.dil;
+#pragma unroll
+        for (int j = 0; j < APW; ++j) {
+            const int yi = py[j] + dy, xi2 = px[j] + dx;
+            const bool ok = yi >= 0 && yi < p.H && xi2 >= 0 && xi2 < p.W;
+            pa[j] = ok ? X + ((long)(pb[j] * p.H + yi) * p.W + xi2) * p.ldx + pc[j] : Z + pc[j];
+            kadv[j] = ok ? 1 : 0;
+        }
+#pragma unroll
+        for (int j = 0; j < BPW; ++j) {
+            const int row = (wid * BPW + j) * 8 + r8;
+            const int gn = min(n0 + row, N - 1);
+            pw[j] = Wt + (long)gn * p.ldw + tap * p.Cin + (slot ^ ((row >> 1) & 7)) * EPC;
+        }
+    };
+    load_tap();
+    auto issue_next = [&](int buf) {
+        const uint32_t base = lds0 + buf * STAGE;
+#pragma unroll
+        for (int j = 0; j < APW; ++j)
+            glds16(pa[j] + kadv[j] * k0, __builtin_amdgcn_readfirstlane(base + (wid * APW + j) * 1024));
+#pragma unroll
+        for (int j = 0; j < BPW; ++j)
+            glds16(pw[j] + k0, __builtin_amdgcn_readfirstlane(base + BM * BKB + (wid * BPW + j) * 1024));
+        k0 += BK;
+        if (k0 == p.Cin) { k0 = 0; ++tap; if (tap < p.ksize * p.ksize) load_tap(); }
+    };
+    const int fr = lane & 15, fq = lane >> 4;
+    auto read_frags = [&](int buf, int sidx, uint4 (&a)[TM], uint4 (&b)[TN]) {
+        const char* sA = smem + buf * STAGE;
+        const char* sB = sA + BM * BKB;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+            a[i] = *reinterpret_cast<const uint4*>(sA + nt_lds_off(wm * TM * 16 + i * 16 + fr, 4 * sidx + fq));
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+            b[j] = *reinterpret_cast<const uint4*>(sB + nt_lds_off(wn * TN * 16 + j * 16 + fr, 4 * sidx + fq));
+    };
+    auto mma_all = [&](const uint4 (&a)[TM], const uint4 (&b)[TN]) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) acc[i][j] = Mma<T>::run(a[i], b[j], acc[i][j]);
+    };
+
+    // same pipeline as gemm_nt_v4: three k-tiles of loads in flight, fragments of the next half k-tile read before
+    // the MFMAs of the current one, last k-tile peeled
+    if (ntot > 0) issue_next(0);
+    if (ntot > 1) issue_next(1);
+    if (ntot > 2) issue_next(2);
+    if (ntot > 2) wait_vmcnt<2 * LPT>(); else if (ntot > 1) wait_vmcnt<LPT>(); else wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();
+    uint4 a0[TM], b0[TN], a1[TM], b1[TN];
+    if (ntot > 0) read_frags(0, 0, a0, b0);
+    int cur = 0;
+    for (int kt = 0; kt + 1 < ntot; ++kt) {
+        read_frags(cur, 1, a1, b1);
+        __builtin_amdgcn_sched_barrier(0);
+        mma_all(a0, b0);
+        __builtin_amdgcn_sched_barrier(0);
+        const int nxt = (cur == 2) ? 0 : cur + 1;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (kt + 2 < ntot) wait_vmcnt<LPT>(); else wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();
+        if (kt + 3 < ntot) issue_next(cur);
+        read_frags(nxt, 0, a0, b0);
+        __builtin_amdgcn_sched_barrier(0);
+        mma_all(a1, b1);
+        __builtin_amdgcn_sched_barrier(0);
+        cur = nxt;
+    }
+    if (ntot > 0) {
+        read_frags(cur, 1, a1, b1);
+        mma_all(a0, b0);
+        mma_all(a1, b1);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+
+    constexpr int WR = TM * 16, WC = TN * 16;
+    float* slab = reinterpret_cast<float*>(smem) + wid * (WR * WC);
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = i * 16 + fq * 4 + r, col = j * 16 + fr;
+                slab[row * WC + (col ^ (((row >> 2) & 3) << 4))] = acc[i][j][r];
+            }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+    constexpr int LPR = WC / 8, RPP = 64 / LPR;      // 8 columns per lane (Cout % 8 == 0)
+    T* Y = reinterpret_cast<T*>(p.Y);
+    const T* Rs = reinterpret_cast<const T*>(p.res);
+    const int c8 = (lane % LPR) * 8, gn = n0 + wn * WC + c8, rl = lane / LPR;
+    if (gn >= N) return;
+    float bv[8];
+    ld8<float>(p.bias + gn, bv);                     // column terms once, not once per pass
+    const bool relu = p.relu != 0;
+#pragma unroll
+    for (int pass = 0; pass < WR / RPP; ++pass) {    // fully unrolled: the residual loads of all passes go out together
+        const int row = pass * RPP + rl;
+        const int gm = m0 + wm * WR + row;
+        if (gm >= M) continue;
+        const float4 va = *reinterpret_cast<const float4*>(slab + row * WC + slab_col(row, c8, WC));
+        const float4 vb = *reinterpret_cast<const float4*>(slab + row * WC + slab_col(row, c8 + 4, WC));
+        float v[8] = {va.x, va.y, va.z, va.w, vb.x, vb.y, vb.z, vb.w};
+        const long off = (long)gm * p.ldy + gn;
+        float rv[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        if (Rs) ld8<T>(Rs + off, rv);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { const float x = v[e] + bv[e] + rv[e]; v[e] = relu ? fmaxf(x, 0.f) : x; }
+        st8<T>(Y + off, v);
+    }
+}
+
 // ------------------------------------------------------------------------------------------
 // gemm_tn: out[k,n] += alpha * sum_r A[r,k] * D[r,n]
 // LDS image [BR][128 elems] per operand, 32-B segments XOR-swizzled so that the transposing
@@ -1427,10 +1599,20 @@ static int launch_conv(const cmpc_conv_args* a, hipStream_t st) {
     if (big) {
         static bool attr = false;
         if (!attr) { (void)hipFuncSetAttribute((const void*)conv_v2_kernel<T, 256>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * (256 + 128) * BKB); attr = true; }
+        if (!getenv("CMPC_CONV_V2")) {
+            static bool attr3 = false;
+            if (!attr3) { (void)hipFuncSetAttribute((const void*)conv_v3_kernel<T, 256>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * (256 + 128) * BKB); attr3 = true; }
+            hipLaunchKernelGGL((conv_v3_kernel<T, 256>), dim3((unsigned)(((M + 255) / 256) * gn)), dim3(512), 3 * (256 + 128) * BKB, st, *a);
+        } else
         hipLaunchKernelGGL((conv_v2_kernel<T, 256>), dim3((unsigned)(((M + 255) / 256) * gn)), dim3(512), 3 * (256 + 128) * BKB, st, *a);
     } else {
         static bool attr = false;
         if (!attr) { (void)hipFuncSetAttribute((const void*)conv_v2_kernel<T, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * (128 + 128) * BKB); attr = true; }
+        if (!getenv("CMPC_CONV_V2")) {
+            static bool attr3 = false;
+            if (!attr3) { (void)hipFuncSetAttribute((const void*)conv_v3_kernel<T, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * (128 + 128) * BKB); attr3 = true; }
+            hipLaunchKernelGGL((conv_v3_kernel<T, 128>), dim3((unsigned)(((M + 127) / 128) * gn)), dim3(512), 3 * (128 + 128) * BKB, st, *a);
+        } else
         hipLaunchKernelGGL((conv_v2_kernel<T, 128>), dim3((unsigned)(((M + 127) / 128) * gn)), dim3(512), 3 * (128 + 128) * BKB, st, *a);
     }
     return cmpc_check_launch("conv_nhwc");
