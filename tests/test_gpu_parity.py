@@ -280,6 +280,20 @@ def test_graph_replay_equals_eager(case):
         assert float((sa[n] - sb[n]).abs().max()) <= 0.05 * lr, n
 
 
+def test_train_steps_do_not_leak(case):
+    """Device memory is flat across train steps (the stage operators keep detached aliases of their outputs: an output
+    kept on ctx as the same object is an uncollectable cycle, which leaked 1.1 GiB per full-size step)."""
+    import gc
+    m = _model(case, "bf16")
+    used = []
+    for step in range(7):
+        m.train_step(case["words"], case["im"], case["tgt"], case["sl"])
+        torch.cuda.synchronize()
+        gc.collect()
+        used.append(torch.cuda.memory_allocated())
+    assert used[6] == used[3] == used[4], used
+
+
 def test_facade_contract_and_errors(case):
     cfg = case["cfg"]
     m = _model(case, "f32", mode="eval")
