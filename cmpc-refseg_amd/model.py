@@ -99,6 +99,8 @@ class LSTM_model(object):
         self._opt_pending = False
         self._opt_stage0 = None
         self._inflight = []
+        self._bb_graph_on = os.environ.get("CMPC_BACKBONE_GRAPH", "1") != "0"
+        self._bb = {"calls": 0, "next": 0, "graph": [None, None], "inp": [None, None], "out": [None, None]}
         self.marks = [] if os.environ.get("CMPC_MARKS") else None
         # the three pyramid levels (and the three exchange modules of a round) are independent: each gets
         # its own HIP stream so HBM-bound stage kernels of one level overlap MFMA-bound GEMMs of another.
@@ -191,6 +193,13 @@ class LSTM_model(object):
             st.wait_event(ready)
         else:
             st.wait_stream(main)
+        if self._bb_graph_on and not self.use_graph and not torch.cuda.is_current_stream_capturing():
+            with torch.cuda.stream(st):
+                feats = self._backbone_graphed(im, st)
+                self._mark("backbone")
+            im.record_stream(st)
+            if feats is not None:
+                return feats, st
         with torch.cuda.stream(st):
             feats = self.backbone(im)
             self._mark("backbone")
@@ -200,6 +209,30 @@ class LSTM_model(object):
                 f.record_stream(s2)
         im.record_stream(st)
         return feats, st
+
+    def _backbone_graphed(self, im, st):
+        """The frozen backbone is a static single-stream chain of ~105 launches: after two eager passes it is replayed
+        from a captured HIP graph (the host then spends ~0.1 ms on it instead of ~2.7 ms; a single-stream graph replays
+        at eager speed on the GPU).  Two graphs with their own static input / output buffers alternate: the taps of step n
+        are read until the end of step n (lateral weight gradients) while step n+1's pass may already be running.
+        Returns None while still warming up (caller runs eagerly)."""
+        bb = self._bb
+        if bb["calls"] < 2:
+            bb["calls"] += 1
+            return None
+        k = bb["next"]
+        bb["next"] = 1 - k
+        if bb["graph"][k] is None:
+            inp = torch.empty_like(im)
+            inp.copy_(im)
+            torch.cuda.synchronize(self.device)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, stream=st):
+                out = self.backbone(inp)
+            bb["graph"][k], bb["inp"][k], bb["out"][k] = g, inp, out
+        bb["inp"][k].copy_(im, non_blocking=True)
+        bb["graph"][k].replay()
+        return bb["out"][k]
 
     def head(self, feats, words, seq_len, target=None, after=None):
         """build_graph() on given backbone taps (CMPC_model.py:89-142).  Returns the fetch dict.
