@@ -1459,18 +1459,20 @@ __global__ __launch_bounds__(256) void gemm_nt_skinny_f32_kernel(const cmpc_gemm
         const long lda = p.lda[s], ldb = p.ldb[s];
         const int K = p.K[s];
         for (int k = (wid * 64 + lane) * 4; k < K; k += 1024) {
-            float4 w[NC];
+            // Unconditional loads from clamped rows (results of rows >= M / columns >= N are never stored): with a
+            // branch around each load hipcc waited for every one of them in turn -- 8 dependent L2 round trips, about
+            // 8 of the 14 us this latency-bound kernel took.
+            float4 w[NC], a[MMAX];
 #pragma unroll
             for (int c = 0; c < NC; ++c)
-                w[c] = (n0 + c < p.N) ? *reinterpret_cast<const float4*>(Bt + (n0 + c) * ldb + k) : make_float4(0.f, 0.f, 0.f, 0.f);
+                w[c] = *reinterpret_cast<const float4*>(Bt + (long)min(n0 + c, p.N - 1) * ldb + k);
 #pragma unroll
-            for (int m = 0; m < MMAX; ++m) {
-                if (m < p.M) {
-                    const float4 a = *reinterpret_cast<const float4*>(A + m * lda + k);
+            for (int m = 0; m < MMAX; ++m)
+                a[m] = *reinterpret_cast<const float4*>(A + (long)min(m, p.M - 1) * lda + k);
 #pragma unroll
-                    for (int c = 0; c < NC; ++c) acc[m][c] += a.x * w[c].x + a.y * w[c].y + a.z * w[c].z + a.w * w[c].w;
-                }
-            }
+            for (int m = 0; m < MMAX; ++m)
+#pragma unroll
+                for (int c = 0; c < NC; ++c) acc[m][c] += a[m].x * w[c].x + a[m].y * w[c].y + a[m].z * w[c].z + a[m].w * w[c].w;
         }
     }
 #pragma unroll
@@ -1485,17 +1487,21 @@ __global__ __launch_bounds__(256) void gemm_nt_skinny_f32_kernel(const cmpc_gemm
     if (t >= MMAX * NC) return;
     const int m = t / NC, c = t % NC, gn = n0 + c;
     if (m >= p.M || gn >= p.N) return;
+    // the optional terms are loaded unconditionally (absent ones from a dummy readable address, then dropped by a
+    // select), so that the loads are ONE round trip instead of up to four dependent ones
+    float* C = reinterpret_cast<float*>(p.C) + (long)m * p.ldc + gn;
+    const int rps = p.rows_per_sample > 0 ? p.rows_per_sample : 1;
+    const float* pb0 = p.bias ? p.bias + gn : C;
+    const float* pb1 = p.sbias ? p.sbias + (m / rps) * (long)p.ld_sbias + gn : C;
+    const float* pb2 = p.pbias ? p.pbias + (m % rps) * (long)p.ld_pbias + gn : C;
+    const float b0 = *pb0, b1 = *pb1, b2 = *pb2, old = *C;
     float x = 0.f;
     if (gn < p.n_valid) {
         x = (red[0][t] + red[1][t] + red[2][t] + red[3][t]) * p.alpha;
-        const int rps = p.rows_per_sample > 0 ? p.rows_per_sample : 1;
-        if (p.bias) x += p.bias[gn];
-        if (p.sbias) x += p.sbias[(m / rps) * (long)p.ld_sbias + gn];
-        if (p.pbias) x += p.pbias[(m % rps) * (long)p.ld_pbias + gn];
+        x += (p.bias ? b0 : 0.f) + (p.sbias ? b1 : 0.f) + (p.pbias ? b2 : 0.f);
         x = act_apply(x, p.act);
     }
-    float* C = reinterpret_cast<float*>(p.C) + (long)m * p.ldc + gn;
-    if (p.accumulate) x += *C;
+    if (p.accumulate) x += old;
     *C = x;
 }
 
