@@ -11,7 +11,10 @@ __host__ inline int rows_grid(int N, int cap) { int g = (N + WPB - 1) / WPB; ret
 // ------------------------------------------------------------------------------------------
 // mutan_fusion (CMPC_model.py:295-328)
 // ------------------------------------------------------------------------------------------
-template <typename T>
+// FULL = (ld == MB * 512): every lane owns live columns in every block, so the `c0 < ld` guards vanish at compile time.
+// With the guards each (head, block) piece is its own exec-masked region and hipcc waits for its load before the next
+// region's load is issued: ten dependent round trips per row (mutan_bwd ran at 2.1 TB/s).
+template <typename T, bool FULL>
 __global__ __launch_bounds__(256) void mutan_fwd_kernel(T* __restrict__ P, const float* __restrict__ g, T* __restrict__ X1,
                                                        float* __restrict__ rstd, int N, int ld, int C) {
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, b = blockIdx.y;
@@ -23,7 +26,7 @@ __global__ __launch_bounds__(256) void mutan_fwd_kernel(T* __restrict__ P, const
 #pragma unroll
         for (int k = 0; k < MB; ++k) {
             const int c0 = k * 512 + lane * 8;
-            if (c0 < ld) ld8<float>(gb + h * ld + c0, gv[h][k]);
+            if (FULL || c0 < ld) ld8<float>(gb + h * ld + c0, gv[h][k]);
             else {
 #pragma unroll
                 for (int e = 0; e < 8; ++e) gv[h][k][e] = 0.f;
@@ -37,21 +40,29 @@ __global__ __launch_bounds__(256) void mutan_fwd_kernel(T* __restrict__ P, const
         for (int k = 0; k < MB; ++k)
 #pragma unroll
             for (int e = 0; e < 8; ++e) q[k][e] = 0.f;
+        // all ten pieces of the row are loaded before the first in-place store: load -> tanh -> store per piece was a
+        // chain of ten dependent round trips (the compiler cannot move a load above a store to the same array)
+        float pv[5][MB][8];
+#pragma unroll
+        for (int h = 0; h < 5; ++h)
+#pragma unroll
+            for (int k = 0; k < MB; ++k) {
+                const int c0 = k * 512 + lane * 8;
+                if (FULL || c0 < ld) ld8<T>(Pr + h * ld + c0, pv[h][k]);
+            }
 #pragma unroll
         for (int h = 0; h < 5; ++h) {
 #pragma unroll
             for (int k = 0; k < MB; ++k) {
                 const int c0 = k * 512 + lane * 8;
-                if (c0 < ld) {
-                    float pv[8];
-                    ld8<T>(Pr + h * ld + c0, pv);
+                if (FULL || c0 < ld) {
 #pragma unroll
                     for (int e = 0; e < 8; ++e) {
-                        const float th = (c0 + e < C) ? tanhf(pv[e]) : 0.f;
-                        pv[e] = th;
+                        const float th = (c0 + e < C) ? tanhf(pv[h][k][e]) : 0.f;
+                        pv[h][k][e] = th;
                         q[k][e] += th * gv[h][k][e];
                     }
-                    st8<T>(Pr + h * ld + c0, pv);
+                    st8<T>(Pr + h * ld + c0, pv[h][k]);
                 }
             }
         }
@@ -70,7 +81,7 @@ __global__ __launch_bounds__(256) void mutan_fwd_kernel(T* __restrict__ P, const
 #pragma unroll
         for (int k = 0; k < MB; ++k) {
             const int c0 = k * 512 + lane * 8;
-            if (c0 < ld) {
+            if (FULL || c0 < ld) {
 #pragma unroll
                 for (int e = 0; e < 8; ++e) q[k][e] *= rs;
                 st8<T>(X1 + r * ld + c0, q[k]);
@@ -80,7 +91,7 @@ __global__ __launch_bounds__(256) void mutan_fwd_kernel(T* __restrict__ P, const
     }
 }
 
-template <typename T>
+template <typename T, bool FULL>
 __global__ __launch_bounds__(256) void mutan_bwd_kernel(T* __restrict__ Th, const float* __restrict__ g, const T* __restrict__ X1,
                                                        const float* __restrict__ rstd, const T* __restrict__ dX1, float* part,
                                                        int N, int ld, int C) {
@@ -93,7 +104,7 @@ __global__ __launch_bounds__(256) void mutan_bwd_kernel(T* __restrict__ Th, cons
 #pragma unroll
         for (int k = 0; k < MB; ++k) {
             const int c0 = k * 512 + lane * 8;
-            if (c0 < ld) ld8<float>(gb + h * ld + c0, gv[h][k]);
+            if (FULL || c0 < ld) ld8<float>(gb + h * ld + c0, gv[h][k]);
             else {
 #pragma unroll
                 for (int e = 0; e < 8; ++e) gv[h][k][e] = 0.f;
@@ -113,7 +124,7 @@ __global__ __launch_bounds__(256) void mutan_bwd_kernel(T* __restrict__ Th, cons
 #pragma unroll
         for (int k = 0; k < MB; ++k) {
             const int c0 = k * 512 + lane * 8;
-            if (c0 < ld) {
+            if (FULL || c0 < ld) {
                 ld8<T>(dX1 + r * ld + c0, d[k]); ld8<T>(X1 + r * ld + c0, xv[k]);
 #pragma unroll
                 for (int e = 0; e < 8; ++e) { if (c0 + e >= C) d[k][e] = 0.f; dot += d[k][e] * xv[k][e]; }
@@ -135,21 +146,23 @@ __global__ __launch_bounds__(256) void mutan_bwd_kernel(T* __restrict__ Th, cons
                 d[k][e] = a * (d[k][e] - xv[k][e] * dot) * (1.f - tq * tq);
             }
         T* Tr = Th + r * 5 * ld;
+        // per column block: the five heads' pieces are loaded before the first in-place store (see mutan_fwd)
 #pragma unroll
-        for (int h = 0; h < 5; ++h) {
+        for (int k = 0; k < MB; ++k) {
+            const int c0 = k * 512 + lane * 8;
+            if (FULL || c0 < ld) {
+                float tv[5][8];
 #pragma unroll
-            for (int k = 0; k < MB; ++k) {
-                const int c0 = k * 512 + lane * 8;
-                if (c0 < ld) {
-                    float tv[8];
-                    ld8<T>(Tr + h * ld + c0, tv);
+                for (int h = 0; h < 5; ++h) ld8<T>(Tr + h * ld + c0, tv[h]);
+#pragma unroll
+                for (int h = 0; h < 5; ++h) {
 #pragma unroll
                     for (int e = 0; e < 8; ++e) {
-                        const float th = tv[e];
+                        const float th = tv[h][e];
                         acc[h][k][e] += d[k][e] * th;
-                        tv[e] = (c0 + e < C) ? d[k][e] * gv[h][k][e] * (1.f - th * th) : 0.f;
+                        tv[h][e] = (c0 + e < C) ? d[k][e] * gv[h][k][e] * (1.f - th * th) : 0.f;
                     }
-                    st8<T>(Tr + h * ld + c0, tv);
+                    st8<T>(Tr + h * ld + c0, tv[h]);
                 }
             }
         }
@@ -160,7 +173,7 @@ __global__ __launch_bounds__(256) void mutan_bwd_kernel(T* __restrict__ Th, cons
 #pragma unroll
         for (int k = 0; k < MB; ++k) {
             const int c0 = k * 512 + lane * 8;
-            if (c0 < ld) {
+            if (FULL || c0 < ld) {
 #pragma unroll
                 for (int e = 0; e < 8; ++e) lds[w * ld + c0 + e] = acc[h][k][e];
             }
@@ -487,7 +500,10 @@ bool map_ok(const char* what, int ld, int C, int dt) {
 
 extern "C" int cmpc_mutan_fwd(int dt, void* P, const float* g, void* X1, float* rstd, int B, int N, int ld, int C, void* stream) {
     if (!map_ok("mutan_fwd", ld, C, dt)) return CMPC_EINVAL;
-    CMPC_DISPATCH_DT(dt, hipLaunchKernelGGL((mutan_fwd_kernel<T>), dim3(rows_grid(N, 400), B), dim3(256), 0, ST, (T*)P, g, (T*)X1, rstd, N, ld, C));
+    CMPC_DISPATCH_DT(dt, {
+        if (ld == MB * 512) hipLaunchKernelGGL((mutan_fwd_kernel<T, true>), dim3(rows_grid(N, 400), B), dim3(256), 0, ST, (T*)P, g, (T*)X1, rstd, N, ld, C);
+        else hipLaunchKernelGGL((mutan_fwd_kernel<T, false>), dim3(rows_grid(N, 400), B), dim3(256), 0, ST, (T*)P, g, (T*)X1, rstd, N, ld, C);
+    });
     return cmpc_check_launch("mutan_fwd");
 }
 
@@ -497,8 +513,12 @@ extern "C" int cmpc_mutan_bwd(int dt, void* Th, const float* g, const void* X1, 
     const int gx = rows_grid(N, 64);
     float* part = (float*)cmpc_ws((size_t)B * gx * 5 * ld * sizeof(float), ST);
     if (!part) return CMPC_EHIP;
-    CMPC_DISPATCH_DT(dt, hipLaunchKernelGGL((mutan_bwd_kernel<T>), dim3(gx, B), dim3(256), WPB * ld * sizeof(float), ST,
-                                             (T*)Th, g, (const T*)X1, rstd, (const T*)dX1, part, N, ld, C));
+    CMPC_DISPATCH_DT(dt, {
+        if (ld == MB * 512) hipLaunchKernelGGL((mutan_bwd_kernel<T, true>), dim3(gx, B), dim3(256), WPB * ld * sizeof(float), ST,
+                                               (T*)Th, g, (const T*)X1, rstd, (const T*)dX1, part, N, ld, C);
+        else hipLaunchKernelGGL((mutan_bwd_kernel<T, false>), dim3(gx, B), dim3(256), WPB * ld * sizeof(float), ST,
+                                (T*)Th, g, (const T*)X1, rstd, (const T*)dX1, part, N, ld, C);
+    });
     if (cmpc_reduce_parts_f32(part, 5L * ld, B, gx, 5, ld, C, dg, 5L * ld, ld, 1, ST)) return CMPC_EHIP;
     return cmpc_check_launch("mutan_bwd");
 }
