@@ -52,7 +52,7 @@ __device__ __forceinline__ int slab_col(int row, int col, int WC) { return col ^
 // depends on the lane's 8 columns (bias, the n_valid mask, tail flags) is hoisted out of the pass loop; row indices
 // are 32-bit (a 64-bit division per pass was the other big cost); the pass loop is fully unrolled so that the LDS
 // reads and the per-sample / accumulate loads of all passes are in flight together.
-template <typename T, int WR, int WC, int ACT>
+template <typename T, int WR, int WC, int ACT, int UNR>
 __device__ __forceinline__ void gemm_nt_epilogue_act(const cmpc_gemm_nt_args& p, const float* slab, int lane, int row0, int col0, long bz) {
     constexpr int LPR = WC / 8, RPP = 64 / LPR, NPASS = WR / RPP;
     const int c8 = (lane % LPR) * 8, gn = col0 + c8, rl = lane / LPR;
@@ -74,7 +74,7 @@ __device__ __forceinline__ void gemm_nt_epilogue_act(const cmpc_gemm_nt_args& p,
     const unsigned rps = p.rows_per_sample > 0 ? (unsigned)p.rows_per_sample : 1u;
     const unsigned rbase = (unsigned)(bz * (long)p.M);            // batch * M < 2^31 for every caller
     const float alpha = p.alpha;
-#pragma unroll
+#pragma unroll UNR
     for (int pass = 0; pass < NPASS; ++pass) {
         const int row = pass * RPP + rl, gm = row0 + row;
         if (gm >= p.M) continue;
@@ -122,13 +122,15 @@ __device__ __forceinline__ void gemm_nt_epilogue_act(const cmpc_gemm_nt_args& p,
     }
 }
 
-template <typename T, int WR, int WC>
+// UNR: how many passes are unrolled together (all of them when the accumulators are dead; 2 in the 256 x 256 kernel,
+// where the second half's 64 accumulator registers are still live during the first half's epilogue)
+template <typename T, int WR, int WC, int UNR = 64>
 __device__ __forceinline__ void gemm_nt_epilogue(const cmpc_gemm_nt_args& p, const float* slab, int lane, int row0, int col0, long bz) {
     switch (p.act) {
-        case ACT_RELU: gemm_nt_epilogue_act<T, WR, WC, ACT_RELU>(p, slab, lane, row0, col0, bz); break;
-        case ACT_TANH: gemm_nt_epilogue_act<T, WR, WC, ACT_TANH>(p, slab, lane, row0, col0, bz); break;
-        case ACT_SIGMOID: gemm_nt_epilogue_act<T, WR, WC, ACT_SIGMOID>(p, slab, lane, row0, col0, bz); break;
-        default: gemm_nt_epilogue_act<T, WR, WC, ACT_NONE>(p, slab, lane, row0, col0, bz); break;
+        case ACT_RELU: gemm_nt_epilogue_act<T, WR, WC, ACT_RELU, UNR>(p, slab, lane, row0, col0, bz); break;
+        case ACT_TANH: gemm_nt_epilogue_act<T, WR, WC, ACT_TANH, UNR>(p, slab, lane, row0, col0, bz); break;
+        case ACT_SIGMOID: gemm_nt_epilogue_act<T, WR, WC, ACT_SIGMOID, UNR>(p, slab, lane, row0, col0, bz); break;
+        default: gemm_nt_epilogue_act<T, WR, WC, ACT_NONE, UNR>(p, slab, lane, row0, col0, bz); break;
     }
 }
 
@@ -278,6 +280,13 @@ __device__ __forceinline__ void glds16(const void* gsrc, uint32_t lds_dst) {
     uint32_t keep;
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+
+// Same with a wave-uniform 64-bit base (SGPR pair) plus a 32-bit per-lane byte offset: half the address VGPRs.
+__device__ __forceinline__ void glds16s(const void* sbase, uint32_t voff, uint32_t lds_dst) {
+    uint32_t keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds_dst) : "memory");
 }
 
 template <typename T, int BM>
@@ -618,55 +627,96 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 
     const int r16 = lane >> 2, slot = lane & 3;
     const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
-    auto issue = [&](int tile, int buf) {
-        int s = 0, t = tile;
-        if (t >= ntile[0]) { t -= ntile[0]; s = 1; if (t >= ntile[1]) { t -= ntile[1]; s = 2; } }
-        const T* Ap = reinterpret_cast<const T*>(p.A[s]) + bz * p.sA[s];
-        const T* Bp = reinterpret_cast<const T*>(p.Bt[s]) + bz * p.sB[s];
-        const long lda = p.lda[s], ldb = p.ldb[s];
-        const int k0 = t * BK;
-        const uint32_t base = lds0 + buf * STAGE;
+    // issue cursor with the per-lane row pointers of the current K-segment in registers (as in v4)
+    // wave-uniform segment bases (SGPR pairs) + 32-bit per-lane byte offsets (an operand of this path is < 4 GiB)
+    const T* sA;
+    const T* sB;
+    uint32_t oa[APW], ob[BPW];
+    int iseg = 0, itile = 0, seg_left = ntile[0];
+    auto load_seg = [&](const int sg) {
+        sA = reinterpret_cast<const T*>(p.A[sg]) + bz * p.sA[sg];
+        sB = reinterpret_cast<const T*>(p.Bt[sg]) + bz * p.sB[sg];
+        const int lda = p.lda[sg], ldb = p.ldb[sg];
 #pragma unroll
         for (int j = 0; j < APW; ++j) {
-            const int blk = wid * APW + j, row = blk * 16 + r16;
-            const int c = slot ^ v5_g(row);
-            const int gm = min(m0 + row, p.M - 1);           // rows past M: any valid address (never stored)
-            glds16(Ap + gm * lda + k0 + c * EPC, __builtin_amdgcn_readfirstlane(base + blk * 1024));
+            const int row = (wid * APW + j) * 16 + r16;
+            oa[j] = (uint32_t)((min(m0 + row, p.M - 1) * (long)lda + (slot ^ v5_g(row)) * EPC) * (long)sizeof(T));   // rows past M: any valid address
         }
 #pragma unroll
         for (int j = 0; j < BPW; ++j) {
-            const int blk = wid * BPW + j, row = blk * 16 + r16;
-            const int c = slot ^ v5_g(row);
-            const int gn = min(n0 + row, p.N - 1);
-            glds16(Bp + gn * ldb + k0 + c * EPC, __builtin_amdgcn_readfirstlane(base + BM * ROWB + blk * 1024));
+            const int row = (wid * BPW + j) * 16 + r16;
+            ob[j] = (uint32_t)((min(n0 + row, p.N - 1) * (long)ldb + (slot ^ v5_g(row)) * EPC) * (long)sizeof(T));
         }
     };
-
-    if (ntot > 0) issue(0, 0);
-    if (ntot > 1) issue(1, 1);
-    if (ntot > 2) issue(2, 2);
+    load_seg(0);
+    auto issue_next = [&](int buf) {
+        const int k0 = itile * BK;
+        const uint32_t base = lds0 + buf * STAGE;
+#pragma unroll
+        for (int j = 0; j < APW; ++j)
+            glds16s(sA + k0, oa[j], __builtin_amdgcn_readfirstlane(base + (wid * APW + j) * 1024));
+#pragma unroll
+        for (int j = 0; j < BPW; ++j)
+            glds16s(sB + k0, ob[j], __builtin_amdgcn_readfirstlane(base + BM * ROWB + (wid * BPW + j) * 1024));
+        ++itile;
+        if (--seg_left == 0) {
+            itile = 0;
+            ++iseg;
+            if (iseg == 1 && p.nseg > 1) { seg_left = ntile[1]; load_seg(1); }
+            else if (iseg == 2 && p.nseg > 2) { seg_left = ntile[2]; load_seg(2); }
+        }
+    };
     const int fr = lane & 15, fq = lane >> 4;
+    auto read_b = [&](int buf, uint4 (&b)[TN]) {
+        const char* sB = smem + buf * STAGE + BM * ROWB;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) b[j] = *reinterpret_cast<const uint4*>(sB + v5_lds_off(wn * (TN * 16) + j * 16 + fr, fq));
+    };
+    auto read_a = [&](int buf, int half, uint4 (&a)[4]) {
+        const char* sA = smem + buf * STAGE;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) a[i] = *reinterpret_cast<const uint4*>(sA + v5_lds_off(wm * (TM * 16) + (half * 4 + i) * 16 + fr, fq));
+    };
+    auto mma_half = [&](int half, const uint4 (&a)[4], const uint4 (&b)[TN]) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) acc[half * 4 + i][j] = Mma<T>::run(a[i], b[j], acc[half * 4 + i][j]);
+    };
+
+    // Pipeline: three k-tiles of loads in flight (4 stages); per k-tile the wave's 32 MFMAs run as two halves of 16
+    // with the LDS reads of the NEXT half issued in front of each (A rows 64-127 of this tile; then B and A rows 0-63 of
+    // the next tile, which the barrier in between has just published).
+    if (ntot > 0) issue_next(0);
+    if (ntot > 1) issue_next(1);
+    if (ntot > 2) issue_next(2);
+    if (ntot > 2) wait_vmcnt<2 * LPT>(); else if (ntot > 1) wait_vmcnt<LPT>(); else wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();
+    TRACE_MARK(1);
+    uint4 alo[4], ahi[4], bb[TN];
+    if (ntot > 0) { read_b(0, bb); read_a(0, 0, alo); }
     int cur = 0;
-    for (int kt = 0; kt < ntot; ++kt) {
-        // tile kt must have landed; the (up to) two younger ones stay in flight
-        if (kt + 2 < ntot) wait_vmcnt<2 * LPT>(); else if (kt + 1 < ntot) wait_vmcnt<LPT>(); else wait_vmcnt<0>();
+    for (int kt = 0; kt + 1 < ntot; ++kt) {
+        if (kt + 3 < ntot) issue_next((cur + 3) & 3);           // buffer of tile kt-1: free since the previous barrier
+        read_a(cur, 1, ahi);
+        __builtin_amdgcn_sched_barrier(0);
+        mma_half(0, alo, bb);
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // every read of tile kt is in registers before the barrier
+        if (kt + 3 < ntot) wait_vmcnt<2 * LPT>(); else if (kt + 2 < ntot) wait_vmcnt<LPT>(); else wait_vmcnt<0>();
         __builtin_amdgcn_s_barrier();
-        if (kt == 0) TRACE_MARK(1);
-        if (kt + 3 < ntot) issue(kt + 3, (cur + 3) & 3);      // the buffer of tile kt-1: every wave is past its reads
-        const char* sA = smem + cur * STAGE;
-        const char* sB = sA + BM * ROWB;
-        uint4 a[TM], b[TN];
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-            b[j] = *reinterpret_cast<const uint4*>(sB + v5_lds_off(wn * (TN * 16) + j * 16 + fr, fq));
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-            a[i] = *reinterpret_cast<const uint4*>(sA + v5_lds_off(wm * (TM * 16) + i * 16 + fr, fq));
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-            for (int j = 0; j < TN; ++j) acc[i][j] = Mma<T>::run(a[i], b[j], acc[i][j]);
-        cur = (cur + 1) & 3;
+        const int nxt = (cur + 1) & 3;
+        read_a(nxt, 0, alo);                                   // next tile's first A half under this tile's second MFMA half
+        __builtin_amdgcn_sched_barrier(0);
+        mma_half(1, ahi, bb);
+        __builtin_amdgcn_sched_barrier(0);
+        read_b(nxt, bb);                                       // (B is single-buffered: 256 registers per wave is the budget)
+        cur = nxt;
+    }
+    if (ntot > 0) {
+        read_a(cur, 1, ahi);
+        mma_half(0, alo, bb);
+        mma_half(1, ahi, bb);
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
@@ -688,7 +738,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_wave_barrier();
         if (half == 0) TRACE_MARK(3);
-        gemm_nt_epilogue<T, WR, WC>(p, slab, lane, m0 + wm * (TM * 16) + half * 64, n0 + wn * WC, bz);
+        gemm_nt_epilogue<T, WR, WC, 1>(p, slab, lane, m0 + wm * (TM * 16) + half * 64, n0 + wn * WC, bz);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // slab reads of this half are done before it is overwritten
         __builtin_amdgcn_wave_barrier();
     }
@@ -1537,12 +1587,11 @@ extern "C" int cmpc_gemm_nt(const cmpc_gemm_nt_args* a, void* stream) {
         const char* e4 = getenv("CMPC_GEMM_V4");
         const bool v4 = e4 ? atoi(e4) != 0 : (!getenv("CMPC_GEMM_V2") && !getenv("CMPC_GEMM_V3") && (ktot < 2048 || (ktot < 4096 && a->N >= 1024)));
         {
-            // 256 x 256 tiles: study kernel, only on request -- see the kernel's header
             bool k32 = true;
             for (int s2 = 0; s2 < a->nseg; ++s2) k32 = k32 && (a->K[s2] % 32 == 0);
             const char* e5 = getenv("CMPC_GEMM_V5");
-            const bool use5 = e5 ? atoi(e5) != 0 : false;       // 256 x 256 study kernel: 0-9 % faster for N >= 1024, slower below
-            if (use5 && k32 && !v4) {
+            const bool use5 = e5 ? atoi(e5) != 0 : (a->N >= 1024 && a->M >= 2048);   // 256 x 256 tiles: 1.1-1.25x for N >= 1024 (scripts/gemm_ksweep.py), slower below (too few workgroups)
+            if (use5 && k32) {
                 static bool attr5 = false;
                 if (!attr5) { (void)hipFuncSetAttribute((const void*)gemm_nt_v5_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 512 * 64); attr5 = true; }
                 dim3 grid((unsigned)(((a->M + 255) / 256) * ((a->N + 255) / 256)), 1, a->batch);
