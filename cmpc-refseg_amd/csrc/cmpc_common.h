@@ -73,6 +73,11 @@ template <> __device__ __forceinline__ void st8<bf16_t>(bf16_t* p, const float (
     *reinterpret_cast<uint4*>(p) = a;
 }
 
+// the value a stored element will read back as (bf16 storage rounds; fp32 storage is exact)
+template <typename T> __device__ __forceinline__ float stored_value(float v);
+template <> __device__ __forceinline__ float stored_value<float>(float v) { return v; }
+template <> __device__ __forceinline__ float stored_value<bf16_t>(float v) { return bf2f(f2bf(v)); }
+
 // wave64 reductions via cross-lane shuffles
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

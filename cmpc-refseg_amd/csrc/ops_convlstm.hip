@@ -146,10 +146,14 @@ __global__ __launch_bounds__(256) void clstm_b_kernel(T* __restrict__ Yg, const 
                 } else { cp[e] = 0.f; o[e] = 0.f; }
             }
             st8<T>(c_pre + r * ld + c0, cp); st8<T>(y + 3 * ld + c0, o);
-            ld8<T>(c_pre + r * ld + c0, cp); ld8<T>(y + 3 * ld + c0, o);
+            // the statistics are those of the STORED (bf16-rounded) values, which is what clstm_c normalises; rounding
+            // in registers instead of reading the two vectors back saves a dependent memory round trip per row
 #pragma unroll
             for (int e = 0; e < 8; ++e)
-                if (c0 + e < M) { ao1 += o[e]; ao2 += o[e] * o[e]; ac1 += cp[e]; ac2 += cp[e] * cp[e]; }
+                if (c0 + e < M) {
+                    const float ov = stored_value<T>(o[e]), cv = stored_value<T>(cp[e]);
+                    ao1 += ov; ao2 += ov * ov; ac1 += cv; ac2 += cv * cv;
+                }
         }
         so1 += ao1; so2 += ao2; sc1 += ac1; sc2 += ac2;
     }
