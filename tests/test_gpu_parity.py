@@ -395,3 +395,46 @@ def test_full_size_mean_iou_delta_vs_oracle():
     print("full-size parity:", {k: f"dIoU={v[0]:.2e} flipped_px={v[1]} up_rel_err={v[2]:.2e}" for k, v in res.items()}, "oracle mIoU", float(ref["mIoU"]))
     assert res["f32"][0] <= 1e-4 and res["f32"][2] < 1e-3
     assert res["bf16"][0] <= 5e-3
+
+
+def test_full_size_gradients_vs_oracle():
+    """Backward at the benchmark's sizes (B=1): the full-width kernel paths (256 x 256 GEMM tiles, the grouped
+    weight-gradient launch with unsplit 1600-row reductions, full-width mutan / ConvLSTM / score kernels) are not reached
+    by the tiny case.  fp32 mode: a parameter gradient of every stage within 2e-3 of the oracle's (fp32 sums over
+    1600 x 1000 terms in a different order); bf16 mode: within 0.12."""
+    from bench import synth_batch
+    torch.set_num_threads(16)
+    B = 1
+    cfg = O.Cfg(batch_size=B)
+    hp, bp = O.init_head_params(cfg), O.init_backbone_params(cfg)
+    w, im, sl, tg = synth_batch(B, 20, 320, 320, cfg.vocab_size, 5)
+    w, im, sl, tg = map(torch.from_numpy, (w, im, sl, tg))
+    with torch.no_grad():
+        feats = O.backbone_forward(bp, im, cfg)
+    scal, grads, _ = O.grads_of(hp, feats, w, sl, tg, cfg)
+    flags = {k: f for k, _, _, f in O.head_param_specs(cfg)}
+
+    def ref(n):              # gradient of cls_loss_all (L2 and the x2 multiplier live in the Adam kernel)
+        g = grads[n] / (2.0 if "x2" in flags[n] else 1.0)
+        return g - cfg.weight_decay * hp[n] if "reg" in flags[n] else g
+    names = ["text_objseg/c5_lateral/DW", "text_objseg/c3_lateral/biases", "text_objseg/vis_trans_c4_head3/DW",
+             "text_objseg/lang_trans_c5_head1/DW", "text_objseg/gconv_update_spa_graph_c3/DW", "text_objseg/words_trans_c4/DW",
+             "text_objseg/spa_graph_trans2_c5/DW", "text_objseg/fusion_c5/DW", "text_objseg/trans_feat_c3_2_f1/DW",
+             "text_objseg/lang_feat_c4_f2/DW", "text_objseg/rnn/conv_lstm_cell/kernel", "text_objseg/rnn/conv_lstm_cell/W_ci",
+             "text_objseg/score/DW", "text_objseg/score_c4/DW", "text_objseg/rnn/lstm_cell/kernel", "text_objseg/words_parse_1/DW",
+             "text_objseg/gconv_feat_ln_spa_graph_c5/gamma"]
+    P = U.pkg()
+    worst = {}
+    for dtype, tol in (("f32", 2e-3), ("bf16", 0.12)):
+        m = P.LSTM_model(batch_size=B, mode="train", dtype=dtype, head_params=hp, backbone_params=bp)
+        o = m.loss_and_grads([f.to(m.device) for f in feats], w, tg, sl)
+        torch.cuda.synchronize()
+        assert abs(float(o["loss_all"].detach()) - scal["loss_all"]) <= (2e-4 if dtype == "f32" else 3e-2) * abs(scal["loss_all"])
+        g = m.store.grad_dict()
+        errs = {n: U.rel_err(g[n], ref(n)) for n in names}
+        worst[dtype] = max(errs.items(), key=lambda kv: kv[1])
+        for n, e in errs.items():
+            assert e < tol, (dtype, n, e)
+        del m, o, g
+        torch.cuda.empty_cache()
+    print("full-size gradient parity, worst relative error:", worst)
