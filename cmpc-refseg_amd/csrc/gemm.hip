@@ -1587,8 +1587,9 @@ extern "C" int cmpc_gemm_nt(const cmpc_gemm_nt_args* a, void* stream) {
         const char* e4 = getenv("CMPC_GEMM_V4");
         const bool v4 = e4 ? atoi(e4) != 0 : (!getenv("CMPC_GEMM_V2") && !getenv("CMPC_GEMM_V3") && (ktot < 2048 || (ktot < 4096 && a->N >= 1024)));
         {
-            bool k32 = true;
-            for (int s2 = 0; s2 < a->nseg; ++s2) k32 = k32 && (a->K[s2] % 32 == 0);
+            bool k32 = true;        // and every operand addressable with the kernel's 32-bit byte offsets
+            for (int s2 = 0; s2 < a->nseg; ++s2)
+                k32 = k32 && (a->K[s2] % 32 == 0) && ((long)a->M * a->lda[s2] * esz < (1L << 32)) && ((long)a->N * a->ldb[s2] * esz < (1L << 32));
             const char* e5 = getenv("CMPC_GEMM_V5");
             const bool use5 = e5 ? atoi(e5) != 0 : (a->N >= 1024 && a->M >= 2048);   // 256 x 256 tiles: 1.1-1.25x for N >= 1024 (scripts/gemm_ksweep.py), slower below (too few workgroups)
             if (use5 && k32) {
