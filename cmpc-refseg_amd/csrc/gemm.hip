@@ -1486,6 +1486,144 @@ __global__ __launch_bounds__(512) void gemm_tn_v2_kernel(const cmpc_gemm_tn_args
 }
 
 // ------------------------------------------------------------------------------------------
+// gemm_tn, 256 (k) x 256 (n) output tile -- the weight-gradient counterpart of gemm_nt_v5: 8 waves (2 x 4, 128 x 64 per
+// wave), 32 reduction rows per step, four LDS stages of 32 KiB filled by LDS-DMA (three steps of loads in flight), the
+// step's 32 MFMAs per wave in two halves with the next half's transposing LDS reads issued in front of each.  Twice the
+// output area per operand byte of the 128 x 128 kernel.  Used by the grouped launch for bf16 products with K, N >= 256.
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ void gemm_tn_big_body(const cmpc_gemm_tn_args& p, const int bx, const int by, const int bz, char* smem) {
+    constexpr int BR = 32, ROWB = 512, TILE = BR * ROWB, STAGE = 2 * TILE;
+    constexpr int LPT = 4;                                      // 32 one-KiB pieces (16 A + 16 D) / 8 waves
+    const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wid >> 2, wn = wid & 3;
+    const int ntn = (p.Nv + 255) / 256;
+    const int k0 = (bx / ntn) * 256, n0 = (bx % ntn) * 256;
+    const int b1 = bz % p.nb, b2 = bz / p.nb;
+    const bf16_t* A = reinterpret_cast<const bf16_t*>(p.A) + p.a_off[b1] + (long)b2 * p.a_bs;
+    const bf16_t* D = reinterpret_cast<const bf16_t*>(p.D) + p.d_off[b1] + (long)b2 * p.d_bs;
+    float* out = p.out + p.o_off[b1] + (long)b2 * p.o_bs;
+    const int per = (p.R + p.rsplit - 1) / p.rsplit;
+    const int rbeg = by * per;
+    const int rend = min(p.R, rbeg + per);
+    const int nt = (rend > rbeg) ? (rend - rbeg + BR - 1) / BR : 0;
+    if (nt == 0) return;
+
+    f4 acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f4{0.f, 0.f, 0.f, 0.f};
+
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+    const bf16_t* Z = reinterpret_cast<const bf16_t*>(p.zeros);
+    // a piece = 2 slab rows x 512 B; lane -> (row = lane>>5, 16-B chunk position = lane&31).  LDS position of (row, chunk c):
+    // row*512 + ((c>>1) ^ f(row))*32 + (c&1)*16, so the lane that lands on position c fetches source chunk ((c>>1)^f)*2 + (c&1)
+    // (f < 8 flips the low three bits of the 32-B segment index: the row's two 256-B halves are permuted separately).
+    int pr[LPT], csrc[LPT];
+#pragma unroll
+    for (int j = 0; j < LPT; ++j) {
+        const int piece = wid * LPT + j;
+        pr[j] = (piece & 15) * 2 + (lane >> 5);
+        const int cpos = lane & 31, f = (pr[j] & 3) | (((pr[j] >> 3) & 1) << 2);
+        csrc[j] = (((cpos >> 1) ^ f) << 1) | (cpos & 1);
+    }
+    auto issue = [&](int t, int buf) {
+        const int r0 = rbeg + t * BR;
+#pragma unroll
+        for (int j = 0; j < LPT; ++j) {
+            const int piece = wid * LPT + j;                    // 0..15 -> A slab, 16..31 -> D slab (wave-uniform)
+            const bool isA = piece < 16;
+            const int gr = r0 + pr[j];
+            const int col = (isA ? k0 : n0) + csrc[j] * 8;
+            const bool ok = gr < rend && col < (isA ? p.Ka : p.Nd);
+            const bf16_t* g = ok ? (isA ? A + (long)gr * p.lda + col : D + (long)gr * p.ldd + col) : Z;
+            glds16(g, __builtin_amdgcn_readfirstlane(lds0 + buf * STAGE + (isA ? 0 : TILE) + (piece & 15) * 1024));
+        }
+    };
+    const int fr = lane & 15, fq = lane >> 4;
+    const int q4 = fr >> 2, p4 = fr & 3;
+    const int r_lo = 8 * fq + q4;
+    auto trfrag = [&](const char* slab, int col) -> uint4 {
+        const s4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s4*)(slab + tn_swz(r_lo, col * 2, ROWB)));
+        const s4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s4*)(slab + tn_swz(r_lo + 4, col * 2, ROWB)));
+        const s8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        return __builtin_bit_cast(uint4, v);
+    };
+    auto read_a = [&](int buf, int half, uint4 (&a)[4]) {
+        const char* sA = smem + buf * STAGE;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) a[i] = trfrag(sA, wm * 128 + (half * 4 + i) * 16 + 4 * p4);
+    };
+    auto read_d = [&](int buf, uint4 (&d)[4]) {
+        const char* sD = smem + buf * STAGE + TILE;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) d[j] = trfrag(sD, wn * 64 + j * 16 + 4 * p4);
+    };
+    auto mma_half = [&](int half, const uint4 (&a)[4], const uint4 (&d)[4]) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                acc[half * 4 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf8v, a[i]), __builtin_bit_cast(bf8v, d[j]), acc[half * 4 + i][j], 0, 0, 0);
+    };
+
+    issue(0, 0);
+    if (nt > 1) issue(1, 1);
+    if (nt > 2) issue(2, 2);
+    if (nt > 2) wait_vmcnt<2 * LPT>(); else if (nt > 1) wait_vmcnt<LPT>(); else wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();
+    uint4 alo[4], ahi[4], dd[4];
+    read_d(0, dd); read_a(0, 0, alo);
+    int cur = 0;
+    for (int t = 0; t + 1 < nt; ++t) {
+        if (t + 3 < nt) issue(t + 3, (cur + 3) & 3);             // buffer of step t-1: free since the previous barrier
+        read_a(cur, 1, ahi);
+        __builtin_amdgcn_sched_barrier(0);
+        mma_half(0, alo, dd);
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // every read of step t is in registers before the barrier
+        if (t + 3 < nt) wait_vmcnt<2 * LPT>(); else if (t + 2 < nt) wait_vmcnt<LPT>(); else wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();
+        const int nxt = (cur + 1) & 3;
+        read_a(nxt, 0, alo);
+        __builtin_amdgcn_sched_barrier(0);
+        mma_half(1, ahi, dd);
+        __builtin_amdgcn_sched_barrier(0);
+        read_d(nxt, dd);
+        cur = nxt;
+    }
+    read_a(cur, 1, ahi);
+    mma_half(0, alo, dd);
+    mma_half(1, ahi, dd);
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int k = k0 + wm * 128 + i * 16 + fq * 4 + r;
+                const int n = n0 + wn * 64 + j * 16 + fr;
+                if (k < p.Kv && n < p.Nv) atomicAdd(out + (long)k * p.ldo + n, acc[i][j][r] * p.alpha);
+            }
+    // all waves are past their LDS reads before the next item's DMA overwrites the stages
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+}
+
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void gemm_tn_grouped_big_kernel(const TnGroupDesc* __restrict__ table, int ndesc, int total) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    for (int w = blockIdx.x; w < total; w += gridDim.x) {
+        int lo = 0, hi = ndesc;
+        while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (table[mid].item_begin <= w) lo = mid; else hi = mid; }
+        const TnGroupDesc& d = table[lo];
+        const int local = w - d.item_begin;
+        const int tiles = d.tiles, rs = d.a.rsplit;
+        const int bx = local % tiles, rest = local / tiles;
+        gemm_tn_big_body(d.a, bx, rest % rs, rest / rs, smem);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // gemm_nt for M <= 16 rows (the language side: [B, .] vectors against whole weight matrices).
 // Weight-streaming: one wave per NC output columns, K split over the 64 lanes (float4 loads of
 // the K-contiguous weight rows), the few A rows re-read from L1/L2; wave-shuffle reduction.
@@ -1707,49 +1845,67 @@ static int tn_validate(const cmpc_gemm_tn_args* a) {
 extern "C" int cmpc_gemm_tn_grouped(const cmpc_gemm_tn_args* args, int n, void* stream) {
     if (n < 0 || (n > 0 && !args)) { cmpc_set_error("gemm_tn_grouped: bad args"); return CMPC_EINVAL; }
     hipStream_t st = (hipStream_t)stream;
-    std::vector<int> order;
-    long tiles_tot = 0;
+    // two lists: bf16 products with a large output (256 x 256 tiles, gemm_tn_grouped_big_kernel) and the rest
+    std::vector<int> order[2];
+    long tiles_tot[2] = {0, 0};
+    // CMPC_TN_BIG=1: 256 x 256 tiles for the large bf16 products.  Off by default: measured 2.5 ms against 2.2 ms for the
+    // whole flush with 128 x 128 tiles (400-step items leave a long tail on 256 slots); kept for the next round.
+    const bool use_big = getenv("CMPC_TN_BIG") && atoi(getenv("CMPC_TN_BIG")) != 0;
     for (int i = 0; i < n; ++i) {
         const int rc = tn_validate(&args[i]);
         if (rc != CMPC_OK) return rc;
         if (args[i].R == 0) continue;
-        order.push_back(i);
-        tiles_tot += (long)((args[i].Kv + 127) / 128) * ((args[i].Nv + 127) / 128) * args[i].nb * args[i].nb2;
+        const int big = (use_big && args[i].dtype == DT_BF16 && args[i].zeros && args[i].Kv >= 256 && args[i].Nv >= 256 && args[i].R >= 1024) ? 1 : 0;
+        const int ts = big ? 256 : 128;
+        order[big].push_back(i);
+        tiles_tot[big] += (long)((args[i].Kv + ts - 1) / ts) * ((args[i].Nv + ts - 1) / ts) * args[i].nb * args[i].nb2;
     }
-    const int m = (int)order.size();
-    if (m == 0) return CMPC_OK;
-    // split reductions only as far as needed to put ~1024 items (2 per CU, 2 rounds) in the launch
-    const int want = (int)((1024 + tiles_tot - 1) / tiles_tot);
-    std::vector<TnGroupDesc> descs(m);
-    std::vector<long> len(m);
-    for (int j = 0; j < m; ++j) {
-        TnGroupDesc& d = descs[j];
-        d.a = args[order[j]];
-        const int br = d.a.dtype == DT_F32 ? TnCfg<float>::BR : TnCfg<bf16_t>::BR;
-        d.a.rsplit = std::max(1, std::min(want, std::max(1, d.a.R / (4 * br))));
-        d.tiles = ((d.a.Kv + 127) / 128) * ((d.a.Nv + 127) / 128);
-        // steps of one item; an fp32 step (32 rows, 16x16x4 MFMA) costs about as much as a bf16 step of 64 rows
-        len[j] = ((d.a.R + d.a.rsplit - 1) / d.a.rsplit + br - 1) / br;
-    }
-    std::vector<int> idx(m);
-    for (int j = 0; j < m; ++j) idx[j] = j;
-    std::stable_sort(idx.begin(), idx.end(), [&](int x, int y) { return len[x] > len[y]; });
-    TnGroupDesc* table = (TnGroupDesc*)cmpc_ws((size_t)m * sizeof(TnGroupDesc), st);
+    const int m0 = (int)order[0].size(), m1 = (int)order[1].size();
+    if (m0 + m1 == 0) return CMPC_OK;
+    TnGroupDesc* table = (TnGroupDesc*)cmpc_ws((size_t)(m0 + m1) * sizeof(TnGroupDesc), st);
     if (!table) return CMPC_EHIP;
-    int items = 0;
-    for (int c0 = 0; c0 < m; c0 += TN_UPLOAD) {
-        TnUploadArgs ua;
-        ua.n = std::min(TN_UPLOAD, m - c0);
-        ua.base = c0;
-        for (int i = 0; i < ua.n; ++i) {
-            ua.d[i] = descs[idx[c0 + i]];
-            ua.d[i].item_begin = items;
-            items += ua.d[i].tiles * ua.d[i].a.rsplit * ua.d[i].a.nb * ua.d[i].a.nb2;
+    int base = 0;
+    for (int big = 1; big >= 0; --big) {                 // the long launch first
+        const int m = (int)order[big].size();
+        if (m == 0) continue;
+        const int ts = big ? 256 : 128;
+        // split reductions only as far as needed to fill the persistent grid twice
+        const int slots = big ? 256 : 512;
+        const int want = (int)((2 * slots + tiles_tot[big] - 1) / tiles_tot[big]);
+        std::vector<TnGroupDesc> descs(m);
+        std::vector<long> len(m);
+        for (int j = 0; j < m; ++j) {
+            TnGroupDesc& d = descs[j];
+            d.a = args[order[big][j]];
+            const int br = big ? 32 : (d.a.dtype == DT_F32 ? TnCfg<float>::BR : TnCfg<bf16_t>::BR);
+            d.a.rsplit = std::max(1, std::min(want, std::max(1, d.a.R / (16 * br))));
+            d.tiles = ((d.a.Kv + ts - 1) / ts) * ((d.a.Nv + ts - 1) / ts);
+            len[j] = ((d.a.R + d.a.rsplit - 1) / d.a.rsplit + br - 1) / br;     // steps of one item
         }
-        hipLaunchKernelGGL(tn_desc_upload_kernel, dim3(1), dim3(256), 0, st, ua, table);
+        std::vector<int> idx(m);
+        for (int j = 0; j < m; ++j) idx[j] = j;
+        std::stable_sort(idx.begin(), idx.end(), [&](int x, int y) { return len[x] > len[y]; });   // long items first
+        int items = 0;
+        for (int c0 = 0; c0 < m; c0 += TN_UPLOAD) {
+            TnUploadArgs ua;
+            ua.n = std::min(TN_UPLOAD, m - c0);
+            ua.base = base + c0;
+            for (int i = 0; i < ua.n; ++i) {
+                ua.d[i] = descs[idx[c0 + i]];
+                ua.d[i].item_begin = items;
+                items += ua.d[i].tiles * ua.d[i].a.rsplit * ua.d[i].a.nb * ua.d[i].a.nb2;
+            }
+            hipLaunchKernelGGL(tn_desc_upload_kernel, dim3(1), dim3(256), 0, st, ua, table);
+        }
+        if (big) {
+            static bool attr = false;
+            if (!attr) { (void)hipFuncSetAttribute((const void*)gemm_tn_grouped_big_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 2 * 32 * 512); attr = true; }
+            hipLaunchKernelGGL(gemm_tn_grouped_big_kernel, dim3(std::min(items, slots)), dim3(512), 4 * 2 * 32 * 512, st, table + base, m, items);
+        } else {
+            hipLaunchKernelGGL(gemm_tn_grouped_kernel, dim3(std::min(items, slots)), dim3(256), 2 * 2 * TnCfg<bf16_t>::BR * 128 * 2, st, table + base, m, items);
+        }
+        base += m;
     }
-    const int grid = std::min(items, 512);
-    hipLaunchKernelGGL(gemm_tn_grouped_kernel, dim3(grid), dim3(256), 2 * 2 * TnCfg<bf16_t>::BR * 128 * 2, st, table, m, items);
     return cmpc_check_launch("gemm_tn_grouped");
 }
 

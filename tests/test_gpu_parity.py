@@ -105,18 +105,22 @@ def test_gemm_tn_against_torch(dt, tdt, tol):
                 d_bs=R * 2 * N, o_bs=K * 2 * N, alpha=2.0)
     assert U.rel_err(out.cpu(), (2.0 * torch.bmm(A.float().transpose(1, 2), D.float())).cpu()) < tol
 
-def test_gemm_tn_grouped_against_torch():
-    """cmpc_gemm_tn_grouped: a mixed bag of deferred products (bf16 and fp32, inner-batch offsets, an outer batch
+@pytest.mark.parametrize("big", ["0", "1"])
+def test_gemm_tn_grouped_against_torch(big, monkeypatch):
+    """cmpc_gemm_tn_grouped (big=1: with the optional 256 x 256-tile kernel for the large bf16 products): a mixed bag of deferred products (bf16 and fp32, inner-batch offsets, an outer batch
     accumulating into one output, two products adding into the SAME output, an empty reduction) in few launches."""
     P, ops, dev = U.pkg(), _ops(), torch.device("cuda:0")
+    monkeypatch.setenv("CMPC_TN_BIG", big)
     torch.manual_seed(3)
 
     class Cx:                      # the two attributes gemm_tn(..., wg=cx) looks at
-        defer, deferred = True, []
+        defer = True
     cx, refs, outs = Cx(), [], []
+    cx.deferred = []
     for i, (dt, R, K, N) in enumerate(((1, 1500, 256, 128), (1, 4000, 128, 384), (0, 160, 72, 40), (1, 64, 8, 24), (0, 8, 128, 128),
                                        (1, 700, 512, 512), (0, 0, 8, 8), (1, 2500, 64, 1024), (0, 300, 200, 16), (1, 1000, 128, 128),
-                                       (1, 999, 136, 264), (1, 130, 128, 64))):
+                                       (1, 999, 136, 264), (1, 130, 128, 64),
+                                       (1, 3000, 512, 768), (1, 1500, 304, 264), (1, 2048, 256, 256), (1, 1100, 1024, 328))):      # 256 x 256-tile kernel
         tdt = torch.bfloat16 if dt == 1 else torch.float32
         Kp, Np = (K + 7) // 8 * 8, (N + 7) // 8 * 8
         A = torch.randn(R, Kp, device=dev).to(tdt); D = torch.randn(R, Np, device=dev).to(tdt)
@@ -133,7 +137,7 @@ def test_gemm_tn_grouped_against_torch():
     Ab = torch.randn(3, 40, 64, device=dev); Db = torch.randn(3, 40, 128, device=dev); ob = torch.zeros(64, 128, device=dev)
     ops.gemm_tn(0, Ab, 64, 64, Db, 128, 64, ob, 128, 40, 64, 64, offs=((0, 0, 0), (0, 64, 64)), nb2=3, a_bs=40 * 64, d_bs=40 * 128, o_bs=0, wg=cx)
     outs.append(ob); refs.append(torch.einsum("brk,brn->kn", Ab, Db))
-    assert len(cx.deferred) == 15 and all(torch.equal(o, o) for o in outs)
+    assert len(cx.deferred) == 19
     arr = (P._lib.GemmTnArgs * len(cx.deferred))()
     import ctypes
     for i, (a, _A, _D) in enumerate(cx.deferred):
