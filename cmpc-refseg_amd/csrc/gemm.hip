@@ -1719,7 +1719,7 @@ extern "C" int cmpc_gemm_nt(const cmpc_gemm_nt_args* a, void* stream) {
         const int gn = (a->N + 127) / 128;
         int ktot = 0;
         for (int s2 = 0; s2 < a->nseg; ++s2) ktot += a->K[s2];      // long K: producer/consumer waves (v3) win; short K: v2
-        const bool big = (long)((a->M + 255) / 256) * gn * a->batch >= 384 || getenv("CMPC_GEMM_BM256");
+        const bool big = (long)((a->M + 255) / 256) * gn * a->batch >= 192 || getenv("CMPC_GEMM_BM256");   // one round of 256-row tiles beats two of 128-row ones
         // v4 (fragment double buffering, hoisted row pointers) wins for short and medium K, v3 (producer /
         // consumer waves) for long K (scripts/gemm_ksweep.py); v2 is kept as the plain reference structure.
         const char* e4 = getenv("CMPC_GEMM_V4");
