@@ -1789,7 +1789,7 @@ static int launch_conv(const cmpc_conv_args* a, hipStream_t st) {
     const int Ho = (a->H + a->stride - 1) / a->stride, Wo = (a->W + a->stride - 1) / a->stride;
     const long M = (long)a->B * Ho * Wo;
     const int gn = (a->Cout + 127) / 128;
-    const bool big = ((M + 255) / 256) * gn >= 384;
+    const bool big = ((M + 255) / 256) * gn >= 192;       // as in cmpc_gemm_nt
     if (big) {
         static bool attr = false;
         if (!attr) { (void)hipFuncSetAttribute((const void*)conv_v2_kernel<T, 256>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * (256 + 128) * BKB); attr = true; }
