@@ -93,7 +93,7 @@ class LSTM_model(object):
         self.last = {}
         # CMPC_GRAPH=1: train_step replays forward + backward from ONE captured HIP graph (about 1200 launches
         # per step, no Python in the loop).  Off by default: on ROCm 7.2 the replay of the 4-stream graph is
-        # slower (17.8 ms) than eager launches on the same 4 streams (15.6 ms); on one stream both take 19.2 ms.
+        # slower (13.6-14.1 ms) than eager launches on the same 4 streams (11.9 ms); the one-stream graph takes 14.8 ms.
         self.use_graph = os.environ.get("CMPC_GRAPH", "0") != "0"
         self._graph, self._gin, self._gout, self._eager_steps = None, None, None, 0
         self._opt_pending = False
