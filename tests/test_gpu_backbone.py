@@ -12,15 +12,20 @@ from tests.util import O
 pytestmark = pytest.mark.gpu
 
 
+@pytest.mark.parametrize("variant", ["default", "CMPC_CONV_V2"])
 @pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-5), (torch.bfloat16, 2e-2)])
-def test_conv_nhwc_matches_torch(dtype, tol):
+def test_conv_nhwc_matches_torch(dtype, tol, variant, monkeypatch):
+    """both conv kernels (conv_v3 by default, conv_v2 behind its switch), 128- and 256-row tiles"""
+    if variant != "default":
+        monkeypatch.setenv(variant, "1")
     bb = importlib.import_module("cmpc-refseg_amd.backbone")
     dev = torch.device("cuda:0")
     torch.manual_seed(0)
     for (k, cin, cout, stride, dil, hw, B, with_res, relu) in (
             (1, 64, 256, 1, 1, 20, 2, False, False), (1, 256, 64, 1, 1, 20, 2, False, True), (3, 64, 64, 1, 1, 20, 2, False, True),
             (1, 256, 128, 2, 1, 20, 2, False, True), (3, 128, 128, 1, 2, 12, 3, False, True), (3, 64, 128, 1, 4, 10, 1, False, True),
-            (1, 128, 512, 1, 1, 12, 3, True, True), (3, 256, 256, 1, 2, 40, 8, False, True), (1, 192, 72, 2, 1, 9, 2, True, False)):
+            (1, 128, 512, 1, 1, 12, 3, True, True), (3, 256, 256, 1, 2, 40, 8, False, True), (1, 192, 72, 2, 1, 9, 2, True, False),
+            (1, 256, 1024, 1, 1, 40, 8, True, True), (3, 128, 512, 1, 4, 40, 8, False, True)):       # 256-row tiles (>= 192 tiles)
         m = bb._ConvBN(k, cin, cout, stride, dil, relu=relu)
         w = torch.randn(k, k, cin, cout) * (2.0 / (k * k * cin)) ** 0.5
         p = {"c/weights": w, "b/gamma": torch.rand(cout) + 0.5, "b/beta": torch.randn(cout) * 0.1,

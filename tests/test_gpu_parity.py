@@ -80,9 +80,13 @@ def test_gemm_nt_against_torch(dt, tdt, tol):
     assert U.rel_err(C.float().cpu(), torch.bmm(A.float(), Bt.float().transpose(1, 2)).cpu()) < tol
 
 
+@pytest.mark.parametrize("variant", ["default", "CMPC_TN_V2"])
 @pytest.mark.parametrize("dt,tdt,tol", [(0, torch.float32, 1e-5), (1, torch.bfloat16, 1e-5)])
-def test_gemm_tn_against_torch(dt, tdt, tol):
-    """A = I-style check with ASYMMETRIC operands plus random cases (exact products of bf16 inputs in fp32)."""
+def test_gemm_tn_against_torch(dt, tdt, tol, variant, monkeypatch):
+    """A = I-style check with ASYMMETRIC operands plus random cases (exact products of bf16 inputs in fp32); also with
+    the LDS-DMA variant of the kernel forced."""
+    if variant != "default":
+        monkeypatch.setenv(variant, "1")
     ops, dev = _ops(), torch.device("cuda:0")
     torch.manual_seed(1)
     R, K, N = 256, 128, 128
