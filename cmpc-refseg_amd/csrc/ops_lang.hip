@@ -73,6 +73,70 @@ __global__ void lstm_cell_bwd_kernel(const float* __restrict__ ga, const float* 
     dh[o] = 0.f;          // the caller adds dgates . W_h^T
 }
 
+// One step of the LSTM backward recurrence in ONE launch: dh = (dh kept for finished sequences) + dgates[t] . W_h^T, then
+// the cell backward of step t-1 on that dh (what cmpc_gemm_nt(skinny) + cmpc_lstm_cell_bwd did in two launches of a
+// host-paced serial chain).  A workgroup owns 4 hidden units: its 4 waves split K = 4*ld (float4 loads, all issued before
+// the first use), the 8 x 4 partial sums are reduced across lanes, and threads 0..31 then run the cell backward of their
+// (sample, unit).  B <= 8.
+__global__ __launch_bounds__(256) void lstm_bwd_step_kernel(const float* __restrict__ dg_t, const float* __restrict__ Wn, int ldw,
+                                                           const float* __restrict__ ga, const float* __restrict__ c_prev, const float* __restrict__ c_out,
+                                                           const int* __restrict__ seq_len, int tm1, const float* __restrict__ dout, int ld_dout,
+                                                           float* __restrict__ dh, float* __restrict__ dc, float* __restrict__ dg_out, int B, int ld, int R) {
+    constexpr int NC = 4, MMAX = 8;
+    __shared__ float red[4][MMAX * NC];
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int k0 = blockIdx.x * NC, K = 4 * ld;
+    float acc[MMAX][NC];
+#pragma unroll
+    for (int m = 0; m < MMAX; ++m)
+#pragma unroll
+        for (int c = 0; c < NC; ++c) acc[m][c] = 0.f;
+    for (int k = (wid * 64 + lane) * 4; k < K; k += 1024) {
+        float4 w[NC], a[MMAX];
+#pragma unroll
+        for (int c = 0; c < NC; ++c) w[c] = *reinterpret_cast<const float4*>(Wn + (long)min(k0 + c, ld - 1) * ldw + k);
+#pragma unroll
+        for (int m = 0; m < MMAX; ++m) a[m] = *reinterpret_cast<const float4*>(dg_t + (long)min(m, B - 1) * K + k);
+#pragma unroll
+        for (int m = 0; m < MMAX; ++m)
+#pragma unroll
+            for (int c = 0; c < NC; ++c) acc[m][c] += a[m].x * w[c].x + a[m].y * w[c].y + a[m].z * w[c].z + a[m].w * w[c].w;
+    }
+#pragma unroll
+    for (int m = 0; m < MMAX; ++m)
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            const float v = wave_sum(acc[m][c]);
+            if (lane == 0) red[wid][m * NC + c] = v;
+        }
+    __syncthreads();
+    const int t = threadIdx.x;
+    if (t >= MMAX * NC) return;
+    const int b = t / NC, c = k0 + t % NC;
+    if (b >= B || c >= ld) return;
+    const long o = (long)b * ld + c;
+    float* dg = dg_out + (long)b * 4 * ld;
+    // dh after the product of step t (columns >= R of W_h^T are zero rows of the packed operand, so they add 0)
+    const float dh_in = dh[o] + (c < R ? (red[0][t] + red[1][t] + red[2][t] + red[3][t]) : 0.f);
+    const bool live = tm1 < seq_len[b];
+    if (!live || c >= R) {
+        dg[c] = 0.f; dg[ld + c] = 0.f; dg[2 * ld + c] = 0.f; dg[3 * ld + c] = 0.f;
+        if (c >= R) { dh[o] = 0.f; dc[o] = 0.f; } else dh[o] = dh_in;       // state gradients pass through for finished sequences
+        return;
+    }
+    const float* g = ga + (long)b * 4 * ld;
+    const float is = g[c], jt = g[ld + c], fs = g[2 * ld + c], os = g[3 * ld + c];
+    const float cn = c_out[o], tc = tanhf(cn);
+    const float dhn = dout[(long)b * ld_dout + c] + dh_in;
+    const float dcn = dc[o] + dhn * os * (1.f - tc * tc);
+    dg[c] = dcn * jt * is * (1.f - is);
+    dg[ld + c] = dcn * is * (1.f - jt * jt);
+    dg[2 * ld + c] = dcn * c_prev[o] * fs * (1.f - fs);
+    dg[3 * ld + c] = dhn * tc * os * (1.f - os);
+    dc[o] = dcn * fs;
+    dh[o] = 0.f;
+}
+
 __global__ void parse_softmax_fwd_kernel(const float* __restrict__ logits, int ld, const float* __restrict__ mask, float* __restrict__ parse, int n) {
     const int r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= n) return;
@@ -269,6 +333,14 @@ extern "C" int cmpc_lstm_cell_bwd(const float* gates_act, const float* c_prev, c
                                   int B, int ld, int R, void* stream) {
     hipLaunchKernelGGL(lstm_cell_bwd_kernel, dim3((ld + 255) / 256, B), dim3(256), 0, ST, gates_act, c_prev, c_out, seq_len, t, dout_t, ld_dout, dh, dc, dgates, ld, R);
     return cmpc_check_launch("lstm_cell_bwd");
+}
+extern "C" int cmpc_lstm_bwd_step(const float* dgates_t, const float* Wn, int ldw, const float* gates_act_tm1, const float* c_prev, const float* c_out,
+                                  const int* seq_len, int tm1, const float* dout_tm1, int ld_dout, float* dh, float* dc, float* dgates_tm1,
+                                  int B, int ld, int R, void* stream) {
+    if (B < 1 || B > 8 || ld % 4 || ldw % 4 || !dgates_t || !Wn) { cmpc_set_error("lstm_bwd_step: need 1 <= B <= 8 and 16-B aligned rows"); return CMPC_EINVAL; }
+    hipLaunchKernelGGL(lstm_bwd_step_kernel, dim3((ld + 3) / 4), dim3(256), 0, ST, dgates_t, Wn, ldw, gates_act_tm1, c_prev, c_out, seq_len, tm1,
+                       dout_tm1, ld_dout, dh, dc, dgates_tm1, B, ld, R);
+    return cmpc_check_launch("lstm_bwd_step");
 }
 extern "C" int cmpc_parse_softmax_fwd(const float* logits, int ld, const float* mask, float* parse, int n, void* stream) {
     hipLaunchKernelGGL(parse_softmax_fwd_kernel, dim3((n + 63) / 64), dim3(64), 0, ST, logits, ld, mask, parse, n);

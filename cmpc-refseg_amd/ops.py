@@ -289,11 +289,21 @@ class TextEncoder(torch.autograd.Function):
         dh = zeros((B, Cp), F32, dev)
         dc = zeros((B, Cp), F32, dev)
         dg = empty((T, B, 4 * Cp), F32, dev)
-        for t in reversed(range(T)):
-            _lib.call("cmpc_lstm_cell_bwd", _p(gates[t]), _p(c_all[t]), _p(c_all[t + 1]), _p(seq_len), t,
-                      _p(douts) + 4 * t * Cp, T * Cp, _p(dh), _p(dc), _p(dg[t]), B, Cp, R, _st())
-            gemm_nt(F32, [(dg[t], 4 * Cp, cx.opp("lstm.n", Gp, 0), 4 * Cp, 4 * Cp)], dh, Cp, B, Cp, n_valid=R,
-                    accumulate=True)
+        if B <= 8 and os.environ.get("CMPC_LSTM_FUSED", "1") != "0":
+            # one launch per step: dh += dg[t] . W_h^T fused with the cell backward of step t-1 (the product of step 0
+            # would only feed the unused gradient of the initial state)
+            _lib.call("cmpc_lstm_cell_bwd", _p(gates[T - 1]), _p(c_all[T - 1]), _p(c_all[T]), _p(seq_len), T - 1,
+                      _p(douts) + 4 * (T - 1) * Cp, T * Cp, _p(dh), _p(dc), _p(dg[T - 1]), B, Cp, R, _st())
+            wn = cx.opp("lstm.n", Gp, 0)
+            for t in range(T - 1, 0, -1):
+                _lib.call("cmpc_lstm_bwd_step", _p(dg[t]), wn, 4 * Cp, _p(gates[t - 1]), _p(c_all[t - 1]), _p(c_all[t]), _p(seq_len), t - 1,
+                          _p(douts) + 4 * (t - 1) * Cp, T * Cp, _p(dh), _p(dc), _p(dg[t - 1]), B, Cp, R, _st())
+        else:
+            for t in reversed(range(T)):
+                _lib.call("cmpc_lstm_cell_bwd", _p(gates[t]), _p(c_all[t]), _p(c_all[t + 1]), _p(seq_len), t,
+                          _p(douts) + 4 * t * Cp, T * Cp, _p(dh), _p(dc), _p(dg[t]), B, Cp, R, _st())
+                gemm_nt(F32, [(dg[t], 4 * Cp, cx.opp("lstm.n", Gp, 0), 4 * Cp, 4 * Cp)], dh, Cp, B, Cp, n_valid=R,
+                        accumulate=True)
         gk = ps.gptr("rnn/lstm_cell/kernel")
         gate_offs = lambda row0: tuple((0, g * Cp, row0 * 4 * R + g * R) for g in range(4))
         gemm_tn(F32, emb, Gp, Gp, dg, 4 * Cp, Cp, gk, 4 * R, T * B, G, R, offs=gate_offs(0), wg=cx)

@@ -211,6 +211,11 @@ int cmpc_lstm_cell_fwd(float* gates, const float* c_prev, const float* h_prev, c
 int cmpc_lstm_cell_bwd(const float* gates_act, const float* c_prev, const float* c_out, const int* seq_len, int t,
                        const float* dout_t, int ld_dout, float* dh, float* dc, float* dgates,
                        int B, int ld, int R, void* stream);
+/* one launch per step of the backward recurrence (B <= 8): dh += dgates_t . W_h^T (Wn = the [ld][4 ld] operand rows of W_h),
+ * then cmpc_lstm_cell_bwd of step t-1 on it (util dynamic_rnn / LSTMCell backward, CMPC_model.py:144-164 via tf.gradients) */
+int cmpc_lstm_bwd_step(const float* dgates_t, const float* Wn, int ldw, const float* gates_act_tm1, const float* c_prev, const float* c_out,
+                       const int* seq_len, int tm1, const float* dout_tm1, int ld_dout, float* dh, float* dc, float* dgates_tm1,
+                       int B, int ld, int R, void* stream);
 /* softmax over the 4 parser classes times seq_mask (:352-353) */
 int cmpc_parse_softmax_fwd(const float* logits, int ld, const float* mask, float* parse, int n, void* stream);
 int cmpc_parse_softmax_bwd(const float* dparse, const float* parse, const float* mask, float* dlogits, int ld, int n, void* stream);
