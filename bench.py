@@ -138,7 +138,13 @@ def main():
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        torch.distributed.init_process_group("nccl", device_id=torch.device(f"cuda:{local}"))
+        # CMPC_BENCH_REHEARSAL=1 (development only): rehearse the multi-process control flow on a ONE-GPU box -- every rank
+        # on cuda:0, gradients exchanged with gloo.  The measured configuration is always one rank per GPU over RCCL.
+        if os.environ.get("CMPC_BENCH_REHEARSAL"):
+            torch.distributed.init_process_group("gloo")
+            local = 0
+        else:
+            torch.distributed.init_process_group("nccl", device_id=torch.device(f"cuda:{local}"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X; there is no CPU path for the product")
     torch.cuda.set_device(local)
