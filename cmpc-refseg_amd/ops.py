@@ -181,6 +181,21 @@ def _nocycle(fwd):
     return staticmethod(wrapper)
 
 
+def spatial_grid_padded(h: int, w: int) -> torch.Tensor:
+    """generate_spatial_batch (util/processing_tools.py:5-17) for one image as an [h*w, 64] fp32 matrix: the 8 coordinate
+    channels [xmin, ymin, xmax, ymax, xctr, yctr, 1/w, 1/h] (computed in float64, stored float32 like the reference's
+    np.float32 array), zero padded to the 64-wide K tile of the GEMMs that consume it."""
+    sp = torch.zeros(h * w, 64, dtype=torch.float32)
+    ys = torch.arange(h, dtype=torch.float64).view(h, 1).expand(h, w)
+    xs = torch.arange(w, dtype=torch.float64).view(1, w).expand(h, w)
+    xmin, xmax = xs / w * 2 - 1, (xs + 1) / w * 2 - 1
+    ymin, ymax = ys / h * 2 - 1, (ys + 1) / h * 2 - 1
+    grid = torch.stack([xmin, ymin, xmax, ymax, (xmin + xmax) / 2, (ymin + ymax) / 2,
+                        torch.full_like(xs, 1 / w), torch.full_like(xs, 1 / h)], -1)
+    sp[:, :8] = grid.reshape(h * w, 8).float()
+    return sp
+
+
 class Ctx:
     """Per-model handles shared by every stage operator."""
 
@@ -188,16 +203,7 @@ class Ctx:
         self.cfg, self.ps, self.dt = cfg, store, vis_dt
         self.dev = store.device
         B, N = cfg.batch_size, cfg.N
-        # spatial grid [B*N, 64] (8 coordinate channels, util/processing_tools.py:5-17; zero padded)
-        sp = torch.zeros(N, 64, dtype=torch.float32)
-        h, w = cfg.vf_h, cfg.vf_w
-        ys = torch.arange(h, dtype=torch.float64).view(h, 1).expand(h, w)
-        xs = torch.arange(w, dtype=torch.float64).view(1, w).expand(h, w)
-        xmin, xmax = xs / w * 2 - 1, (xs + 1) / w * 2 - 1
-        ymin, ymax = ys / h * 2 - 1, (ys + 1) / h * 2 - 1
-        grid = torch.stack([xmin, ymin, xmax, ymax, (xmin + xmax) / 2, (ymin + ymax) / 2,
-                            torch.full_like(xs, 1 / w), torch.full_like(xs, 1 / h)], -1)
-        sp[:, :8] = grid.reshape(N, 8).float()
+        sp = spatial_grid_padded(cfg.vf_h, cfg.vf_w)
         self.spatial = sp.repeat(B, 1).to(self.dev).to(tdt(vis_dt)).contiguous()
         self.anchor = torch.zeros((), device=self.dev, requires_grad=True)
         self.wg = None              # weight-gradient stream (set by LSTM_model.set_streams)
