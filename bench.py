@@ -47,41 +47,6 @@ def synth_batch(B, T, H, W, vocab, seed):
     return words, np.ascontiguousarray(im), seq_len, target
 
 
-class GemmTimer:
-    """Wraps ops.gemm_nt: an event pair on the launch stream around every bf16 launch, plus the
-    algorithmic FLOPs of that launch (2*M*n_valid*K_valid, pad columns/rows not counted)."""
-
-    def __init__(self, ops, cfg):
-        self.ops, self.orig, self.rec, self.on = ops, ops.gemm_nt, [], False
-        # padded extent -> algorithmic extent (collisions with the 512/1024/2048 backbone widths
-        # only ever under-count)
-        C, M, Cp, Mp = cfg.v_emb_dim, cfg.mlp_dim, cfg.Cp, cfg.Mp
-        self.valid = {Cp: C, Mp: M, 64: 8, 5 * Cp: 5 * C, 4 * Mp: 4 * M}
-
-    def install(self):
-        ops, orig, me = self.ops, self.orig, self
-
-        def timed(dt, segs, C, ldc, M, N, n_valid=None, batch=1, **kw):
-            if not me.on or dt != 1 or N < 128 or M < 512:      # only launches that dispatch to gemm_nt_v2_kernel<bf16>
-                return orig(dt, segs, C, ldc, M, N, n_valid=n_valid, batch=batch, **kw)
-            k_alg = sum(me.valid.get(s[4], s[4]) for s in segs)
-            nv = N if n_valid is None else n_valid
-            nv = me.valid.get(nv, nv) if nv != 64 else nv
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            orig(dt, segs, C, ldc, M, N, n_valid=n_valid, batch=batch, **kw)
-            e1.record()
-            # algorithmic bytes of the launch: A [M, K] and C [M, N] once per batch entry, the weight [N, K] once (bf16)
-            me.rec.append((e0, e1, 2.0 * M * batch * nv * k_alg, 2.0 * (M * batch * (k_alg + nv) + nv * k_alg)))
-        ops.gemm_nt = timed
-
-    def summary(self):
-        t = sum(r[0].elapsed_time(r[1]) for r in self.rec) * 1e-3
-        f = sum(r[2] for r in self.rec)
-        self.alg_bytes = sum(r[3] for r in self.rec)
-        return t, f, len(self.rec)
-
-
 def cpu_baseline(args):
     """The oracle (test infrastructure) timed as the CPU baseline: one full train step
     (backbone forward + head forward/backward + TF-Adam) on `cpu_images` synthetic images."""
@@ -151,7 +116,6 @@ def main():
     dev = torch.device(f"cuda:{local}")
 
     pkg = importlib.import_module("cmpc-refseg_amd")
-    ops = importlib.import_module("cmpc-refseg_amd.ops")
     B, T, H, W = args.batch, 20, 320, 320
     log("building model")
     model = pkg.LSTM_model(batch_size=B, num_steps=T, H=H, W=W, mode="train", dtype=args.dtype, device=str(dev))
@@ -164,19 +128,15 @@ def main():
     torch.cuda.synchronize()
     ready = torch.cuda.Event()
     ready.record()                                   # the synthetic batch is resident in HBM from here on
-    timer = GemmTimer(ops, model.cfg)
-    if not args.no_kernel_timing:
-        timer.install()
 
     def barrier():
         if world > 1:
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
-    model.capture(words, im, target, seq_len)          # set-up: HIP-graph capture of forward+backward (no optimizer step)
-    # Set-up, not warm-up: the caching allocator needs ~8 steps to size its pools for two steps in flight on six
-    # streams (about 200 hipMalloc calls in all); they are taken here so that the W warm-up steps and the K timed
-    # steps below run on a settled allocator whatever W is.
+    # Set-up, not warm-up: the first passes size the library's per-stream partial-sum workspaces, run MIOpen's search for
+    # the stem convolution and capture the two backbone graphs; they are taken here so that the W warm-up steps and the K
+    # timed steps below run in steady state whatever W is.
     SETUP_STEPS = 6
     for _ in range(SETUP_STEPS):
         model.train_step(words, im, target, seq_len, ready=ready)
@@ -192,22 +152,23 @@ def main():
         _, scal = model.train_step(words, im, target, seq_len, ready=ready)
     barrier()
     dt = time.perf_counter() - t0
-    # Per-launch timing of the dominant kernel: in the timed region above the three pyramid levels run
-    # on three streams, so a kernel's start->end event interval also contains other streams' kernels.
-    # The event pairs are therefore taken over the same K steps re-run on ONE stream (same kernels,
-    # same shapes, same data), which is also how the committed rocprof summary is collected.
+    launches = model.eng.launch_count()            # library launches of the last forward + backward + optimizer step
+    # Per-launch timing of the dominant kernel family: in the timed region above the three pyramid levels run on three
+    # lane streams, so a kernel's start->end event interval also contains other streams' kernels.  The event pairs
+    # (cmpc_kernel_timing: hipEvents on the stream each launch is issued on, inside the library) are therefore taken over the
+    # same K steps re-run on ONE stream (same kernels, same shapes, same data), which is also how the committed rocprof
+    # summary is collected.
+    ktime = None
     if not args.no_kernel_timing:
-        model.set_streams(1)
-        model.use_graph = False                       # eager launches, so that every launch can be bracketed
+        model.set_lanes(1)
         model.train_step(words, im, target, seq_len)
         torch.cuda.synchronize()
-        timer.on = True
+        model.eng.kernel_timing(True)
         for _ in range(args.steps):
             model.train_step(words, im, target, seq_len)
-        torch.cuda.synchronize()
-        timer.on = False
-        model.set_streams(int(os.environ.get("CMPC_STREAMS", "3")))
-        model.use_graph = os.environ.get("CMPC_GRAPH", "0") != "0"
+        ktime = model.eng.kernel_timing_read()
+        model.eng.kernel_timing(False)
+        model.set_lanes(3 if int(os.environ.get("CMPC_STREAMS", "3")) > 1 else 1)
     # forward-only rate (SURVEY 8d reports both): sess.run([pred, up, sigm]) on the same batch, same K
     dt_fwd = None
     if not args.no_forward_only:
@@ -239,20 +200,21 @@ def main():
         if dt_fwd is not None:
             out["forward_only"] = {"images_per_sec": B * world * args.steps / dt_fwd, "ms_per_step": 1e3 * dt_fwd / args.steps,
                                    "what": "model.forward: backbone + head forward -> pred, up, sigm (rank-0 clock)"}
-        if not args.no_kernel_timing and timer.rec:
-            t, f, n = timer.summary()
+        out["head_launches_per_step"] = launches
+        if ktime is not None and ktime[3] > 0:
+            t, f, by, n = ktime
             peak = 2500.0 if args.dtype == "bf16" else 157.3
             # HBM-side bytes per launch from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE on this
             # same command, scripts/pmc_traffic.py); bench.py cannot run the profiler on itself
             traffic = None
-            tp = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_gemm_nt_traffic.json")
+            tp = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r02_gemm_nt_traffic.json")
             if args.dtype == "bf16" and B == 8 and os.path.exists(tp):
                 traffic = json.load(open(tp))["hbm_bytes_per_launch"]
             out["roofline"] = {"bound": "mfma", "achieved": f / t / 1e12, "peak": peak, "unit": "TFLOP/s",
                                "frac": f / t / 1e12 / peak, "traffic": traffic,
-                               "algorithmic_bytes_per_launch": timer.alg_bytes / n,
-                               "kernel": "gemm_nt_v4/v3_kernel<bf16> (all 1x1-conv / dX products of the head)",
-                               "measured": "event pairs around every launch over the same K steps re-run on ONE stream (in the timed region 4 streams overlap, so a start->end interval there also contains other streams' kernels)",
+                               "algorithmic_bytes_per_launch": by / n,
+                               "kernel": "gemm_nt_v5/v4/v3_kernel<bf16> (every 1x1-conv / dX product of the head)",
+                               "measured": "hipEvent pairs around every launch (cmpc_kernel_timing, on the launch stream) over the same K steps re-run on ONE stream (in the timed region the lane streams overlap, so a start->end interval there also contains other streams' kernels)",
                                "launches_per_step": n / args.steps, "ms_per_step_in_kernel": 1e3 * t / args.steps}
         if world == 1 and not args.no_cpu_baseline:
             log("cpu baseline (oracle on host cores)")

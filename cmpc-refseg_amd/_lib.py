@@ -90,7 +90,32 @@ class AdamSeg(C.Structure):
     _fields_ = [("off", C.c_int64), ("count", C.c_int), ("wd", C.c_float), ("gmult", C.c_float)]
 
 
+class EngineCfg(C.Structure):
+    """cmpc_cfg (include/cmpc.h)"""
+    _fields_ = [
+        ("batch_size", C.c_int), ("num_steps", C.c_int), ("vf_h", C.c_int), ("vf_w", C.c_int), ("H", C.c_int), ("W", C.c_int),
+        ("vf_dim", C.c_int), ("c4_dim", C.c_int), ("c3_dim", C.c_int),
+        ("vocab_size", C.c_int), ("v_emb_dim", C.c_int), ("mlp_dim", C.c_int), ("rnn_size", C.c_int), ("glove_dim", C.c_int),
+        ("parse_dim", C.c_int),
+        ("start_lr", C.c_double), ("end_lr", C.c_double), ("lr_power", C.c_double), ("lr_decay_step", C.c_int),
+        ("weight_decay", C.c_float), ("loss_w", C.c_float * 4),
+        ("dtype", C.c_int), ("n_lanes", C.c_int), ("device", C.c_int),
+    ]
+
+
+class Feeds(C.Structure):
+    """cmpc_feeds"""
+    _fields_ = [("words", C.c_void_p), ("seq_len", C.c_void_p), ("c3", C.c_void_p), ("c4", C.c_void_p), ("c5", C.c_void_p),
+                ("target_fine", C.c_void_p), ("feats_ready", C.c_void_p)]
+
+
+class Fetches(C.Structure):
+    """cmpc_fetches"""
+    _fields_ = [("pred", C.c_void_p), ("up", C.c_void_p), ("sigm", C.c_void_p)]
+
+
 _P, _I, _F, _L = C.c_void_p, C.c_int, C.c_float, C.c_int64
+_PP = C.POINTER(C.c_void_p)
 
 # name -> argtypes (return type is always int).  Must list every symbol include/cmpc.h declares.
 SIGNATURES = {
@@ -143,7 +168,31 @@ SIGNATURES = {
     "cmpc_pack_weights": [_P, _P, _P, _P, _I, _I, _P],
     "cmpc_pack_weights_range": [_P, _P, _P, _P, _P, _I, _I, _I, _P],
     "cmpc_adam_step": [_P, _P, _P, _P, _P, _I, _F, _F, _F, _F, _F, _P],
+    # whole-path entry points (handle = void*)
+    "cmpc_default_cfg": [C.POINTER(EngineCfg)],
+    "cmpc_create": [C.POINTER(EngineCfg), _PP],
+    "cmpc_destroy": [_P],
+    "cmpc_param_info": [_P, _I, C.POINTER(C.c_char_p), C.POINTER(_L), C.POINTER(_I), C.POINTER(_L * 4)],
+    "cmpc_buffers": [_P, _PP, _PP, _PP, _PP, C.POINTER(_L)],
+    "cmpc_set_weights": [_P, C.c_char_p, _P, _L],
+    "cmpc_get_weights": [_P, C.c_char_p, _P, _L],
+    "cmpc_pack": [_P, _P],
+    "cmpc_get_step": [_P, C.POINTER(_L)],
+    "cmpc_set_step": [_P, _L],
+    "cmpc_forward": [_P, C.POINTER(Feeds), C.POINTER(Fetches), _P],
+    "cmpc_backward": [_P, _P],
+    "cmpc_optimizer_step": [_P, _F, _P, C.POINTER(C.c_double)],
+    "cmpc_tap": [_P, C.c_char_p, _PP, C.POINTER(_I), C.POINTER(_I), C.POINTER(_L * 4)],
+    "cmpc_tap_name": [_P, _I, C.POINTER(C.c_char_p)],
+    "cmpc_launch_count": [_P, C.POINTER(_L)],
+    "cmpc_set_lanes": [_P, _I],
+    "cmpc_kernel_timing": [_P, _I],
+    "cmpc_kernel_timing_read": [_P, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(_L)],
+    "cmpc_plan_info": [_P, C.POINTER(C.POINTER(PackDesc)), C.POINTER(_I), C.POINTER(_L), C.POINTER(_L), C.POINTER(_I)],
+    "cmpc_operand_info": [_P, C.c_char_p, C.POINTER(_L), C.POINTER(_I), C.POINTER(_I), C.POINTER(_I)],
 }
+# entry points that return a count, not a status
+COUNTS = {"cmpc_param_count": [_P], "cmpc_tap_count": [_P]}
 
 _lib = None
 
@@ -166,6 +215,10 @@ def load():
     lib.cmpc_abi_version.argtypes = []
     for name, argtypes in SIGNATURES.items():
         fn = getattr(lib, name)          # AttributeError if a declared symbol is not exported
+        fn.restype = C.c_int
+        fn.argtypes = argtypes
+    for name, argtypes in COUNTS.items():
+        fn = getattr(lib, name)
         fn.restype = C.c_int
         fn.argtypes = argtypes
     _lib = lib

@@ -1,8 +1,10 @@
 """DeepLab-ResNet-101 (output stride 8), frozen -- the reference's visual backbone
 (external/tensorflow-deeplab-resnet/deeplab_resnet/model.py:19-401 on kaffe/tensorflow/network.py:105-270).
 
-Per BASELINE.json's north_star the backbone runs on PyTorch-ROCm (MIOpen convolutions), not on the
-hand-written kernels; it is inference-only (is_training=False, CMPC_model.py:73), so every slim
+BASELINE.json's north_star allows the backbone on PyTorch-ROCm; here only the 7x7 stem convolution and the
+max-pool are torch (MIOpen) calls: every 1x1 / 3x3 convolution runs on the implicit-GEMM HIP kernel
+(cmpc_conv_nhwc, csrc/gemm.hip) with the folded-BN shift, residual add and ReLU in its epilogue.  The backbone is
+inference-only (is_training=False, CMPC_model.py:73), so every slim
 batch_norm (epsilon 1e-3, network.py:260-270) is folded into its convolution at load time.
 TF 'SAME' padding is reproduced explicitly: the 7x7/2 stem pads (2,3), the 3x3/2 max-pool pads
 (0,1) with -inf, dilated 3x3 convolutions pad by their rate.
@@ -98,12 +100,16 @@ class _ConvBN(nn.Module):
         w = p[f"{conv}/weights"].double().permute(3, 2, 0, 1) * sc.view(-1, 1, 1, 1)      # HWIO -> OIHW
         self.weight.data.copy_(w.to(self.weight.dtype))
         self.bias.data.copy_(sh.to(self.bias.dtype))
-        self.bias32.copy_(sh.float())
+        self._shift32 = sh.float().cpu()              # exact fp32 master of the folded-BN shift: a plain attribute, so no
+        self.bias32.copy_(self._shift32)              # module-wide dtype cast can round it (see _apply)
         self.w_ohwi.copy_(w.permute(0, 2, 3, 1).reshape(w.shape[0], -1).to(self.w_ohwi.dtype))
 
     def _apply(self, fn, *a, **kw):
         out = super()._apply(fn, *a, **kw)
-        self.bias32 = self.bias32.float()          # the epilogue kernel always reads an fp32 shift
+        # the epilogue kernel always reads an fp32 shift.  super()._apply has just pushed the buffer through `fn`
+        # (.to(bfloat16) rounds it to 8 bits): restore it from the exact master instead of widening the rounded copy.
+        shift = getattr(self, "_shift32", None)
+        self.bias32 = shift.to(self.bias32.device) if shift is not None else self.bias32.float()
         self.zeros = self.zeros.to(torch.uint8)
         return out
 

@@ -1,0 +1,1384 @@
+// engine.hip -- whole-path entry points of the C ABI (include/cmpc.h: cmpc_create / cmpc_forward / cmpc_backward /
+// cmpc_optimizer_step / cmpc_destroy): LSTM_model.build_graph() + train_op() of the reference
+// (/root/reference/CMPC_model.py:89-142,426-492) as ONE C++ object that owns the parameters, the packed GEMM
+// operands, a static workspace for every intermediate of a step, three lane streams and their events, and
+// enqueues the stage kernels of this library directly -- no Python, no autograd, no allocation and no environment
+// lookups in a step.  The backward pass is hand-sequenced (reverse stage order, fan-out gradients summed explicitly).
+//
+// Stage order and stream plan (forward; backward mirrors it):
+//   main : text encoder (lstm, :144-164) -> parser (:347-357) -> valid_lang (:166-178)      [overlaps the backbone]
+//   lanes: c5 | c4 | c3 : lateral+l2norm (:108-113) -> mutan (:295-328) -> spa_graph (:359-410) -> fusion (:338-344)
+//                         -> score_cX + upsample + BCE (:128-133,440-443)
+//   main : nec_lang (:180-192)
+//   lanes: gated exchange round 1 (:271-276), join, round 2 (:278-284)
+//   main : ConvLSTM over (c3, c4, c5) (:287-290, util/cell.py:36-79) -> score + upsample + sigmoid + BCE + mIoU
+#include "cmpc_common.h"
+#include "../../include/cmpc.h"
+#include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <array>
+#include <string.h>
+#include <algorithm>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+extern long g_cmpc_launches;     // ops_norm.hip: bumped by cmpc_check_launch
+
+namespace {
+
+#define CK(x) do { const int _rc = (x); if (_rc != CMPC_OK) return _rc; } while (0)
+#define HCK(x) do { const hipError_t _e = (x); if (_e != hipSuccess) { cmpc_set_error("%s: %s", #x, hipGetErrorString(_e)); return CMPC_EHIP; } } while (0)
+
+inline int pad64(int x) { return (x + 63) / 64 * 64; }
+inline size_t up256(size_t x) { return (x + 255) / 256 * 256; }
+
+// ------------------------------------------------------------------------------------------
+// small kernels of the orchestration itself (everything else lives in the stage files)
+// ------------------------------------------------------------------------------------------
+struct AddArgs { const void* src[8]; int n; };
+
+// dst[i] = (acc ? dst[i] : 0) + sum_k src_k[i]   (fan-out gradients of a stage output; 8 elements per lane)
+template <typename T>
+__global__ __launch_bounds__(256) void add_n_kernel(T* __restrict__ dst, AddArgs a, int acc, long n8) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (long)gridDim.x * blockDim.x) {
+        float s[8];
+        if (acc) ld8<T>(dst + i * 8, s);
+        else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) s[e] = 0.f;
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            if (k < a.n) {
+                float v[8];
+                ld8<T>(reinterpret_cast<const T*>(a.src[k]) + i * 8, v);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) s[e] += v[e];
+            }
+        }
+        st8<T>(dst + i * 8, s);
+    }
+}
+
+__global__ void transpose_i32_kernel(const int* __restrict__ src, int* __restrict__ dst, int rows, int cols) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;          // dst[c][r] = src[r][c]
+    if (i < rows * cols) { const int r = i / cols, c = i - r * cols; dst[c * rows + r] = src[i]; }
+}
+// dst[i] = src[i*stride + col]
+__global__ void col_get_kernel(const float* __restrict__ src, int stride, int col, float* __restrict__ dst, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] = src[(long)i * stride + col];
+}
+// dst[i*stride + col] += a[i] + b[i] + c[i]
+__global__ void col_add3_kernel(float* __restrict__ dst, int stride, int col, const float* __restrict__ a, const float* __restrict__ b,
+                                const float* __restrict__ c, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[(long)i * stride + col] += a[i] + b[i] + c[i];
+}
+// scalars[0..5] = loss_all, loss_c3, loss_c4, loss_c5, loss_last, mIoU  (CMPC_model.py:440-447,486-490)
+__global__ void scalars_kernel(const float* __restrict__ l_last, const float* __restrict__ l5, const float* __restrict__ l4, const float* __restrict__ l3,
+                               const int* __restrict__ inter, const int* __restrict__ uni, int B, float w0, float w5, float w4, float w3,
+                               float* __restrict__ out) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    float a = 0.f, b5 = 0.f, b4 = 0.f, b3 = 0.f;
+    double iou = 0.0;
+    for (int b = 0; b < B; ++b) { a += l_last[b]; b5 += l5[b]; b4 += l4[b]; b3 += l3[b]; iou += (double)inter[b] / (double)uni[b]; }
+    a /= B; b5 /= B; b4 /= B; b3 /= B;
+    out[0] = w0 * a + w5 * b5 + w4 * b4 + w3 * b3;
+    out[1] = b3; out[2] = b4; out[3] = b5; out[4] = a;
+    out[5] = (float)(iou / B);
+}
+
+// ------------------------------------------------------------------------------------------
+struct ParamSpec { std::string name; int rank; int64_t shape[4]; int64_t count; int64_t off; float wd; float gmult; };
+struct Operand { size_t off; int dt; int rows; int ld; };
+struct Tap { std::string name; void* ptr; int dt; int rank; int64_t shape[4]; };
+
+struct GemmOpt {
+    int n_valid = -1, batch = 1; int64_t sC = 0; int c_f32 = 0;
+    const float* bias = nullptr; const float* sbias = nullptr; int ld_sbias = 0;
+    const float* pbias = nullptr; int ld_pbias = 0; int rows_per_sample = 0;
+    int act = ACT_NONE; float alpha = 1.f; int accumulate = 0;
+};
+struct Seg { const void* A; int lda; const void* Bt; int ldb; int K; int64_t sA = 0; int64_t sB = 0; };
+
+// bump allocator: first pass (base == nullptr) measures, second pass assigns
+struct Bump {
+    char* base = nullptr; size_t off = 0;
+    void* take(size_t bytes) { void* p = base ? base + off : nullptr; off += up256(bytes); return p; }
+};
+
+struct LevelBuf {          // one pyramid level (c5 / c4 / c3), forward then backward
+    int cin;
+    const void* feat;
+    void *X0, *P, *X1, *PT, *PTt, *gw_w_t, *gw_v_t, *Zt, *Y, *G, *U, *X2, *F;
+    float *lat_rstd, *g, *mut_rstd, *Wd, *PTf, *PTtf, *k0s, *A0, *pr, *gw_w, *gw_v, *gsc, *Ztf, *rrow, *sb;
+    double *sums1, *sums2;
+    float *score, *up, *loss; int* iu;
+    // backward
+    void *dfus, *dpre, *dX1, *dX2, *dU, *dG, *dY, *Z, *dZ, *dZt, *dA0_t, *dX0, *dV;
+    float *dscore, *dsb, *dvl, *Zf, *dgw_w, *dZf, *dZtf, *dgw_v, *dA0, *dpr, *gsc2, *dPT, *dk0s, *dWd, *dwf, *dg;
+    double* bs;
+};
+struct ExgBuf {            // one gated_exchange_module
+    float *q, *kq, *logits, *attn, *pooled, *gvpre, *gv, *rs1, *g[2], *rstd;
+    void *r[2], *out;
+    void *dfeat, *dp[2], *dfs[2];
+    float *dg[2], *dgv, *dgvpre, *dpooled, *dnec, *dattn, *dlog, *dkq, *dq;
+};
+struct ClstmStep { void *Yg, *c_pre, *c_new, *h_new, *dYg, *dc_prev, *dx, *dh; double* sums; };
+
+}  // namespace
+
+struct cmpc_engine_s {
+    cmpc_cfg cfg;
+    int B, T, N, R, C, Cp, M, Mp, G, Gp, P, Pp, Tp, RNN, dt, esz, h, w, H, W, V;
+    // parameters
+    std::vector<ParamSpec> specs;
+    std::unordered_map<std::string, int> pindex;
+    int64_t total = 0;
+    float *params = nullptr, *grads = nullptr, *adam_m = nullptr, *adam_v = nullptr;
+    // packed operands
+    std::vector<cmpc_pack_desc> descs;
+    std::unordered_map<std::string, Operand> ops;
+    size_t arena_bytes = 0;
+    char* arena = nullptr;
+    cmpc_pack_desc* descs_dev = nullptr; int* tile_prefix_dev = nullptr; int* tile_desc_dev = nullptr;
+    int ndesc = 0, total_tiles = 0, stage0_ndesc = 0, stage0_tiles = 0;
+    cmpc_adam_seg* segs_dev = nullptr; int nseg = 0;
+    int64_t step = 0;
+    // workspace: [zero_fwd | zero_bwd | rest]
+    char* ws = nullptr; size_t ws_bytes = 0, zf_bytes = 0, zb_bytes = 0;
+    void* zero_page = nullptr;
+    // streams / events
+    hipStream_t lane[3] = {nullptr, nullptr, nullptr};
+    std::vector<hipEvent_t> evpool; size_t evnext = 0;
+    hipEvent_t ev_opt0 = nullptr, ev_opt1 = nullptr; bool opt_pending = false;
+    // buffers
+    void* spatial = nullptr;
+    int* words_tb; float *emb, *xg, *gates, *h_all, *c_all, *outs, *wf, *wf_rstd, *mask;
+    float *douts, *dh, *dc, *dgt, *demb;
+    float *h1, *lg, *parse, *dlg, *dh1;
+    float *vl, *vl_rstd, *nec, *nec_rstd, *dparse, *dwf, *dvl, *dnec;
+    LevelBuf lv[3];                 // c5, c4, c3
+    ExgBuf ex[6];                   // c3, c4, c5, c3_2, c4_2, c5_2
+    void* de1[3];                   // gradients of the round-1 outputs (c3, c4, c5)
+    ClstmStep cl[3]; void* cl_scr; double* cl_bs;
+    float *score, *up, *sigm, *loss; int* iu; float *dscore; void* dfused;
+    float* scalars;
+    bool have_target = false;
+    const int32_t* seq_len_feed = nullptr; const float* target_feed = nullptr;      // caller-owned feeds the backward pass re-reads
+    hipStream_t last_main = nullptr; long l0 = 0;
+    std::vector<cmpc_gemm_tn_args> deferred;
+    std::vector<Tap> taps;
+    std::unordered_map<std::string, int> tapindex;
+    long launches_step = 0;
+    // optional per-launch timing of the dominant kernel family (bench.py's roofline): event pairs around every bf16 MFMA gemm_nt
+    bool timing = false; std::vector<hipEvent_t> tev; std::vector<double> tflops, tbytes;
+};
+
+namespace {
+typedef cmpc_engine_s E;
+const char* LEVELS[3] = {"c5", "c4", "c3"};
+const char* EXG[6] = {"c3", "c4", "c5", "c3_2", "c4_2", "c5_2"};
+
+std::string fmt(const char* f, ...) {
+    char buf[256]; va_list ap; va_start(ap, f); vsnprintf(buf, sizeof(buf), f, ap); va_end(ap); return buf;
+}
+
+// ------------------------------------------------------------------------------------------
+// parameter manifest: names, shapes, creation order of the variables under scope "text_objseg"
+// (CMPC_model.py:84; _conv :412-417; lstm :144-156; layer_norm :364,370; util/cell.py:42-66)
+// ------------------------------------------------------------------------------------------
+void add_param(E* e, const std::string& name, std::initializer_list<int64_t> shape, float wd, float gmult) {
+    ParamSpec s; s.name = "text_objseg/" + name; s.rank = (int)shape.size(); s.count = 1; int i = 0;
+    for (int64_t d : shape) { s.shape[i++] = d; s.count *= d; }
+    for (; i < 4; ++i) s.shape[i] = 1;
+    s.off = e->total; s.wd = wd; s.gmult = gmult;
+    e->total += (s.count + 3) / 4 * 4;                    // every parameter 16-B aligned
+    e->pindex[s.name] = (int)e->specs.size();
+    e->specs.push_back(s);
+}
+void add_conv(E* e, const std::string& name, int k, int cin, int cout) {
+    add_param(e, name + "/DW", {k, k, cin, cout}, e->cfg.weight_decay, 1.f);     // 'DW' -> L2 (:433)
+    add_param(e, name + "/biases", {cout}, 0.f, 2.f);                            // 'biases' -> gradient x2 (:464-465)
+}
+void add_ln(E* e, const std::string& scope, int dim) {
+    add_param(e, scope + "/beta", {dim}, 0.f, 1.f);
+    add_param(e, scope + "/gamma", {dim}, 0.f, 1.f);
+}
+void build_manifest(E* e) {
+    const int C = e->C, M = e->M, R = e->RNN;
+    add_param(e, "Variable", {e->V, e->G}, 0.f, 1.f);
+    add_param(e, "rnn/lstm_cell/kernel", {e->G + R, 4 * R}, 0.f, 1.f);
+    add_param(e, "rnn/lstm_cell/bias", {4 * R}, 0.f, 1.f);
+    add_conv(e, "c5_lateral", 1, e->cfg.vf_dim, C);
+    add_conv(e, "c4_lateral", 1, e->cfg.c4_dim, C);
+    add_conv(e, "c3_lateral", 1, e->cfg.c3_dim, C);
+    add_conv(e, "words_parse_1", 1, R, e->P);
+    add_conv(e, "words_parse_2", 1, e->P, 4);
+    for (const char* lv : LEVELS) {
+        for (int hd = 1; hd <= 5; ++hd) {
+            add_conv(e, fmt("vis_trans_%s_head%d", lv, hd), 1, C + 8, C);
+            add_conv(e, fmt("lang_trans_%s_head%d", lv, hd), 1, R, C);
+        }
+        add_conv(e, fmt("words_trans_%s", lv), 1, R, R);
+        add_conv(e, fmt("spa_graph_trans2_%s", lv), 1, C, C);
+        add_ln(e, fmt("gconv_feat_ln_spa_graph_%s", lv), C);
+        add_conv(e, fmt("gconv_update_spa_graph_%s", lv), 1, C, C);
+        add_ln(e, fmt("gconv_update_ln_spa_graph_%s", lv), C);
+        add_conv(e, fmt("fusion_%s", lv), 1, 2 * C + R + 8, M);
+    }
+    for (const char* lv : LEVELS) add_conv(e, fmt("score_%s", lv), 3, M, 1);
+    for (const char* x : EXG) {
+        add_conv(e, fmt("spa_graph_key_%sgv_f1", x), 1, M, M);
+        add_conv(e, fmt("lang_query_%sgv_f1", x), 1, R, M);
+        add_conv(e, fmt("gv_lang_%sgv_f1", x), 1, M + R, M);
+        add_conv(e, fmt("lang_feat_%s_f1", x), 1, M, M);
+        add_conv(e, fmt("trans_feat_%s_f1", x), 1, M, M);
+        add_conv(e, fmt("lang_feat_%s_f2", x), 1, M, M);
+        add_conv(e, fmt("trans_feat_%s_f2", x), 1, M, M);
+    }
+    const std::string pre = "rnn/conv_lstm_cell";
+    add_param(e, pre + "/kernel", {1, 1, 2 * M, 4 * M}, 0.f, 1.f);
+    add_param(e, pre + "/W_ci", {e->h, e->w, M}, 0.f, 1.f);
+    add_param(e, pre + "/W_cf", {e->h, e->w, M}, 0.f, 1.f);
+    add_ln(e, pre + "/LayerNorm", M);
+    add_ln(e, pre + "/LayerNorm_1", M);
+    add_ln(e, pre + "/LayerNorm_2", M);
+    add_param(e, pre + "/W_co", {e->h, e->w, M}, 0.f, 1.f);
+    add_ln(e, pre + "/LayerNorm_3", M);
+    add_ln(e, pre + "/LayerNorm_4", M);
+    add_conv(e, "score", 3, M, 1);
+}
+
+inline const ParamSpec& spec(const E* e, const std::string& name) { return e->specs[e->pindex.at("text_objseg/" + name)]; }
+inline int64_t poff(const E* e, const std::string& name) { return spec(e, name).off; }
+inline float* pptr(const E* e, const std::string& name, int64_t elem = 0) { return e->params + poff(e, name) + elem; }
+inline float* gptr(const E* e, const std::string& name, int64_t elem = 0) { return e->grads + poff(e, name) + elem; }
+
+// ------------------------------------------------------------------------------------------
+// operand plan: zero-padded packed copies of the masters, '<key>.t' = [Np][Kp] (output-major, forward) and
+// '<key>.n' = [Kp][Np] (input-major, dX); concatenations of the reference are K-segments of one operand
+// ------------------------------------------------------------------------------------------
+typedef std::vector<std::array<int, 3>> Segs;      // (src, len, dst)
+
+Operand& new_operand(E* e, const std::string& key, int dt, int rows, int ld) {
+    const int esz = dt == DT_F32 ? 4 : 2;
+    Operand op{e->arena_bytes, dt, rows, ld};
+    e->arena_bytes += up256((size_t)rows * ld * esz);
+    return e->ops[key] = op;
+}
+void add_desc(E* e, const Operand& op, const std::string& pname, int ld_src, int transpose, int row0, int col0, int rows, int cols,
+              const Segs& ks, const Segs& ns) {
+    const int esz = op.dt == DT_F32 ? 4 : 2;
+    cmpc_pack_desc d; memset(&d, 0, sizeof(d));
+    d.src_off = poff(e, pname); d.ld_src = ld_src;
+    d.dst_off = (int64_t)op.off + ((int64_t)row0 * op.ld + col0) * esz;
+    d.dst_dt = op.dt; d.transpose = transpose;
+    d.rows = rows; d.cols = cols; d.ld_dst = op.ld;
+    d.nks = (int)ks.size();
+    for (size_t i = 0; i < ks.size(); ++i) { d.ks_src[i] = ks[i][0]; d.ks_len[i] = ks[i][1]; d.ks_dst[i] = ks[i][2]; }
+    d.nns = (int)ns.size();
+    for (size_t i = 0; i < ns.size(); ++i) { d.ns_src[i] = ns[i][0]; d.ns_len[i] = ns[i][1]; d.ns_dst[i] = ns[i][2]; }
+    e->descs.push_back(d);
+}
+void linear(E* e, const std::string& key, const std::string& pname, int dt, int K, int N, int Kp, int Np, bool fwd = true, bool bwd = true,
+            Segs ks = {}, Segs ns = {}) {
+    if (ks.empty()) ks = {{0, K, 0}};
+    if (ns.empty()) ns = {{0, N, 0}};
+    const ParamSpec& s = spec(e, pname);
+    const int ld_src = (int)s.shape[s.rank - 1];
+    if (fwd) { Operand& op = new_operand(e, key + ".t", dt, Np, Kp); add_desc(e, op, pname, ld_src, 1, 0, 0, Np, Kp, ks, ns); }
+    if (bwd) { Operand& op = new_operand(e, key + ".n", dt, Kp, Np); add_desc(e, op, pname, ld_src, 0, 0, 0, Kp, Np, ks, ns); }
+}
+void plan_operands(E* e) {
+    const int C = e->C, M = e->M, R = e->RNN, G = e->G, P = e->P, Cp = e->Cp, Mp = e->Mp, Gp = e->Gp, Pp = e->Pp;
+    const int V = e->dt, L = DT_F32;
+    // text LSTM: kernel [G+R, 4R], gates i,j,f,o -> padded gate blocks of Cp
+    Segs gate_ns; for (int g = 0; g < 4; ++g) gate_ns.push_back({g * R, R, g * Cp});
+    linear(e, "lstm", "rnn/lstm_cell/kernel", L, G + R, 4 * R, Gp + Cp, 4 * Cp, true, true, {{0, G, 0}, {G, R, Gp}}, gate_ns);
+    { Operand& ob = new_operand(e, "lstm.b", L, 1, 4 * Cp); add_desc(e, ob, "rnn/lstm_cell/bias", 4 * R, 0, 0, 0, 1, 4 * Cp, {{0, 1, 0}}, gate_ns); }
+    linear(e, "parse1", "words_parse_1/DW", L, R, P, Cp, Pp);
+    linear(e, "parse2", "words_parse_2/DW", L, P, 4, Pp, 64);
+    e->stage0_ndesc = (int)e->descs.size();       // what the text encoder + parser read: packed (and published) first
+    const int cins[3] = {e->cfg.vf_dim, e->cfg.c4_dim, e->cfg.c3_dim};
+    for (int i = 0; i < 3; ++i) linear(e, fmt("lat_%s", LEVELS[i]), fmt("%s_lateral/DW", LEVELS[i]), V, cins[i], C, pad64(cins[i]), Cp, true, false);
+    for (const char* lv : LEVELS) {
+        // mutan: five heads side by side; forward operand [5Cp][Cp+64] (k: C visual rows, then the 8 spatial rows)
+        Operand opt = new_operand(e, fmt("mutan_%s.t", lv), V, 5 * Cp, Cp + 64);
+        Operand opn = new_operand(e, fmt("mutan_%s.n", lv), V, Cp, 5 * Cp);
+        Operand lgt = new_operand(e, fmt("mlang_%s.t", lv), L, 5 * Cp, Cp);
+        Operand lgn = new_operand(e, fmt("mlang_%s.n", lv), L, Cp, 5 * Cp);
+        Operand opb = new_operand(e, fmt("mutan_%s.b", lv), L, 1, 5 * Cp);
+        Operand lgb = new_operand(e, fmt("mlang_%s.b", lv), L, 1, 5 * Cp);
+        for (int hd = 0; hd < 5; ++hd) {
+            const std::string pn = fmt("vis_trans_%s_head%d/DW", lv, hd + 1), pl = fmt("lang_trans_%s_head%d/DW", lv, hd + 1);
+            add_desc(e, opt, pn, C, 1, hd * Cp, 0, Cp, Cp + 64, {{0, C, 0}, {C, 8, Cp}}, {{0, C, 0}});
+            add_desc(e, opn, pn, C, 0, 0, hd * Cp, Cp, Cp, {{0, C, 0}}, {{0, C, 0}});
+            add_desc(e, lgt, pl, C, 1, hd * Cp, 0, Cp, Cp, {{0, R, 0}}, {{0, C, 0}});
+            add_desc(e, lgn, pl, C, 0, 0, hd * Cp, Cp, Cp, {{0, R, 0}}, {{0, C, 0}});
+            add_desc(e, opb, fmt("vis_trans_%s_head%d/biases", lv, hd + 1), C, 0, 0, hd * Cp, 1, Cp, {{0, 1, 0}}, {{0, C, 0}});
+            add_desc(e, lgb, fmt("lang_trans_%s_head%d/biases", lv, hd + 1), C, 0, 0, hd * Cp, 1, Cp, {{0, 1, 0}}, {{0, C, 0}});
+        }
+        linear(e, fmt("wtrans_%s", lv), fmt("words_trans_%s/DW", lv), L, R, R, Cp, Cp);
+        linear(e, fmt("t2_%s", lv), fmt("spa_graph_trans2_%s/DW", lv), L, C, C, Cp, Cp);
+        linear(e, fmt("gupd_%s", lv), fmt("gconv_update_spa_graph_%s/DW", lv), V, C, C, Cp, Cp);
+        const std::string fus = fmt("fusion_%s/DW", lv);
+        linear(e, fmt("fus_%s", lv), fus, V, 2 * C + R + 8, M, 2 * Cp + 64, Mp, true, true, {{0, C, 0}, {C, C, Cp}, {2 * C + R, 8, 2 * Cp}});
+        linear(e, fmt("fusl_%s", lv), fus, L, R, M, Cp, Mp, true, true, {{2 * C, R, 0}});
+    }
+    for (const char* x : EXG) {
+        linear(e, fmt("key_%s", x), fmt("spa_graph_key_%sgv_f1/DW", x), L, M, M, Mp, Mp);
+        linear(e, fmt("query_%s", x), fmt("lang_query_%sgv_f1/DW", x), L, R, M, Cp, Mp);
+        linear(e, fmt("gv_%s", x), fmt("gv_lang_%sgv_f1/DW", x), L, M + R, M, Mp + Cp, Mp, true, true, {{0, M, 0}, {M, R, Mp}});
+        for (const char* f : {"f1", "f2"}) {
+            linear(e, fmt("lfeat_%s_%s", x, f), fmt("lang_feat_%s_%s/DW", x, f), L, M, M, Mp, Mp);
+            linear(e, fmt("tfeat_%s_%s", x, f), fmt("trans_feat_%s_%s/DW", x, f), V, M, M, Mp, Mp);
+        }
+    }
+    Segs cl_ns; for (int g = 0; g < 4; ++g) cl_ns.push_back({g * M, M, g * Mp});
+    linear(e, "clstm", "rnn/conv_lstm_cell/kernel", V, 2 * M, 4 * M, 2 * Mp, 4 * Mp, true, true, {{0, M, 0}, {M, M, Mp}}, cl_ns);
+}
+inline const void* opp(const E* e, const std::string& key, int row = 0, int col = 0) {
+    const Operand& o = e->ops.at(key);
+    const int esz = o.dt == DT_F32 ? 4 : 2;
+    return e->arena + o.off + ((size_t)row * o.ld + col) * esz;
+}
+
+int upload_tables(E* e) {
+    const int n = (int)e->descs.size();
+    e->ndesc = n;
+    std::vector<int> pref(n + 1, 0), tdesc;
+    for (int i = 0; i < n; ++i) {
+        const cmpc_pack_desc& d = e->descs[i];
+        const int kp = d.transpose ? d.cols : d.rows, np = d.transpose ? d.rows : d.cols;
+        const int t = ((kp + 63) / 64) * ((np + 127) / 128);
+        pref[i + 1] = pref[i] + t;
+        for (int j = 0; j < t; ++j) tdesc.push_back(i);
+    }
+    e->total_tiles = pref[n]; e->stage0_tiles = pref[e->stage0_ndesc];
+    HCK(hipMalloc(&e->descs_dev, sizeof(cmpc_pack_desc) * n));
+    HCK(hipMemcpy(e->descs_dev, e->descs.data(), sizeof(cmpc_pack_desc) * n, hipMemcpyHostToDevice));
+    HCK(hipMalloc(&e->tile_prefix_dev, sizeof(int) * (n + 1)));
+    HCK(hipMemcpy(e->tile_prefix_dev, pref.data(), sizeof(int) * (n + 1), hipMemcpyHostToDevice));
+    HCK(hipMalloc(&e->tile_desc_dev, sizeof(int) * tdesc.size()));
+    HCK(hipMemcpy(e->tile_desc_dev, tdesc.data(), sizeof(int) * tdesc.size(), hipMemcpyHostToDevice));
+    std::vector<cmpc_adam_seg> segs;                       // <= 8192 elements each, inside one parameter
+    for (const ParamSpec& s : e->specs)
+        for (int64_t o = 0; o < s.count; o += 8192) segs.push_back(cmpc_adam_seg{s.off + o, (int)std::min<int64_t>(8192, s.count - o), s.wd, s.gmult});
+    e->nseg = (int)segs.size();
+    HCK(hipMalloc(&e->segs_dev, sizeof(cmpc_adam_seg) * segs.size()));
+    HCK(hipMemcpy(e->segs_dev, segs.data(), sizeof(cmpc_adam_seg) * segs.size(), hipMemcpyHostToDevice));
+    return CMPC_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// workspace plan
+// ------------------------------------------------------------------------------------------
+void tap(E* e, const std::string& name, void* p, int dt, std::initializer_list<int64_t> shape) {
+    Tap t; t.name = name; t.ptr = p; t.dt = dt; t.rank = (int)shape.size(); int i = 0;
+    for (int64_t d : shape) t.shape[i++] = d;
+    for (; i < 4; ++i) t.shape[i] = 1;
+    auto it = e->tapindex.find(name);
+    if (it != e->tapindex.end()) e->taps[it->second] = t;
+    else { e->tapindex[name] = (int)e->taps.size(); e->taps.push_back(t); }
+}
+
+// zf: zeroed at the start of every forward; zb: zeroed at the start of every backward; g: written before read
+void plan_workspace(E* e, Bump& zf, Bump& zb, Bump& g) {
+    const int B = e->B, T = e->T, N = e->N, R = e->R, Cp = e->Cp, Mp = e->Mp, Gp = e->Gp, Pp = e->Pp, Tp = e->Tp, H = e->H, W = e->W;
+    const size_t es = e->esz, F = 4, D = 8;
+    const int vd = e->dt;
+    e->zero_page = zf.take(256);
+    e->spatial = g.take((size_t)R * 64 * es);
+    // ---- text encoder / parser / language pools
+    e->words_tb = (int*)g.take((size_t)T * B * 4);
+    e->emb = (float*)g.take((size_t)T * B * Gp * F);
+    e->xg = (float*)g.take((size_t)T * B * 4 * Cp * F);
+    e->gates = (float*)g.take((size_t)T * B * 4 * Cp * F);
+    e->h_all = (float*)zf.take((size_t)(T + 1) * B * Cp * F);
+    e->c_all = (float*)zf.take((size_t)(T + 1) * B * Cp * F);
+    e->outs = (float*)g.take((size_t)B * T * Cp * F);
+    e->wf = (float*)g.take((size_t)B * T * Cp * F);
+    e->wf_rstd = (float*)g.take((size_t)B * T * F);
+    e->mask = (float*)g.take((size_t)B * T * F);
+    e->douts = (float*)g.take((size_t)B * T * Cp * F);
+    e->dh = (float*)zb.take((size_t)B * Cp * F);
+    e->dc = (float*)zb.take((size_t)B * Cp * F);
+    e->dgt = (float*)g.take((size_t)T * B * 4 * Cp * F);
+    e->demb = (float*)g.take((size_t)T * B * Gp * F);
+    e->h1 = (float*)g.take((size_t)B * T * Pp * F);
+    e->lg = (float*)g.take((size_t)B * T * 64 * F);
+    e->parse = (float*)g.take((size_t)B * T * 4 * F);
+    e->dlg = (float*)g.take((size_t)B * T * 64 * F);
+    e->dh1 = (float*)g.take((size_t)B * T * Pp * F);
+    e->vl = (float*)g.take((size_t)B * Cp * F); e->vl_rstd = (float*)g.take((size_t)B * F);
+    e->nec = (float*)g.take((size_t)B * Cp * F); e->nec_rstd = (float*)g.take((size_t)B * F);
+    e->dparse = (float*)zb.take((size_t)B * T * 4 * F);
+    e->dwf = (float*)zb.take((size_t)B * T * Cp * F);
+    e->dvl = (float*)g.take((size_t)B * Cp * F);
+    e->dnec = (float*)g.take((size_t)B * Cp * F);
+    tap(e, "words_feat", e->wf, 0, {B * T, Cp}); tap(e, "seq_mask", e->mask, 0, {B * T}); tap(e, "words_parse", e->parse, 0, {B * T, 4});
+    tap(e, "valid_lang", e->vl, 0, {B, Cp}); tap(e, "nec_lang", e->nec, 0, {B, Cp}); tap(e, "spatial", e->spatial, vd, {R, 64});
+    // ---- pyramid levels
+    const int cins[3] = {e->cfg.vf_dim, e->cfg.c4_dim, e->cfg.c3_dim};
+    const int nch = (N + 63) / 64;
+    for (int i = 0; i < 3; ++i) {
+        LevelBuf& L = e->lv[i]; const char* n = LEVELS[i];
+        L.cin = cins[i];
+        L.X0 = g.take((size_t)R * Cp * es); L.lat_rstd = (float*)g.take((size_t)R * F);
+        L.g = (float*)g.take((size_t)B * 5 * Cp * F); L.P = g.take((size_t)R * 5 * Cp * es);
+        L.X1 = g.take((size_t)R * Cp * es); L.mut_rstd = (float*)g.take((size_t)R * F);
+        L.Wd = (float*)zf.take((size_t)B * Tp * Cp * F);
+        L.PTf = (float*)g.take((size_t)B * Tp * Cp * F); L.PT = g.take((size_t)B * Tp * Cp * es);
+        L.PTtf = (float*)g.take((size_t)Cp * B * Tp * F); L.PTt = g.take((size_t)Cp * B * Tp * es);
+        L.k0s = (float*)g.take((size_t)B * Tp * F);
+        L.A0 = (float*)g.take((size_t)B * N * Tp * F); L.pr = (float*)g.take((size_t)B * T * F);
+        L.gw_w = (float*)g.take((size_t)B * N * Tp * F); L.gw_v = (float*)g.take((size_t)B * N * Tp * F);
+        L.gw_w_t = g.take((size_t)B * N * Tp * es); L.gw_v_t = g.take((size_t)B * N * Tp * es);
+        L.gsc = (float*)g.take((size_t)B * nch * 128 * F);
+        L.Ztf = (float*)zf.take((size_t)B * Cp * Tp * F); L.Zt = g.take((size_t)B * Cp * Tp * es);
+        L.Y = g.take((size_t)R * Cp * es); L.sums1 = (double*)g.take((size_t)B * 2 * D);
+        L.G = g.take((size_t)R * Cp * es); L.U = g.take((size_t)R * Cp * es); L.sums2 = (double*)g.take((size_t)B * 2 * D);
+        L.X2 = g.take((size_t)R * Cp * es); L.rrow = (float*)g.take((size_t)R * F);
+        L.sb = (float*)g.take((size_t)B * Mp * F); L.F = g.take((size_t)R * Mp * es);
+        L.score = (float*)g.take((size_t)B * e->h * e->w * F); L.up = (float*)g.take((size_t)B * H * W * F);
+        L.loss = (float*)zf.take((size_t)B * F); L.iu = (int*)zf.take((size_t)2 * B * 4);
+        // backward
+        L.dfus = g.take((size_t)R * Mp * es); L.dscore = (float*)g.take((size_t)B * e->h * e->w * F);
+        L.dpre = g.take((size_t)R * Mp * es); L.dsb = (float*)zb.take((size_t)B * Mp * F);
+        L.dX1 = g.take((size_t)R * Cp * es); L.dX2 = g.take((size_t)R * Cp * es); L.dvl = (float*)g.take((size_t)B * Cp * F);
+        L.bs = (double*)g.take((size_t)B * 2 * D);
+        L.dU = g.take((size_t)R * Cp * es); L.dG = g.take((size_t)R * Cp * es); L.dY = g.take((size_t)R * Cp * es);
+        L.Zf = (float*)zb.take((size_t)B * Tp * Cp * F); L.Z = g.take((size_t)B * Tp * Cp * es);
+        L.dgw_w = (float*)g.take((size_t)B * N * Tp * F);
+        L.dZf = (float*)zb.take((size_t)B * Tp * Cp * F); L.dZ = g.take((size_t)B * Tp * Cp * es);
+        L.dZtf = (float*)zb.take((size_t)B * Cp * Tp * F); L.dZt = g.take((size_t)B * Cp * Tp * es);
+        L.dgw_v = (float*)g.take((size_t)B * N * Tp * F);
+        L.dA0 = (float*)g.take((size_t)B * N * Tp * F); L.dA0_t = g.take((size_t)B * N * Tp * es);
+        L.dpr = (float*)g.take((size_t)B * T * F); L.gsc2 = (float*)g.take((size_t)B * nch * 128 * F);
+        L.dPT = (float*)zb.take((size_t)B * Tp * Cp * F); L.dk0s = (float*)zb.take((size_t)B * Tp * F);
+        L.dWd = (float*)g.take((size_t)B * Tp * Cp * F); L.dwf = (float*)g.take((size_t)B * T * Cp * F);
+        L.dg = (float*)zb.take((size_t)B * 5 * Cp * F);
+        L.dX0 = g.take((size_t)R * Cp * es); L.dV = g.take((size_t)R * Cp * es);
+        tap(e, fmt("lat_%s", n), L.X0, vd, {R, Cp}); tap(e, fmt("vis_la_sp_%s", n), L.X1, vd, {R, Cp});
+        tap(e, fmt("spa_graph_%s", n), L.X2, vd, {R, Cp}); tap(e, fmt("fusion_%s", n), L.F, vd, {R, Mp});
+        tap(e, fmt("gw_w_%s", n), L.gw_w, 0, {B, N, Tp}); tap(e, fmt("gw_v_%s", n), L.gw_v, 0, {B, N, Tp});
+        tap(e, fmt("score_%s", n), L.score, 0, {B, e->h, e->w, 1}); tap(e, fmt("up_%s", n), L.up, 0, {B, H, W, 1});
+        tap(e, fmt("loss_vec_%s", n), L.loss, 0, {B});
+    }
+    // ---- gated exchange
+    for (int i = 0; i < 6; ++i) {
+        ExgBuf& X = e->ex[i];
+        X.q = (float*)g.take((size_t)B * Mp * F); X.kq = (float*)g.take((size_t)B * Mp * F);
+        X.logits = (float*)g.take((size_t)B * N * F); X.attn = (float*)g.take((size_t)B * N * F);
+        X.pooled = (float*)zf.take((size_t)B * Mp * F);
+        X.gvpre = (float*)g.take((size_t)B * Mp * F); X.gv = (float*)g.take((size_t)B * Mp * F); X.rs1 = (float*)g.take(256);
+        for (int k = 0; k < 2; ++k) { X.g[k] = (float*)g.take((size_t)B * Mp * F); X.r[k] = g.take((size_t)R * Mp * es); }
+        X.out = g.take((size_t)R * Mp * es); X.rstd = (float*)g.take((size_t)R * F);
+        X.dfeat = g.take((size_t)R * Mp * es);
+        for (int k = 0; k < 2; ++k) {
+            X.dp[k] = g.take((size_t)R * Mp * es); X.dfs[k] = g.take((size_t)R * Mp * es);
+            X.dg[k] = (float*)zb.take((size_t)B * Mp * F);
+        }
+        X.dgv = (float*)g.take((size_t)B * Mp * F); X.dgvpre = (float*)g.take((size_t)B * Mp * F);
+        X.dpooled = (float*)g.take((size_t)B * Mp * F); X.dnec = (float*)g.take((size_t)B * Cp * F);
+        X.dattn = (float*)g.take((size_t)B * N * F); X.dlog = (float*)g.take((size_t)B * N * F);
+        X.dkq = (float*)zb.take((size_t)B * Mp * F); X.dq = (float*)g.take((size_t)B * Mp * F);
+        tap(e, fmt("exg_%s", EXG[i]), X.out, vd, {R, Mp});
+    }
+    for (int i = 0; i < 3; ++i) e->de1[i] = g.take((size_t)R * Mp * es);
+    // ---- ConvLSTM + final score
+    for (int s = 0; s < 3; ++s) {
+        ClstmStep& S = e->cl[s];
+        S.Yg = g.take((size_t)R * 4 * Mp * es); S.sums = (double*)g.take((size_t)5 * B * 2 * D);
+        S.c_pre = g.take((size_t)R * Mp * es); S.c_new = g.take((size_t)R * Mp * es); S.h_new = g.take((size_t)R * Mp * es);
+        S.dYg = g.take((size_t)R * 4 * Mp * es); S.dc_prev = g.take((size_t)R * Mp * es);
+        S.dx = g.take((size_t)R * Mp * es); S.dh = g.take((size_t)R * Mp * es);
+    }
+    e->cl_scr = g.take((size_t)R * Mp * es); e->cl_bs = (double*)g.take((size_t)5 * B * 2 * D);
+    e->score = (float*)g.take((size_t)B * e->h * e->w * F); e->up = (float*)g.take((size_t)B * H * W * F);
+    e->sigm = (float*)g.take((size_t)B * H * W * F);
+    e->loss = (float*)zf.take((size_t)B * F); e->iu = (int*)zf.take((size_t)2 * B * 4);
+    e->dscore = (float*)g.take((size_t)B * e->h * e->w * F); e->dfused = g.take((size_t)R * Mp * es);
+    e->scalars = (float*)g.take(256);
+    tap(e, "fused", e->cl[2].h_new, vd, {R, Mp});
+    tap(e, "pred", e->score, 0, {B, e->h, e->w, 1}); tap(e, "up", e->up, 0, {B, H, W, 1}); tap(e, "sigm", e->sigm, 0, {B, H, W, 1});
+    tap(e, "iu", e->iu, 2, {2, B}); tap(e, "loss_vec", e->loss, 0, {B}); tap(e, "scalars", e->scalars, 0, {6});
+}
+
+// ------------------------------------------------------------------------------------------
+// launch helpers
+// ------------------------------------------------------------------------------------------
+hipEvent_t next_event(E* e) { hipEvent_t ev = e->evpool[e->evnext]; e->evnext = (e->evnext + 1) % e->evpool.size(); return ev; }
+
+// lane streams wait for everything queued so far on `from`
+int fork_lanes(E* e, hipStream_t from, hipStream_t (&st)[3]) {
+    if (e->cfg.n_lanes <= 1) { st[0] = st[1] = st[2] = from; return CMPC_OK; }
+    hipEvent_t ev = next_event(e);
+    HCK(hipEventRecord(ev, from));
+    for (int i = 0; i < 3; ++i) { st[i] = e->lane[i]; HCK(hipStreamWaitEvent(e->lane[i], ev, 0)); }
+    return CMPC_OK;
+}
+int join_lanes(E* e, hipStream_t into) {
+    if (e->cfg.n_lanes <= 1) return CMPC_OK;
+    for (int i = 0; i < 3; ++i) {
+        hipEvent_t ev = next_event(e);
+        HCK(hipEventRecord(ev, e->lane[i]));
+        HCK(hipStreamWaitEvent(into, ev, 0));
+    }
+    return CMPC_OK;
+}
+
+thread_local E* t_cur = nullptr;       // the handle whose entry point is running on this thread (timing hook of gemm_nt)
+
+// algorithmic (unpadded) extent of a padded dimension
+inline int valid_extent(const E* e, int x) {
+    if (x == e->Cp) return e->C;
+    if (x == e->Mp) return e->M;
+    if (x == 5 * e->Cp) return 5 * e->C;
+    if (x == 4 * e->Mp) return 4 * e->M;
+    return x;
+}
+
+int gemm_nt(hipStream_t st, int dt, std::initializer_list<Seg> segs, void* C, int ldc, int M, int N, const GemmOpt& o = GemmOpt()) {
+    E* te = t_cur;
+    if (te && te->timing && dt == DT_BF16 && N >= 128 && M >= 512) {        // the launches that dispatch to the bf16 MFMA pipelines
+        te->timing = false;
+        hipEvent_t e0 = nullptr, e1 = nullptr;
+        if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) { cmpc_set_error("timing: hipEventCreate"); return CMPC_EHIP; }
+        (void)hipEventRecord(e0, st);
+        const int rc = gemm_nt(st, dt, segs, C, ldc, M, N, o);
+        (void)hipEventRecord(e1, st);
+        te->timing = true;
+        double kalg = 0;
+        for (const Seg& s : segs) kalg += (s.A == te->spatial && s.K == 64) ? 8 : valid_extent(te, s.K);
+        const double nv = valid_extent(te, o.n_valid < 0 ? N : o.n_valid), rows = (double)M * o.batch;
+        te->tev.push_back(e0); te->tev.push_back(e1);
+        te->tflops.push_back(2.0 * rows * nv * kalg);
+        te->tbytes.push_back(2.0 * (rows * (kalg + nv) + nv * kalg));        // A and C once per row, the weight once (bf16)
+        return rc;
+    }
+    cmpc_gemm_nt_args a; memset(&a, 0, sizeof(a));
+    a.dtype = dt; a.nseg = (int)segs.size();
+    int i = 0;
+    for (const Seg& s : segs) { a.A[i] = s.A; a.lda[i] = s.lda; a.Bt[i] = s.Bt; a.ldb[i] = s.ldb; a.K[i] = s.K; a.sA[i] = s.sA; a.sB[i] = s.sB; ++i; }
+    a.C = C; a.ldc = ldc; a.sC = o.sC; a.c_f32 = o.c_f32;
+    a.M = M; a.N = N; a.n_valid = o.n_valid < 0 ? N : o.n_valid; a.batch = o.batch;
+    a.bias = o.bias; a.sbias = o.sbias; a.ld_sbias = o.ld_sbias; a.pbias = o.pbias; a.ld_pbias = o.ld_pbias;
+    a.rows_per_sample = o.rows_per_sample; a.act = o.act; a.alpha = o.alpha; a.accumulate = o.accumulate;
+    return cmpc_gemm_nt(&a, st);
+}
+
+struct TnOpt { int nb2 = 1; int64_t a_bs = 0, d_bs = 0, o_bs = 0; float alpha = 1.f; bool defer = false; };
+typedef std::vector<std::array<int64_t, 3>> Offs;
+
+// out[k, n] += alpha * sum_r A[r, k] D[r, n]; defer: weight gradient, issued by flush_wgrad() in one grouped launch
+int gemm_tn(E* e, hipStream_t st, int dt, const void* A, int lda, int Ka, const void* D, int ldd, int Nd, float* out, int ldo,
+            int R, int Kv, int Nv, const Offs& offs, const TnOpt& o = TnOpt()) {
+    cmpc_gemm_tn_args a; memset(&a, 0, sizeof(a));
+    a.dtype = dt; a.A = A; a.lda = lda; a.Ka = Ka; a.D = D; a.ldd = ldd; a.Nd = Nd; a.out = out; a.ldo = ldo;
+    a.R = R; a.Kv = Kv; a.Nv = Nv;
+    a.nb = (int)offs.size();
+    for (size_t i = 0; i < offs.size(); ++i) { a.a_off[i] = offs[i][0]; a.d_off[i] = offs[i][1]; a.o_off[i] = offs[i][2]; }
+    a.nb2 = o.nb2; a.a_bs = o.a_bs; a.d_bs = o.d_bs; a.o_bs = o.o_bs;
+    const int tiles = ((Kv + 127) / 128) * ((Nv + 127) / 128) * a.nb * a.nb2;
+    const int br = dt == DT_BF16 ? 64 : 32;
+    a.rsplit = std::max(1, std::min((R + 4 * br - 1) / (4 * br), (512 + tiles - 1) / tiles));
+    a.alpha = o.alpha; a.zeros = e->zero_page;
+    if (o.defer) { e->deferred.push_back(a); return CMPC_OK; }
+    return cmpc_gemm_tn(&a, st);
+}
+const Offs OFF0 = {{0, 0, 0}};
+
+// dpre = dy * act'(y) (optional), db[c] += column sums, dsb[b][c] += per-sample sums; column windows of <= 2048
+int colsum(hipStream_t st, int dt, const void* dy, int R, int stride, int ld, int C, float* db, const void* y = nullptr, void* dpre = nullptr,
+           int act = ACT_NONE, float* dsb = nullptr, int ld_dsb = 0, int rows_per_sample = 0) {
+    const int es = dt == DT_F32 ? 4 : 2;
+    for (int c0 = 0; c0 < ld; c0 += 2048) {
+        const int wd = std::min(2048, ld - c0), cv = std::max(0, std::min(C - c0, wd));
+        if (cv == 0) continue;
+        CK(cmpc_act_bwd(dt, (const char*)dy + (size_t)c0 * es, y ? (const char*)y + (size_t)c0 * es : nullptr,
+                        dpre ? (char*)dpre + (size_t)c0 * es : nullptr, act, R, stride, wd, cv, db ? db + c0 : nullptr,
+                        dsb ? dsb + c0 : nullptr, ld_dsb, rows_per_sample, st));
+    }
+    return CMPC_OK;
+}
+
+int add_n(hipStream_t st, int dt, void* dst, std::initializer_list<const void*> srcs, bool acc, long n) {
+    AddArgs a; a.n = 0;
+    for (const void* s : srcs) a.src[a.n++] = s;
+    for (int i = a.n; i < 8; ++i) a.src[i] = nullptr;
+    const long n8 = n / 8;
+    const int grid = (int)std::min<long>((n8 + 255) / 256, 2048);
+    if (dt == DT_F32) hipLaunchKernelGGL((add_n_kernel<float>), dim3(grid), dim3(256), 0, st, (float*)dst, a, acc ? 1 : 0, n8);
+    else hipLaunchKernelGGL((add_n_kernel<bf16_t>), dim3(grid), dim3(256), 0, st, (bf16_t*)dst, a, acc ? 1 : 0, n8);
+    return cmpc_check_launch("add_n");
+}
+
+// ------------------------------------------------------------------------------------------
+// stage: text encoder -- lstm(), CMPC_model.py:144-164
+// ------------------------------------------------------------------------------------------
+int text_fwd(E* e, hipStream_t st, const int32_t* words, const int32_t* seq_len) {
+    const int B = e->B, T = e->T, R = e->RNN, G = e->G, Cp = e->Cp, Gp = e->Gp, ldk = Gp + Cp;
+    hipLaunchKernelGGL(transpose_i32_kernel, dim3((B * T + 255) / 256), dim3(256), 0, st, words, e->words_tb, B, T);
+    CK(cmpc_check_launch("transpose_i32"));
+    CK(cmpc_embed_gather(pptr(e, "Variable"), e->words_tb, e->emb, T * B, G, Gp, e->V, st));
+    GemmOpt o; o.bias = (const float*)opp(e, "lstm.b");
+    CK(gemm_nt(st, DT_F32, {{e->emb, Gp, opp(e, "lstm.t"), ldk, Gp}}, e->xg, 4 * Cp, T * B, 4 * Cp, o));
+    const void* wh = opp(e, "lstm.t", 0, Gp);
+    for (int t = 0; t < T; ++t) {
+        float* gt = e->gates + (size_t)t * B * 4 * Cp;
+        float *hp = e->h_all + (size_t)t * B * Cp, *cp = e->c_all + (size_t)t * B * Cp;
+        GemmOpt s; s.sbias = e->xg + (size_t)t * B * 4 * Cp; s.ld_sbias = 4 * Cp; s.rows_per_sample = 1;
+        CK(gemm_nt(st, DT_F32, {{hp, Cp, wh, ldk, Cp}}, gt, 4 * Cp, B, 4 * Cp, s));
+        CK(cmpc_lstm_cell_fwd(gt, cp, hp, seq_len, t, cp + (size_t)B * Cp, hp + (size_t)B * Cp, e->outs + (size_t)t * Cp, T * Cp, B, Cp, R, st));
+    }
+    return cmpc_l2norm_rows_fwd(DT_F32, e->outs, e->wf, e->wf_rstd, e->mask, B * T, Cp, R, st);
+}
+int text_bwd(E* e, hipStream_t st, const int32_t* seq_len) {
+    const int B = e->B, T = e->T, R = e->RNN, G = e->G, Cp = e->Cp, Gp = e->Gp;
+    CK(cmpc_l2norm_rows_bwd(DT_F32, e->dwf, e->wf, e->wf_rstd, e->douts, B * T, Cp, R, 0, st));
+    auto gat = [&](int t) { return e->gates + (size_t)t * B * 4 * Cp; };
+    auto call = [&](int t) { return e->c_all + (size_t)t * B * Cp; };
+    auto dgt = [&](int t) { return e->dgt + (size_t)t * B * 4 * Cp; };
+    if (B <= 8) {
+        // one launch per step: dh += dg[t] . W_h^T fused with the cell backward of step t-1
+        CK(cmpc_lstm_cell_bwd(gat(T - 1), call(T - 1), call(T), seq_len, T - 1, e->douts + (size_t)(T - 1) * Cp, T * Cp, e->dh, e->dc, dgt(T - 1), B, Cp, R, st));
+        const float* wn = (const float*)opp(e, "lstm.n", Gp, 0);
+        for (int t = T - 1; t > 0; --t)
+            CK(cmpc_lstm_bwd_step(dgt(t), wn, 4 * Cp, gat(t - 1), call(t - 1), call(t), seq_len, t - 1, e->douts + (size_t)(t - 1) * Cp, T * Cp,
+                                  e->dh, e->dc, dgt(t - 1), B, Cp, R, st));
+    } else {
+        for (int t = T - 1; t >= 0; --t) {
+            CK(cmpc_lstm_cell_bwd(gat(t), call(t), call(t + 1), seq_len, t, e->douts + (size_t)t * Cp, T * Cp, e->dh, e->dc, dgt(t), B, Cp, R, st));
+            GemmOpt o; o.n_valid = R; o.accumulate = 1;
+            CK(gemm_nt(st, DT_F32, {{dgt(t), 4 * Cp, opp(e, "lstm.n", Gp, 0), 4 * Cp, 4 * Cp}}, e->dh, Cp, B, Cp, o));
+        }
+    }
+    float* gk = gptr(e, "rnn/lstm_cell/kernel");
+    Offs o0, o1;
+    for (int g = 0; g < 4; ++g) { o0.push_back({0, (int64_t)g * Cp, (int64_t)g * R}); o1.push_back({0, (int64_t)g * Cp, (int64_t)G * 4 * R + (int64_t)g * R}); }
+    TnOpt d; d.defer = true;
+    CK(gemm_tn(e, st, DT_F32, e->emb, Gp, Gp, e->dgt, 4 * Cp, Cp, gk, 4 * R, T * B, G, R, o0, d));
+    CK(gemm_tn(e, st, DT_F32, e->h_all, Cp, Cp, e->dgt, 4 * Cp, Cp, gk, 4 * R, T * B, R, R, o1, d));
+    float* gb = gptr(e, "rnn/lstm_cell/bias");
+    for (int g = 0; g < 4; ++g) CK(colsum(st, DT_F32, e->dgt + (size_t)g * Cp, T * B, 4 * Cp, Cp, R, gb + (size_t)g * R));
+    GemmOpt o; o.n_valid = G;
+    CK(gemm_nt(st, DT_F32, {{e->dgt, 4 * Cp, opp(e, "lstm.n"), 4 * Cp, 4 * Cp}}, e->demb, Gp, T * B, Gp, o));
+    return cmpc_embed_scatter(e->demb, Gp, e->words_tb, gptr(e, "Variable"), T * B, G, e->V, st);
+}
+
+// ------------------------------------------------------------------------------------------
+// stage: build_lang_parser, CMPC_model.py:347-357
+// ------------------------------------------------------------------------------------------
+int parser_fwd(E* e, hipStream_t st) {
+    const int BT = e->B * e->T, P = e->P, Cp = e->Cp, Pp = e->Pp;
+    GemmOpt a; a.n_valid = P; a.bias = pptr(e, "words_parse_1/biases"); a.act = ACT_RELU;
+    CK(gemm_nt(st, DT_F32, {{e->wf, Cp, opp(e, "parse1.t"), Cp, Cp}}, e->h1, Pp, BT, Pp, a));
+    GemmOpt b; b.n_valid = 4; b.bias = pptr(e, "words_parse_2/biases");
+    CK(gemm_nt(st, DT_F32, {{e->h1, Pp, opp(e, "parse2.t"), Pp, Pp}}, e->lg, 64, BT, 64, b));
+    return cmpc_parse_softmax_fwd(e->lg, 64, e->mask, e->parse, BT, st);
+}
+// dwf accumulates on top of e->dwf
+int parser_bwd(E* e, hipStream_t st) {
+    const int BT = e->B * e->T, R = e->RNN, P = e->P, Cp = e->Cp, Pp = e->Pp;
+    TnOpt d; d.defer = true;
+    CK(cmpc_parse_softmax_bwd(e->dparse, e->parse, e->mask, e->dlg, 64, BT, st));
+    CK(colsum(st, DT_F32, e->dlg, BT, 64, 64, 4, gptr(e, "words_parse_2/biases")));
+    CK(gemm_tn(e, st, DT_F32, e->h1, Pp, Pp, e->dlg, 64, 64, gptr(e, "words_parse_2/DW"), 4, BT, P, 4, OFF0, d));
+    GemmOpt a; a.n_valid = P;
+    CK(gemm_nt(st, DT_F32, {{e->dlg, 64, opp(e, "parse2.n"), 64, 64}}, e->dh1, Pp, BT, Pp, a));
+    CK(colsum(st, DT_F32, e->dh1, BT, Pp, Pp, P, gptr(e, "words_parse_1/biases"), e->h1, e->dh1, ACT_RELU));
+    CK(gemm_tn(e, st, DT_F32, e->wf, Cp, Cp, e->dh1, Pp, Pp, gptr(e, "words_parse_1/DW"), P, BT, R, P, OFF0, d));
+    GemmOpt b; b.n_valid = R; b.accumulate = 1;
+    return gemm_nt(st, DT_F32, {{e->dh1, Pp, opp(e, "parse1.n"), Pp, Pp}}, e->dwf, Cp, BT, Cp, b);
+}
+
+// ------------------------------------------------------------------------------------------
+// stages of one pyramid level
+// ------------------------------------------------------------------------------------------
+int level_fwd(E* e, hipStream_t st, int li, const float* target) {
+    LevelBuf& L = e->lv[li]; const char* lv = LEVELS[li];
+    const int B = e->B, N = e->N, T = e->T, R = e->R, C = e->C, Cp = e->Cp, Tp = e->Tp, M = e->M, Mp = e->Mp, dt = e->dt;
+    // -- lateral 1x1 conv + l2_normalize (CMPC_model.py:108-113)
+    { GemmOpt o; o.n_valid = C; o.bias = pptr(e, fmt("%s_lateral/biases", lv));
+      CK(gemm_nt(st, dt, {{L.feat, L.cin, opp(e, fmt("lat_%s.t", lv)), L.cin, L.cin}}, L.X0, Cp, R, Cp, o));
+      CK(cmpc_l2norm_rows_fwd(dt, L.X0, L.X0, L.lat_rstd, nullptr, R, Cp, C, st)); }
+    // -- mutan_fusion (:295-328)
+    { GemmOpt o; o.bias = (const float*)opp(e, fmt("mlang_%s.b", lv)); o.act = ACT_TANH;
+      CK(gemm_nt(st, DT_F32, {{e->vl, Cp, opp(e, fmt("mlang_%s.t", lv)), Cp, Cp}}, L.g, 5 * Cp, B, 5 * Cp, o));
+      const int ldk = Cp + 64; const std::string k = fmt("mutan_%s.t", lv);
+      GemmOpt p; p.bias = (const float*)opp(e, fmt("mutan_%s.b", lv));
+      CK(gemm_nt(st, dt, {{L.X0, Cp, opp(e, k), ldk, Cp}, {e->spatial, 64, opp(e, k, 0, Cp), ldk, 64}}, L.P, 5 * Cp, R, 5 * Cp, p));
+      CK(cmpc_mutan_fwd(dt, L.P, L.g, L.X1, L.mut_rstd, B, N, Cp, C, st)); }
+    // -- build_spa_graph + graph_conv (:359-410); adjacency never formed, trans2 folded into the word side
+    { const float scale = 1.0f / sqrtf((float)C);
+      const std::string t2n = fmt("t2_%s.n", lv);
+      GemmOpt a; a.n_valid = C; a.batch = B; a.sC = (int64_t)Tp * Cp; a.bias = pptr(e, fmt("words_trans_%s/biases", lv));
+      CK(gemm_nt(st, DT_F32, {{e->wf, Cp, opp(e, fmt("wtrans_%s.t", lv)), Cp, Cp, (int64_t)T * Cp, 0}}, L.Wd, Cp, T, Cp, a));
+      GemmOpt b; b.n_valid = C;
+      CK(gemm_nt(st, DT_F32, {{L.Wd, Cp, opp(e, t2n), Cp, Cp}}, L.PTf, Cp, B * Tp, Cp, b));
+      CK(cmpc_cast(DT_F32, L.PTf, dt, L.PT, (int64_t)B * Tp * Cp, st));
+      CK(gemm_nt(st, DT_F32, {{opp(e, t2n), Cp, L.Wd, Cp, Cp}}, L.PTtf, B * Tp, Cp, B * Tp));
+      CK(cmpc_cast(DT_F32, L.PTtf, dt, L.PTt, (int64_t)Cp * B * Tp, st));
+      CK(cmpc_rowdot1(DT_F32, L.Wd, pptr(e, fmt("spa_graph_trans2_%s/biases", lv)), 0, L.k0s, 1, B * Tp, Cp, C, scale, st));
+      GemmOpt c; c.batch = B; c.sC = (int64_t)N * Tp; c.c_f32 = 1; c.alpha = scale; c.sbias = L.k0s; c.ld_sbias = Tp; c.rows_per_sample = N;
+      CK(gemm_nt(st, dt, {{L.X1, Cp, L.PT, Cp, Cp, (int64_t)N * Cp, (int64_t)Tp * Cp}}, L.A0, Tp, N, Tp, c));
+      hipLaunchKernelGGL(col_get_kernel, dim3((B * T + 255) / 256), dim3(256), 0, st, e->parse, 4, 2, L.pr, B * T);
+      CK(cmpc_check_launch("col_get"));
+      CK(cmpc_graph_softmax_fwd(dt, L.A0, L.pr, e->mask, L.gw_w, L.gw_v, L.gw_w_t, L.gw_v_t, L.gsc, B, N, T, Tp, st));
+      TnOpt z; z.nb2 = B; z.a_bs = (int64_t)N * Cp; z.d_bs = (int64_t)N * Tp; z.o_bs = (int64_t)Cp * Tp;     // Z^T = X1^T . gw_v
+      CK(gemm_tn(e, st, dt, L.X1, Cp, Cp, L.gw_v_t, Tp, Tp, L.Ztf, Tp, N, C, T, OFF0, z));
+      CK(cmpc_cast(DT_F32, L.Ztf, dt, L.Zt, (int64_t)B * Cp * Tp, st));
+      GemmOpt y; y.n_valid = C; y.batch = B; y.sC = (int64_t)N * Cp;
+      CK(gemm_nt(st, dt, {{L.gw_w_t, Tp, L.Zt, Tp, Tp, (int64_t)N * Tp, (int64_t)Cp * Tp}}, L.Y, Cp, N, Cp, y));
+      CK(cmpc_sample_stats(dt, L.Y, L.sums1, B, N, Cp, C, st));
+      const std::string ln1 = fmt("gconv_feat_ln_spa_graph_%s", lv), ln2 = fmt("gconv_update_ln_spa_graph_%s", lv);
+      CK(cmpc_gconv_pre_fwd(dt, L.Y, L.X1, L.sums1, pptr(e, ln1 + "/gamma"), pptr(e, ln1 + "/beta"), L.G, B, N, Cp, C, st));
+      GemmOpt u; u.n_valid = C; u.bias = pptr(e, fmt("gconv_update_spa_graph_%s/biases", lv));
+      CK(gemm_nt(st, dt, {{L.G, Cp, opp(e, fmt("gupd_%s.t", lv)), Cp, Cp}}, L.U, Cp, R, Cp, u));
+      CK(cmpc_sample_stats(dt, L.U, L.sums2, B, N, Cp, C, st));
+      CK(cmpc_gconv_post_fwd(dt, L.U, L.sums2, pptr(e, ln2 + "/gamma"), pptr(e, ln2 + "/beta"), L.X2, L.rrow, B, N, Cp, C, st)); }
+    // -- fusion 1x1 over [vis_la_sp | spa_graph | tile(valid_lang) | spatial] (:338-344); the concat is never formed
+    { GemmOpt s; s.n_valid = M;
+      CK(gemm_nt(st, DT_F32, {{e->vl, Cp, opp(e, fmt("fusl_%s.t", lv)), Cp, Cp}}, L.sb, Mp, B, Mp, s));
+      const int ldk = 2 * Cp + 64; const std::string k = fmt("fus_%s.t", lv);
+      GemmOpt f; f.n_valid = M; f.bias = pptr(e, fmt("fusion_%s/biases", lv)); f.sbias = L.sb; f.ld_sbias = Mp; f.rows_per_sample = N; f.act = ACT_RELU;
+      CK(gemm_nt(st, dt, {{L.X1, Cp, opp(e, k), ldk, Cp}, {L.X2, Cp, opp(e, k, 0, Cp), ldk, Cp}, {e->spatial, 64, opp(e, k, 0, 2 * Cp), ldk, 64}},
+                 L.F, Mp, R, Mp, f)); }
+    // -- score_cX 3x3 + legacy bilinear + BCE (:128-133,440-443)
+    CK(cmpc_score_conv_fwd(dt, L.F, pptr(e, fmt("score_%s/DW", lv)), pptr(e, fmt("score_%s/biases", lv)), L.score, B, e->h, e->w, Mp, M, st));
+    return cmpc_upsample_fwd(L.score, L.up, nullptr, target, L.loss, L.iu, L.iu + B, B, e->h, e->w, e->H, e->W, st);
+}
+
+// dfus (the level's fusion-output gradient from the exchange modules) must already hold the sum of its consumers
+int level_bwd(E* e, hipStream_t st, int li, const float* target) {
+    LevelBuf& L = e->lv[li]; const char* lv = LEVELS[li];
+    const int B = e->B, N = e->N, T = e->T, R = e->R, C = e->C, Cp = e->Cp, Tp = e->Tp, M = e->M, Mp = e->Mp, dt = e->dt, Rr = e->RNN;
+    const int es = e->esz;
+    TnOpt d; d.defer = true;
+    // -- score head: dfus += score-conv backward of w_lv/B * (sigmoid(up) - target)
+    CK(cmpc_upsample_loss_bwd(L.up, target, L.dscore, e->cfg.loss_w[1 + li] / B, B, e->h, e->w, e->H, e->W, st));
+    CK(cmpc_score_conv_bwd(dt, L.dscore, L.F, pptr(e, fmt("score_%s/DW", lv)), L.dfus, 1, gptr(e, fmt("score_%s/DW", lv)),
+                           gptr(e, fmt("score_%s/biases", lv)), B, e->h, e->w, Mp, M, st));
+    // -- fusion
+    { CK(colsum(st, dt, L.dfus, R, Mp, Mp, M, gptr(e, fmt("fusion_%s/biases", lv)), L.F, L.dpre, ACT_RELU, L.dsb, Mp, N));
+      float* gw = gptr(e, fmt("fusion_%s/DW", lv));
+      CK(gemm_tn(e, st, dt, L.X1, Cp, Cp, L.dpre, Mp, Mp, gw, M, R, C, M, OFF0, d));
+      CK(gemm_tn(e, st, dt, L.X2, Cp, Cp, L.dpre, Mp, Mp, gw + (size_t)C * M, M, R, C, M, OFF0, d));
+      CK(gemm_tn(e, st, dt, e->spatial, 64, 64, L.dpre, Mp, Mp, gw + (size_t)(2 * C + Rr) * M, M, R, 8, M, OFF0, d));
+      CK(gemm_tn(e, st, DT_F32, e->vl, Cp, Cp, L.dsb, Mp, Mp, gw + (size_t)2 * C * M, M, B, Rr, M, OFF0, d));
+      const std::string k = fmt("fus_%s.n", lv);
+      GemmOpt o; o.n_valid = C;
+      CK(gemm_nt(st, dt, {{L.dpre, Mp, opp(e, k), Mp, Mp}}, L.dX1, Cp, R, Cp, o));
+      CK(gemm_nt(st, dt, {{L.dpre, Mp, opp(e, k, Cp, 0), Mp, Mp}}, L.dX2, Cp, R, Cp, o));
+      GemmOpt v; v.n_valid = Rr;
+      CK(gemm_nt(st, DT_F32, {{L.dsb, Mp, opp(e, fmt("fusl_%s.n", lv)), Mp, Mp}}, L.dvl, Cp, B, Cp, v)); }
+    // -- spa_graph / graph_conv
+    { const float scale = 1.0f / sqrtf((float)C);
+      const std::string ln1 = fmt("gconv_feat_ln_spa_graph_%s", lv), ln2 = fmt("gconv_update_ln_spa_graph_%s", lv);
+      CK(cmpc_gconv_post_bwd(dt, L.dX2, L.X2, L.rrow, L.U, L.sums2, pptr(e, ln2 + "/gamma"), L.dU, gptr(e, ln2 + "/gamma"), gptr(e, ln2 + "/beta"),
+                             L.bs, B, N, Cp, C, st));
+      CK(colsum(st, dt, L.dU, R, Cp, Cp, C, gptr(e, fmt("gconv_update_spa_graph_%s/biases", lv))));
+      CK(gemm_tn(e, st, dt, L.G, Cp, Cp, L.dU, Cp, Cp, gptr(e, fmt("gconv_update_spa_graph_%s/DW", lv)), C, R, C, C, OFF0, d));
+      GemmOpt o; o.n_valid = C;
+      CK(gemm_nt(st, dt, {{L.dU, Cp, opp(e, fmt("gupd_%s.n", lv)), Cp, Cp}}, L.dG, Cp, R, Cp, o));
+      // dX1 (already holding fusion's share) += dG*[G>0]; dY = LN backward
+      CK(cmpc_gconv_pre_bwd(dt, L.dG, L.G, L.Y, L.sums1, pptr(e, ln1 + "/gamma"), L.dX1, 1, L.dY, gptr(e, ln1 + "/gamma"), gptr(e, ln1 + "/beta"),
+                            L.bs, B, N, Cp, C, st));
+      // Y = gw_w . Z,  Z = gw_v^T . X1
+      TnOpt zt; zt.nb2 = B; zt.a_bs = (int64_t)N * Tp; zt.d_bs = (int64_t)N * Cp; zt.o_bs = (int64_t)Tp * Cp;
+      CK(gemm_tn(e, st, dt, L.gw_v_t, Tp, Tp, L.X1, Cp, Cp, L.Zf, Cp, N, T, C, OFF0, zt));
+      CK(cmpc_cast(DT_F32, L.Zf, dt, L.Z, (int64_t)B * Tp * Cp, st));
+      GemmOpt gw; gw.batch = B; gw.sC = (int64_t)N * Tp; gw.c_f32 = 1;
+      CK(gemm_nt(st, dt, {{L.dY, Cp, L.Z, Cp, Cp, (int64_t)N * Cp, (int64_t)Tp * Cp}}, L.dgw_w, Tp, N, Tp, gw));
+      CK(gemm_tn(e, st, dt, L.gw_w_t, Tp, Tp, L.dY, Cp, Cp, L.dZf, Cp, N, T, C, OFF0, zt));
+      CK(cmpc_cast(DT_F32, L.dZf, dt, L.dZ, (int64_t)B * Tp * Cp, st));
+      TnOpt z2; z2.nb2 = B; z2.a_bs = (int64_t)N * Cp; z2.d_bs = (int64_t)N * Tp; z2.o_bs = (int64_t)Cp * Tp;
+      CK(gemm_tn(e, st, dt, L.dY, Cp, Cp, L.gw_w_t, Tp, Tp, L.dZtf, Tp, N, C, T, OFF0, z2));
+      CK(cmpc_cast(DT_F32, L.dZtf, dt, L.dZt, (int64_t)B * Cp * Tp, st));
+      CK(gemm_nt(st, dt, {{L.X1, Cp, L.dZ, Cp, Cp, (int64_t)N * Cp, (int64_t)Tp * Cp}}, L.dgw_v, Tp, N, Tp, gw));
+      GemmOpt ax; ax.n_valid = C; ax.batch = B; ax.sC = (int64_t)N * Cp; ax.accumulate = 1;
+      CK(gemm_nt(st, dt, {{L.gw_v_t, Tp, L.dZt, Tp, Tp, (int64_t)N * Tp, (int64_t)Cp * Tp}}, L.dX1, Cp, N, Cp, ax));
+      CK(cmpc_graph_softmax_bwd(dt, L.dgw_w, L.dgw_v, L.gw_w, L.gw_v, L.A0, L.pr, e->mask, L.dA0, L.dA0_t, L.dpr, L.gsc2, B, N, T, Tp, st));
+      // A0 = scale * (X1 . PT^T) + k0s
+      GemmOpt a0 = ax; a0.alpha = scale;
+      CK(gemm_nt(st, dt, {{L.dA0_t, Tp, L.PTt, B * Tp, Tp, (int64_t)N * Tp, (int64_t)Tp}}, L.dX1, Cp, N, Cp, a0));
+      TnOpt pt = zt; pt.alpha = scale;
+      CK(gemm_tn(e, st, dt, L.dA0_t, Tp, Tp, L.X1, Cp, Cp, L.dPT, Cp, N, T, C, OFF0, pt));
+      CK(colsum(st, DT_F32, L.dA0, R, Tp, Tp, T, nullptr, nullptr, nullptr, ACT_NONE, L.dk0s, Tp, N));
+      // k0s = scale * Wd . b_t2 ; PT = Wd . W_t2^T
+      CK(cmpc_wcolsum(DT_F32, L.Wd, L.dk0s, gptr(e, fmt("spa_graph_trans2_%s/biases", lv)), 0, 1, B * Tp, Cp, C, scale, st));
+      CK(gemm_nt(st, DT_F32, {{L.dPT, Cp, opp(e, fmt("t2_%s.t", lv)), Cp, Cp}}, L.dWd, Cp, B * Tp, Cp, o));
+      CK(gemm_tn(e, st, DT_F32, L.dPT, Cp, Cp, L.Wd, Cp, Cp, gptr(e, fmt("spa_graph_trans2_%s/DW", lv)), C, B * Tp, C, C, OFF0, d));
+      CK(cmpc_rank1_update(DT_F32, L.dWd, L.dk0s, pptr(e, fmt("spa_graph_trans2_%s/biases", lv)), nullptr, nullptr, 0, scale, 0.0f, 1, B * Tp, Cp, C, st));
+      // Wd = wf . W_w + b_w   (rows t < T of every sample; pad rows of dWd are zero)
+      CK(colsum(st, DT_F32, L.dWd, B * Tp, Cp, Cp, C, gptr(e, fmt("words_trans_%s/biases", lv))));
+      TnOpt ww; ww.nb2 = B; ww.a_bs = (int64_t)T * Cp; ww.d_bs = (int64_t)Tp * Cp; ww.o_bs = 0; ww.defer = true;
+      CK(gemm_tn(e, st, DT_F32, e->wf, Cp, Cp, L.dWd, Cp, Cp, gptr(e, fmt("words_trans_%s/DW", lv)), C, T, C, C, OFF0, ww));
+      GemmOpt dw; dw.n_valid = C; dw.batch = B; dw.sC = (int64_t)T * Cp;
+      CK(gemm_nt(st, DT_F32, {{L.dWd, Cp, opp(e, fmt("wtrans_%s.n", lv)), Cp, Cp, (int64_t)Tp * Cp, 0}}, L.dwf, Cp, T, Cp, dw)); }
+    // -- mutan
+    { CK(cmpc_mutan_bwd(dt, L.P, L.g, L.X1, L.mut_rstd, L.dX1, L.dg, B, N, Cp, C, st));
+      void* dP = L.P;                         // overwritten in place
+      const int64_t base_w = poff(e, fmt("vis_trans_%s_head1/DW", lv));
+      Offs ov, os;
+      for (int hd = 0; hd < 5; ++hd) {
+          const int64_t rel = poff(e, fmt("vis_trans_%s_head%d/DW", lv, hd + 1)) - base_w;
+          ov.push_back({0, (int64_t)hd * Cp, rel}); os.push_back({0, (int64_t)hd * Cp, rel + (int64_t)C * C});
+          CK(colsum(st, dt, (char*)dP + (size_t)hd * Cp * es, R, 5 * Cp, Cp, C, gptr(e, fmt("vis_trans_%s_head%d/biases", lv, hd + 1))));
+      }
+      float* gwv = gptr(e, fmt("vis_trans_%s_head1/DW", lv));
+      CK(gemm_tn(e, st, dt, L.X0, Cp, Cp, dP, 5 * Cp, Cp, gwv, C, R, C, C, ov, d));
+      CK(gemm_tn(e, st, dt, e->spatial, 64, 64, dP, 5 * Cp, Cp, gwv, C, R, 8, C, os, d));
+      GemmOpt o; o.n_valid = C;
+      CK(gemm_nt(st, dt, {{dP, 5 * Cp, opp(e, fmt("mutan_%s.n", lv)), 5 * Cp, 5 * Cp}}, L.dX0, Cp, R, Cp, o));
+      const int64_t base_l = poff(e, fmt("lang_trans_%s_head1/DW", lv));
+      Offs ol;
+      for (int hd = 0; hd < 5; ++hd) {
+          CK(colsum(st, DT_F32, L.dg + (size_t)hd * Cp, B, 5 * Cp, Cp, C, gptr(e, fmt("lang_trans_%s_head%d/biases", lv, hd + 1)),
+                    L.g + (size_t)hd * Cp, L.dg + (size_t)hd * Cp, ACT_TANH));
+          ol.push_back({0, (int64_t)hd * Cp, poff(e, fmt("lang_trans_%s_head%d/DW", lv, hd + 1)) - base_l});
+      }
+      CK(gemm_tn(e, st, DT_F32, e->vl, Cp, Cp, L.dg, 5 * Cp, Cp, gptr(e, fmt("lang_trans_%s_head1/DW", lv)), C, B, Rr, C, ol, d));
+      GemmOpt v; v.n_valid = Rr; v.accumulate = 1;          // on top of fusion's share
+      CK(gemm_nt(st, DT_F32, {{L.dg, 5 * Cp, opp(e, fmt("mlang_%s.n", lv)), 5 * Cp, 5 * Cp}}, L.dvl, Cp, B, Cp, v)); }
+    // -- lateral
+    CK(cmpc_l2norm_rows_bwd(dt, L.dX0, L.X0, L.lat_rstd, L.dV, R, Cp, C, 0, st));
+    CK(colsum(st, dt, L.dV, R, Cp, Cp, C, gptr(e, fmt("%s_lateral/biases", lv))));
+    return gemm_tn(e, st, dt, L.feat, L.cin, L.cin, L.dV, Cp, Cp, gptr(e, fmt("%s_lateral/DW", lv)), C, R, L.cin, C, OFF0, d);
+}
+
+// ------------------------------------------------------------------------------------------
+// stage: gated_exchange_module + l2_normalize, CMPC_model.py:194-259,271-284 (key folded into the query)
+// ------------------------------------------------------------------------------------------
+int exchange_fwd(E* e, hipStream_t st, int xi, const void* feat, const void* f1, const void* f2) {
+    ExgBuf& X = e->ex[xi]; const char* lv = EXG[xi];
+    const int B = e->B, N = e->N, R = e->R, Cp = e->Cp, M = e->M, Mp = e->Mp, dt = e->dt;
+    const float s = 1.0f / sqrtf((float)M);
+    GemmOpt q; q.n_valid = M; q.bias = pptr(e, fmt("lang_query_%sgv_f1/biases", lv));
+    CK(gemm_nt(st, DT_F32, {{e->nec, Cp, opp(e, fmt("query_%s.t", lv)), Cp, Cp}}, X.q, Mp, B, Mp, q));
+    GemmOpt k; k.n_valid = M;
+    CK(gemm_nt(st, DT_F32, {{X.q, Mp, opp(e, fmt("key_%s.n", lv)), Mp, Mp}}, X.kq, Mp, B, Mp, k));
+    CK(cmpc_rowdot1(dt, feat, X.kq, Mp, X.logits, B, N, Mp, M, s, st));
+    CK(cmpc_softmax_n_fwd(X.logits, X.attn, B, N, st));
+    CK(cmpc_wcolsum(dt, feat, X.attn, X.pooled, Mp, B, N, Mp, M, 1.0f, st));
+    const int ldk = Mp + Cp; const std::string gvk = fmt("gv_%s.t", lv);
+    GemmOpt g; g.n_valid = M; g.bias = pptr(e, fmt("gv_lang_%sgv_f1/biases", lv));
+    CK(gemm_nt(st, DT_F32, {{X.pooled, Mp, opp(e, gvk), ldk, Mp}, {e->nec, Cp, opp(e, gvk, 0, Mp), ldk, Cp}}, X.gvpre, Mp, B, Mp, g));
+    CK(cmpc_l2norm_all_fwd(X.gvpre, X.gv, X.rs1, B * Mp, st));
+    const void* fx[2] = {f1, f2}; const char* fn[2] = {"f1", "f2"};
+    for (int i = 0; i < 2; ++i) {
+        GemmOpt a; a.n_valid = M; a.bias = pptr(e, fmt("lang_feat_%s_%s/biases", lv, fn[i])); a.act = ACT_SIGMOID;
+        CK(gemm_nt(st, DT_F32, {{X.gv, Mp, opp(e, fmt("lfeat_%s_%s.t", lv, fn[i])), Mp, Mp}}, X.g[i], Mp, B, Mp, a));
+        GemmOpt b; b.n_valid = M; b.bias = pptr(e, fmt("trans_feat_%s_%s/biases", lv, fn[i])); b.act = ACT_RELU;
+        CK(gemm_nt(st, dt, {{fx[i], Mp, opp(e, fmt("tfeat_%s_%s.t", lv, fn[i])), Mp, Mp}}, X.r[i], Mp, R, Mp, b));
+    }
+    return cmpc_exchange_combine_fwd(dt, feat, X.r[0], X.r[1], X.g[0], X.g[1], Mp, X.out, X.rstd, B, N, Mp, M, st);
+}
+// outputs: X.dfeat, X.dfs[0] (d f1), X.dfs[1] (d f2), X.dnec
+int exchange_bwd(E* e, hipStream_t st, int xi, const void* dout, const void* feat, const void* f1, const void* f2) {
+    ExgBuf& X = e->ex[xi]; const char* lv = EXG[xi];
+    const int B = e->B, N = e->N, R = e->R, Cp = e->Cp, M = e->M, Mp = e->Mp, dt = e->dt, Rr = e->RNN;
+    const float s = 1.0f / sqrtf((float)M);
+    TnOpt d; d.defer = true;
+    CK(cmpc_exchange_combine_bwd(dt, dout, X.out, X.rstd, X.r[0], X.r[1], X.g[0], X.g[1], Mp, X.dfeat, 0, X.dp[0], X.dp[1], X.dg[0], X.dg[1],
+                                 B, N, Mp, M, st));
+    const void* fx[2] = {f1, f2}; const char* fn[2] = {"f1", "f2"};
+    for (int i = 0; i < 2; ++i) {
+        CK(colsum(st, dt, X.dp[i], R, Mp, Mp, M, gptr(e, fmt("trans_feat_%s_%s/biases", lv, fn[i]))));
+        CK(gemm_tn(e, st, dt, fx[i], Mp, Mp, X.dp[i], Mp, Mp, gptr(e, fmt("trans_feat_%s_%s/DW", lv, fn[i])), M, R, M, M, OFF0, d));
+        GemmOpt o; o.n_valid = M;
+        CK(gemm_nt(st, dt, {{X.dp[i], Mp, opp(e, fmt("tfeat_%s_%s.n", lv, fn[i])), Mp, Mp}}, X.dfs[i], Mp, R, Mp, o));
+        CK(colsum(st, DT_F32, X.dg[i], B, Mp, Mp, M, gptr(e, fmt("lang_feat_%s_%s/biases", lv, fn[i])), X.g[i], X.dg[i], ACT_SIGMOID));
+        CK(gemm_tn(e, st, DT_F32, X.gv, Mp, Mp, X.dg[i], Mp, Mp, gptr(e, fmt("lang_feat_%s_%s/DW", lv, fn[i])), M, B, M, M, OFF0, d));
+        GemmOpt a; a.n_valid = M; a.accumulate = i == 1;
+        CK(gemm_nt(st, DT_F32, {{X.dg[i], Mp, opp(e, fmt("lfeat_%s_%s.n", lv, fn[i])), Mp, Mp}}, X.dgv, Mp, B, Mp, a));
+    }
+    CK(cmpc_l2norm_all_bwd(X.dgv, X.gv, X.rs1, X.dgvpre, B * Mp, st));
+    CK(colsum(st, DT_F32, X.dgvpre, B, Mp, Mp, M, gptr(e, fmt("gv_lang_%sgv_f1/biases", lv))));
+    float* gwg = gptr(e, fmt("gv_lang_%sgv_f1/DW", lv));
+    CK(gemm_tn(e, st, DT_F32, X.pooled, Mp, Mp, X.dgvpre, Mp, Mp, gwg, M, B, M, M, OFF0, d));
+    CK(gemm_tn(e, st, DT_F32, e->nec, Cp, Cp, X.dgvpre, Mp, Mp, gwg + (size_t)M * M, M, B, Rr, M, OFF0, d));
+    const std::string gvn = fmt("gv_%s.n", lv);
+    GemmOpt m; m.n_valid = M;
+    CK(gemm_nt(st, DT_F32, {{X.dgvpre, Mp, opp(e, gvn), Mp, Mp}}, X.dpooled, Mp, B, Mp, m));
+    GemmOpt r; r.n_valid = Rr;
+    CK(gemm_nt(st, DT_F32, {{X.dgvpre, Mp, opp(e, gvn, Mp, 0), Mp, Mp}}, X.dnec, Cp, B, Cp, r));
+    CK(cmpc_rowdot1(dt, feat, X.dpooled, Mp, X.dattn, B, N, Mp, M, 1.0f, st));
+    CK(cmpc_softmax_n_bwd(X.dattn, X.attn, X.dlog, B, N, st));
+    CK(cmpc_rank1_update(dt, X.dfeat, X.attn, X.dpooled, X.dlog, X.kq, Mp, 1.0f, s, B, N, Mp, M, st));
+    CK(cmpc_wcolsum(dt, feat, X.dlog, X.dkq, Mp, B, N, Mp, M, s, st));
+    CK(gemm_nt(st, DT_F32, {{X.dkq, Mp, opp(e, fmt("key_%s.t", lv)), Mp, Mp}}, X.dq, Mp, B, Mp, m));
+    CK(gemm_tn(e, st, DT_F32, X.dkq, Mp, Mp, X.q, Mp, Mp, gptr(e, fmt("spa_graph_key_%sgv_f1/DW", lv)), M, B, M, M, OFF0, d));
+    CK(colsum(st, DT_F32, X.dq, B, Mp, Mp, M, gptr(e, fmt("lang_query_%sgv_f1/biases", lv))));
+    CK(gemm_tn(e, st, DT_F32, e->nec, Cp, Cp, X.dq, Mp, Mp, gptr(e, fmt("lang_query_%sgv_f1/DW", lv)), M, B, Rr, M, OFF0, d));
+    GemmOpt n; n.n_valid = Rr; n.accumulate = 1;
+    return gemm_nt(st, DT_F32, {{X.dq, Mp, opp(e, fmt("query_%s.n", lv)), Mp, Mp}}, X.dnec, Cp, B, Cp, n);
+}
+
+// ------------------------------------------------------------------------------------------
+// stage: ConvLSTM over (exg3_2, exg4_2, exg5_2), util/cell.py:36-79 via CMPC_model.py:287-290
+// ------------------------------------------------------------------------------------------
+const char* LN_NAMES[5] = {"LayerNorm", "LayerNorm_1", "LayerNorm_2", "LayerNorm_3", "LayerNorm_4"};    // j, i, f, o, c
+void clstm_ln(E* e, cmpc_convlstm_ln& ln, cmpc_convlstm_dln& dln) {
+    for (int i = 0; i < 5; ++i) {
+        const std::string p = std::string("rnn/conv_lstm_cell/") + LN_NAMES[i];
+        ln.beta[i] = pptr(e, p + "/beta"); ln.gamma[i] = pptr(e, p + "/gamma");
+        dln.dbeta[i] = gptr(e, p + "/beta"); dln.dgamma[i] = gptr(e, p + "/gamma");
+    }
+}
+int clstm_fwd(E* e, hipStream_t st) {
+    const int B = e->B, N = e->N, R = e->R, M = e->M, Mp = e->Mp, dt = e->dt;
+    cmpc_convlstm_ln ln; cmpc_convlstm_dln dln; clstm_ln(e, ln, dln);
+    const std::string pre = "rnn/conv_lstm_cell/";
+    const void* xs[3] = {e->ex[3].out, e->ex[4].out, e->ex[5].out};
+    const void *hcur = nullptr, *ccur = nullptr;
+    for (int s = 0; s < 3; ++s) {
+        ClstmStep& S = e->cl[s];
+        if (s == 0) CK(gemm_nt(st, dt, {{xs[s], Mp, opp(e, "clstm.t"), 2 * Mp, Mp}}, S.Yg, 4 * Mp, R, 4 * Mp));
+        else CK(gemm_nt(st, dt, {{xs[s], Mp, opp(e, "clstm.t"), 2 * Mp, Mp}, {hcur, Mp, opp(e, "clstm.t", 0, Mp), 2 * Mp, Mp}}, S.Yg, 4 * Mp, R, 4 * Mp));
+        CK(cmpc_convlstm_a(dt, S.Yg, ccur, pptr(e, pre + "W_ci"), pptr(e, pre + "W_cf"), S.sums, B, N, Mp, M, st));
+        CK(cmpc_convlstm_b(dt, S.Yg, ccur, pptr(e, pre + "W_co"), &ln, S.sums, S.c_pre, B, N, Mp, M, st));
+        CK(cmpc_convlstm_c(dt, S.Yg, S.c_pre, &ln, S.sums, S.c_new, S.h_new, B, N, Mp, M, st));
+        hcur = S.h_new; ccur = S.c_new;
+    }
+    return CMPC_OK;
+}
+// in: e->dfused (gradient of the last h); out: cl[s].dx = gradient of exg_*_2
+int clstm_bwd(E* e, hipStream_t st) {
+    const int B = e->B, N = e->N, R = e->R, M = e->M, Mp = e->Mp, dt = e->dt;
+    cmpc_convlstm_ln ln; cmpc_convlstm_dln dln; clstm_ln(e, ln, dln);
+    const std::string pre = "rnn/conv_lstm_cell/";
+    const void* xs[3] = {e->ex[3].out, e->ex[4].out, e->ex[5].out};
+    float* gk = gptr(e, pre + "kernel");
+    TnOpt d; d.defer = true;
+    const void* dh = e->dfused; const void* dc = nullptr;
+    for (int s = 2; s >= 0; --s) {
+        ClstmStep& S = e->cl[s];
+        const void* h_prev = s > 0 ? e->cl[s - 1].h_new : nullptr;
+        const void* c_prev = s > 0 ? e->cl[s - 1].c_new : nullptr;
+        CK(cmpc_convlstm_bwd(dt, dh, dc, S.Yg, c_prev, S.c_pre, pptr(e, pre + "W_ci"), pptr(e, pre + "W_cf"), pptr(e, pre + "W_co"), &ln, S.sums,
+                             S.dYg, s > 0 ? S.dc_prev : nullptr, gptr(e, pre + "W_ci"), gptr(e, pre + "W_cf"), gptr(e, pre + "W_co"), &dln,
+                             e->cl_scr, e->cl_bs, B, N, Mp, M, st));
+        Offs ox, oh;
+        for (int g = 0; g < 4; ++g) { ox.push_back({0, (int64_t)g * Mp, (int64_t)g * M}); oh.push_back({0, (int64_t)g * Mp, (int64_t)M * 4 * M + (int64_t)g * M}); }
+        CK(gemm_tn(e, st, dt, xs[s], Mp, Mp, S.dYg, 4 * Mp, Mp, gk, 4 * M, R, M, M, ox, d));
+        GemmOpt o; o.n_valid = M;
+        CK(gemm_nt(st, dt, {{S.dYg, 4 * Mp, opp(e, "clstm.n"), 4 * Mp, 4 * Mp}}, S.dx, Mp, R, Mp, o));
+        if (s > 0) {
+            CK(gemm_tn(e, st, dt, h_prev, Mp, Mp, S.dYg, 4 * Mp, Mp, gk, 4 * M, R, M, M, oh, d));
+            CK(gemm_nt(st, dt, {{S.dYg, 4 * Mp, opp(e, "clstm.n", Mp, 0), 4 * Mp, 4 * Mp}}, S.dh, Mp, R, Mp, o));
+            dh = S.dh; dc = S.dc_prev;
+        }
+    }
+    return CMPC_OK;
+}
+
+int flush_wgrad(E* e, hipStream_t st) {
+    if (e->deferred.empty()) return CMPC_OK;
+    const int rc = cmpc_gemm_tn_grouped(e->deferred.data(), (int)e->deferred.size(), st);
+    e->deferred.clear();
+    return rc;
+}
+
+int params_ready(E* e, hipStream_t st, int stage) {
+    // the optimizer of the previous step may run on its own stream: stage 0 = Adam done + text operands repacked,
+    // stage 1 = everything repacked
+    if (!e->opt_pending) return CMPC_OK;
+    HCK(hipStreamWaitEvent(st, stage == 0 ? e->ev_opt0 : e->ev_opt1, 0));
+    if (stage == 1) e->opt_pending = false;
+    return CMPC_OK;
+}
+
+int set_device(const E* e) {
+    if (e->cfg.device < 0) { cmpc_set_error("this handle was created with device = -1 (planning only)"); return CMPC_EINVAL; }
+    int cur = -1;
+    HCK(hipGetDevice(&cur));
+    if (cur != e->cfg.device) HCK(hipSetDevice(e->cfg.device));
+    return CMPC_OK;
+}
+
+}  // namespace
+
+// ==========================================================================================
+extern "C" int cmpc_default_cfg(cmpc_cfg* c) {
+    if (!c) { cmpc_set_error("default_cfg: null"); return CMPC_EINVAL; }
+    memset(c, 0, sizeof(*c));
+    c->batch_size = 1; c->num_steps = 20; c->vf_h = 40; c->vf_w = 40; c->H = 320; c->W = 320;
+    c->vf_dim = 2048; c->c4_dim = 1024; c->c3_dim = 512;
+    c->vocab_size = 12112; c->v_emb_dim = 1000; c->mlp_dim = 500; c->rnn_size = 1000; c->glove_dim = 300; c->parse_dim = 500;
+    c->start_lr = 0.00025; c->end_lr = 0.00001; c->lr_power = 0.9; c->lr_decay_step = 800000; c->weight_decay = 0.0005f;
+    c->loss_w[0] = 0.7f; c->loss_w[1] = c->loss_w[2] = c->loss_w[3] = 0.1f;
+    c->dtype = DT_BF16; c->n_lanes = 3; c->device = 0;
+    return CMPC_OK;
+}
+
+extern "C" int cmpc_destroy(cmpc_handle e) {
+    if (!e) return CMPC_OK;
+    if (e->cfg.device < 0) { delete e; return CMPC_OK; }
+    (void)hipSetDevice(e->cfg.device);
+    (void)hipDeviceSynchronize();
+    for (void* p : {(void*)e->params, (void*)e->grads, (void*)e->adam_m, (void*)e->adam_v, (void*)e->arena, (void*)e->descs_dev,
+                    (void*)e->tile_prefix_dev, (void*)e->tile_desc_dev, (void*)e->segs_dev, (void*)e->ws})
+        if (p) (void)hipFree(p);
+    for (hipStream_t s : e->lane) if (s) (void)hipStreamDestroy(s);
+    for (hipEvent_t ev : e->evpool) (void)hipEventDestroy(ev);
+    if (e->ev_opt0) (void)hipEventDestroy(e->ev_opt0);
+    if (e->ev_opt1) (void)hipEventDestroy(e->ev_opt1);
+    delete e;
+    return CMPC_OK;
+}
+
+extern "C" int cmpc_create(const cmpc_cfg* c, cmpc_handle* out) {
+    if (!c || !out) { cmpc_set_error("create: null argument"); return CMPC_EINVAL; }
+    *out = nullptr;
+    if (c->batch_size < 1 || c->num_steps < 1 || c->num_steps > 64 || c->vf_h < 1 || c->vf_w < 1 || c->H < c->vf_h || c->W < c->vf_w) {
+        cmpc_set_error("create: need batch_size >= 1, 1 <= num_steps <= 64, H >= vf_h >= 1, W >= vf_w >= 1"); return CMPC_EINVAL;
+    }
+    if (c->dtype != DT_F32 && c->dtype != DT_BF16) { cmpc_set_error("create: dtype must be 0 (f32) or 1 (bf16)"); return CMPC_EINVAL; }
+    if (c->rnn_size != c->v_emb_dim) { cmpc_set_error("create: rnn_size must equal v_emb_dim (the affinity contracts them, CMPC_model.py:384)"); return CMPC_EINVAL; }
+    if (c->vf_dim % 64 || c->c4_dim % 64 || c->c3_dim % 64) { cmpc_set_error("create: vf_dim / c4_dim / c3_dim must be multiples of 64 (MFMA K tile)"); return CMPC_EINVAL; }
+    if (c->v_emb_dim < 8 || c->mlp_dim < 8 || c->glove_dim < 1 || c->parse_dim < 4 || c->vocab_size < 1) {
+        cmpc_set_error("create: need v_emb_dim >= 8, mlp_dim >= 8, glove_dim >= 1, parse_dim >= 4, vocab_size >= 1"); return CMPC_EINVAL;
+    }
+    if (pad64(c->v_emb_dim) > 2048 || pad64(c->mlp_dim) > 2048) { cmpc_set_error("create: v_emb_dim, mlp_dim <= 2048 (per-column registers of the map kernels)"); return CMPC_EINVAL; }
+    if (c->n_lanes != 1 && c->n_lanes != 3) { cmpc_set_error("create: n_lanes must be 1 or 3"); return CMPC_EINVAL; }
+    const bool plan_only = c->device == -1;      // host-side planning only (manifest, operand plan, workspace size): no GPU needed
+    if (!plan_only) {
+        int ndev = 0;
+        if (hipGetDeviceCount(&ndev) != hipSuccess || c->device < 0 || c->device >= ndev) {
+            cmpc_set_error("create: no HIP device %d (the CMPC head has no CPU path)", c->device); return CMPC_EHIP;
+        }
+        HCK(hipSetDevice(c->device));
+    }
+    E* e = new E();
+    e->cfg = *c;
+    e->B = c->batch_size; e->T = c->num_steps; e->h = c->vf_h; e->w = c->vf_w; e->N = e->h * e->w; e->R = e->B * e->N;
+    e->H = c->H; e->W = c->W; e->V = c->vocab_size;
+    e->C = c->v_emb_dim; e->Cp = pad64(e->C); e->M = c->mlp_dim; e->Mp = pad64(e->M); e->G = c->glove_dim; e->Gp = pad64(e->G);
+    e->P = c->parse_dim; e->Pp = pad64(e->P); e->Tp = 64; e->RNN = c->rnn_size; e->dt = c->dtype; e->esz = c->dtype == DT_F32 ? 4 : 2;
+    build_manifest(e);
+    plan_operands(e);
+    if (plan_only) {
+        Bump zf, zb, g;
+        plan_workspace(e, zf, zb, g);
+        e->zf_bytes = zf.off; e->zb_bytes = zb.off; e->ws_bytes = zf.off + zb.off + g.off;
+        *out = e;
+        return CMPC_OK;
+    }
+    auto fail = [&](int rc) { cmpc_destroy(e); return rc; };
+#define ECK(x) do { const hipError_t _e = (x); if (_e != hipSuccess) { cmpc_set_error("create: %s: %s", #x, hipGetErrorString(_e)); return fail(CMPC_EHIP); } } while (0)
+    const size_t pbytes = (size_t)e->total * sizeof(float);
+    ECK(hipMalloc(&e->params, pbytes)); ECK(hipMalloc(&e->grads, pbytes)); ECK(hipMalloc(&e->adam_m, pbytes)); ECK(hipMalloc(&e->adam_v, pbytes));
+    ECK(hipMemset(e->params, 0, pbytes)); ECK(hipMemset(e->grads, 0, pbytes)); ECK(hipMemset(e->adam_m, 0, pbytes)); ECK(hipMemset(e->adam_v, 0, pbytes));
+    ECK(hipMalloc(&e->arena, e->arena_bytes)); ECK(hipMemset(e->arena, 0, e->arena_bytes));
+    if (upload_tables(e) != CMPC_OK) return fail(CMPC_EHIP);
+    {   // workspace: measure, allocate, assign
+        Bump zf, zb, g;
+        plan_workspace(e, zf, zb, g);
+        e->zf_bytes = zf.off; e->zb_bytes = zb.off; e->ws_bytes = zf.off + zb.off + g.off;
+        ECK(hipMalloc(&e->ws, e->ws_bytes)); ECK(hipMemset(e->ws, 0, e->ws_bytes));
+        Bump zf2, zb2, g2; zf2.base = e->ws; zb2.base = e->ws + e->zf_bytes; g2.base = e->ws + e->zf_bytes + e->zb_bytes;
+        plan_workspace(e, zf2, zb2, g2);
+    }
+    {   // spatial grid [B*N, 64]: generate_spatial_batch (util/processing_tools.py:5-17), float64 arithmetic, float32 values
+        std::vector<float> sp((size_t)e->N * 64, 0.f);
+        for (int y = 0; y < e->h; ++y)
+            for (int x = 0; x < e->w; ++x) {
+                const double xmin = (double)x / e->w * 2 - 1, xmax = (double)(x + 1) / e->w * 2 - 1;
+                const double ymin = (double)y / e->h * 2 - 1, ymax = (double)(y + 1) / e->h * 2 - 1;
+                float* r = &sp[(size_t)(y * e->w + x) * 64];
+                r[0] = (float)xmin; r[1] = (float)ymin; r[2] = (float)xmax; r[3] = (float)ymax;
+                r[4] = (float)((xmin + xmax) / 2); r[5] = (float)((ymin + ymax) / 2); r[6] = (float)(1.0 / e->w); r[7] = (float)(1.0 / e->h);
+            }
+        float* tmp = nullptr;
+        ECK(hipMalloc(&tmp, (size_t)e->R * 64 * sizeof(float)));
+        for (int b = 0; b < e->B; ++b) ECK(hipMemcpy(tmp + (size_t)b * e->N * 64, sp.data(), sp.size() * sizeof(float), hipMemcpyHostToDevice));
+        if (e->dt == DT_F32) ECK(hipMemcpy(e->spatial, tmp, (size_t)e->R * 64 * sizeof(float), hipMemcpyDeviceToDevice));
+        else if (cmpc_cast(DT_F32, tmp, DT_BF16, e->spatial, (int64_t)e->R * 64, nullptr) != CMPC_OK) { (void)hipFree(tmp); return fail(CMPC_EHIP); }
+        ECK(hipDeviceSynchronize());
+        (void)hipFree(tmp);
+    }
+    for (int i = 0; i < 3; ++i) ECK(hipStreamCreateWithFlags(&e->lane[i], hipStreamNonBlocking));
+    e->evpool.resize(256);
+    for (auto& ev : e->evpool) { ev = nullptr; ECK(hipEventCreateWithFlags(&ev, hipEventDisableTiming)); }
+    ECK(hipEventCreateWithFlags(&e->ev_opt0, hipEventDisableTiming));
+    ECK(hipEventCreateWithFlags(&e->ev_opt1, hipEventDisableTiming));
+#undef ECK
+    e->deferred.reserve(256);
+    *out = e;
+    return CMPC_OK;
+}
+
+extern "C" int cmpc_param_count(cmpc_handle e) { return e ? (int)e->specs.size() : 0; }
+extern "C" int cmpc_param_info(cmpc_handle e, int i, const char** name, int64_t* offset, int* rank, int64_t shape[4]) {
+    if (!e || i < 0 || i >= (int)e->specs.size()) { cmpc_set_error("param_info: bad index"); return CMPC_EINVAL; }
+    const ParamSpec& s = e->specs[i];
+    if (name) *name = s.name.c_str();
+    if (offset) *offset = s.off;
+    if (rank) *rank = s.rank;
+    if (shape) for (int k = 0; k < 4; ++k) shape[k] = s.shape[k];
+    return CMPC_OK;
+}
+extern "C" int cmpc_buffers(cmpc_handle e, float** params, float** grads, float** m, float** v, int64_t* total) {
+    if (!e) { cmpc_set_error("buffers: null handle"); return CMPC_EINVAL; }
+    if (params) *params = e->params;
+    if (grads) *grads = e->grads;
+    if (m) *m = e->adam_m;
+    if (v) *v = e->adam_v;
+    if (total) *total = e->total;
+    return CMPC_OK;
+}
+static int find_param(cmpc_handle e, const char* name, int64_t count, const ParamSpec** out) {
+    if (!e || !name) { cmpc_set_error("weights: null argument"); return CMPC_EINVAL; }
+    auto it = e->pindex.find(name);
+    if (it == e->pindex.end()) { cmpc_set_error("weights: no variable named %s", name); return CMPC_EINVAL; }
+    const ParamSpec& s = e->specs[it->second];
+    if (s.count != count) { cmpc_set_error("weights: %s has %lld elements, got %lld", name, (long long)s.count, (long long)count); return CMPC_EINVAL; }
+    *out = &s;
+    return CMPC_OK;
+}
+extern "C" int cmpc_set_weights(cmpc_handle e, const char* name, const float* src, int64_t count) {
+    const ParamSpec* s = nullptr;
+    CK(find_param(e, name, count, &s));
+    CK(set_device(e));
+    HCK(hipMemcpy(e->params + s->off, src, (size_t)count * sizeof(float), hipMemcpyHostToDevice));
+    return CMPC_OK;
+}
+extern "C" int cmpc_get_weights(cmpc_handle e, const char* name, float* dst, int64_t count) {
+    const ParamSpec* s = nullptr;
+    CK(find_param(e, name, count, &s));
+    CK(set_device(e));
+    HCK(hipDeviceSynchronize());
+    HCK(hipMemcpy(dst, e->params + s->off, (size_t)count * sizeof(float), hipMemcpyDeviceToHost));
+    return CMPC_OK;
+}
+extern "C" int cmpc_pack(cmpc_handle e, void* stream) {
+    if (!e) { cmpc_set_error("pack: null handle"); return CMPC_EINVAL; }
+    CK(set_device(e));
+    CK(params_ready(e, (hipStream_t)stream, 1));
+    return cmpc_pack_weights_range(e->params, e->arena, e->descs_dev, e->tile_prefix_dev, e->tile_desc_dev, e->ndesc, 0, e->total_tiles, stream);
+}
+extern "C" int cmpc_get_step(cmpc_handle e, int64_t* step) { if (!e || !step) return CMPC_EINVAL; *step = e->step; return CMPC_OK; }
+extern "C" int cmpc_set_step(cmpc_handle e, int64_t step) { if (!e || step < 0) return CMPC_EINVAL; e->step = step; return CMPC_OK; }
+
+extern "C" int cmpc_tap_count(cmpc_handle e) { return e ? (int)e->taps.size() : 0; }
+extern "C" int cmpc_tap_name(cmpc_handle e, int i, const char** name) {
+    if (!e || i < 0 || i >= (int)e->taps.size() || !name) { cmpc_set_error("tap_name: bad index"); return CMPC_EINVAL; }
+    *name = e->taps[i].name.c_str();
+    return CMPC_OK;
+}
+extern "C" int cmpc_tap(cmpc_handle e, const char* name, void** ptr, int* dtype, int* rank, int64_t shape[4]) {
+    if (!e || !name) { cmpc_set_error("tap: null argument"); return CMPC_EINVAL; }
+    auto it = e->tapindex.find(name);
+    if (it == e->tapindex.end()) { cmpc_set_error("tap: no intermediate named %s", name); return CMPC_EINVAL; }
+    const Tap& t = e->taps[it->second];
+    if (ptr) *ptr = t.ptr;
+    if (dtype) *dtype = t.dt;
+    if (rank) *rank = t.rank;
+    if (shape) for (int k = 0; k < 4; ++k) shape[k] = t.shape[k];
+    return CMPC_OK;
+}
+extern "C" int cmpc_plan_info(cmpc_handle e, const cmpc_pack_desc** descs, int* ndesc, int64_t* arena_bytes, int64_t* workspace_bytes, int* stage0_ndesc) {
+    if (!e) { cmpc_set_error("plan_info: null handle"); return CMPC_EINVAL; }
+    if (descs) *descs = e->descs.data();
+    if (ndesc) *ndesc = (int)e->descs.size();
+    if (arena_bytes) *arena_bytes = (int64_t)e->arena_bytes;
+    if (workspace_bytes) *workspace_bytes = (int64_t)e->ws_bytes;
+    if (stage0_ndesc) *stage0_ndesc = e->stage0_ndesc;
+    return CMPC_OK;
+}
+extern "C" int cmpc_operand_info(cmpc_handle e, const char* key, int64_t* byte_off, int* dt, int* rows, int* ld) {
+    if (!e || !key) { cmpc_set_error("operand_info: null argument"); return CMPC_EINVAL; }
+    auto it = e->ops.find(key);
+    if (it == e->ops.end()) { cmpc_set_error("operand_info: no operand named %s", key); return CMPC_EINVAL; }
+    if (byte_off) *byte_off = (int64_t)it->second.off;
+    if (dt) *dt = it->second.dt;
+    if (rows) *rows = it->second.rows;
+    if (ld) *ld = it->second.ld;
+    return CMPC_OK;
+}
+extern "C" int cmpc_set_lanes(cmpc_handle e, int n_lanes) {
+    if (!e || (n_lanes != 1 && n_lanes != 3)) { cmpc_set_error("set_lanes: n_lanes must be 1 or 3"); return CMPC_EINVAL; }
+    e->cfg.n_lanes = n_lanes;
+    return CMPC_OK;
+}
+extern "C" int cmpc_kernel_timing(cmpc_handle e, int enable) {
+    if (!e) { cmpc_set_error("kernel_timing: null handle"); return CMPC_EINVAL; }
+    for (hipEvent_t ev : e->tev) (void)hipEventDestroy(ev);
+    e->tev.clear(); e->tflops.clear(); e->tbytes.clear();
+    e->timing = enable != 0;
+    return CMPC_OK;
+}
+extern "C" int cmpc_kernel_timing_read(cmpc_handle e, double* ms, double* flops, double* bytes, int64_t* launches) {
+    if (!e) { cmpc_set_error("kernel_timing_read: null handle"); return CMPC_EINVAL; }
+    CK(set_device(e));
+    HCK(hipDeviceSynchronize());
+    double t = 0, f = 0, b = 0;
+    for (size_t i = 0; i < e->tflops.size(); ++i) {
+        float dt_ms = 0.f;
+        HCK(hipEventElapsedTime(&dt_ms, e->tev[2 * i], e->tev[2 * i + 1]));
+        t += dt_ms; f += e->tflops[i]; b += e->tbytes[i];
+    }
+    if (ms) *ms = t;
+    if (flops) *flops = f;
+    if (bytes) *bytes = b;
+    if (launches) *launches = (int64_t)e->tflops.size();
+    return CMPC_OK;
+}
+extern "C" int cmpc_launch_count(cmpc_handle e, int64_t* n) { if (!e || !n) return CMPC_EINVAL; *n = e->launches_step; return CMPC_OK; }
+
+// ------------------------------------------------------------------------------------------
+extern "C" int cmpc_forward(cmpc_handle e, const cmpc_feeds* f, const cmpc_fetches* fetch, void* stream) {
+    if (!e || !f || !f->words || !f->seq_len || !f->c3 || !f->c4 || !f->c5) { cmpc_set_error("forward: null handle / feed"); return CMPC_EINVAL; }
+    CK(set_device(e));
+    hipStream_t main = (hipStream_t)stream;
+    t_cur = e;
+    e->l0 = g_cmpc_launches;
+    e->seq_len_feed = f->seq_len; e->target_feed = f->target_fine; e->last_main = main;
+    const int B = e->B, Cp = e->Cp;
+    e->have_target = f->target_fine != nullptr;
+    e->deferred.clear();
+    e->lv[0].feat = f->c5; e->lv[1].feat = f->c4; e->lv[2].feat = f->c3;
+    CK(params_ready(e, main, 0));
+    HCK(hipMemsetAsync(e->ws, 0, e->zf_bytes, main));                         // every accumulate-into buffer of the forward pass
+    CK(text_fwd(e, main, f->words, f->seq_len));
+    CK(parser_fwd(e, main));
+    CK(cmpc_lang_pool_fwd(e->parse, e->wf, e->vl, e->vl_rstd, B, e->T, Cp, e->RNN, 2, main));      // valid_lang: entity + attribute
+    CK(params_ready(e, main, 1));
+    if (f->feats_ready) HCK(hipStreamWaitEvent(main, (hipEvent_t)f->feats_ready, 0));
+    hipStream_t st[3];
+    CK(fork_lanes(e, main, st));
+    for (int i = 0; i < 3; ++i) CK(level_fwd(e, st[i], i, f->target_fine));
+    CK(join_lanes(e, main));
+    CK(cmpc_lang_pool_fwd(e->parse, e->wf, e->nec, e->nec_rstd, B, e->T, Cp, e->RNN, 3, main));    // nec_lang: + relation
+    // gated_exchange_fusion_lstm_2times (:261-293): fusion maps in EXG order c3, c4, c5 = lv[2], lv[1], lv[0]
+    const void* fz[3] = {e->lv[2].F, e->lv[1].F, e->lv[0].F};
+    const int o1[3] = {1, 0, 0}, o2[3] = {2, 2, 1};                           // (c3: c4,c5) (c4: c3,c5) (c5: c3,c4)
+    CK(fork_lanes(e, main, st));
+    for (int i = 0; i < 3; ++i) CK(exchange_fwd(e, st[i], i, fz[i], fz[o1[i]], fz[o2[i]]));
+    CK(join_lanes(e, main));
+    const void* ez[3] = {e->ex[0].out, e->ex[1].out, e->ex[2].out};
+    CK(fork_lanes(e, main, st));
+    for (int i = 0; i < 3; ++i) CK(exchange_fwd(e, st[i], 3 + i, ez[i], ez[o1[i]], ez[o2[i]]));
+    CK(join_lanes(e, main));
+    CK(clstm_fwd(e, main));
+    CK(cmpc_score_conv_fwd(e->dt, e->cl[2].h_new, pptr(e, "score/DW"), pptr(e, "score/biases"), e->score, B, e->h, e->w, e->Mp, e->M, main));
+    CK(cmpc_upsample_fwd(e->score, e->up, e->sigm, f->target_fine, e->loss, e->iu, e->iu + B, B, e->h, e->w, e->H, e->W, main));
+    if (e->have_target) {
+        hipLaunchKernelGGL(scalars_kernel, dim3(1), dim3(64), 0, main, e->loss, e->lv[0].loss, e->lv[1].loss, e->lv[2].loss, e->iu, e->iu + B, B,
+                           e->cfg.loss_w[0], e->cfg.loss_w[1], e->cfg.loss_w[2], e->cfg.loss_w[3], e->scalars);
+        CK(cmpc_check_launch("scalars"));
+    }
+    if (fetch) {
+        if (fetch->pred) HCK(hipMemcpyAsync(fetch->pred, e->score, (size_t)B * e->h * e->w * 4, hipMemcpyDeviceToDevice, main));
+        if (fetch->up) HCK(hipMemcpyAsync(fetch->up, e->up, (size_t)B * e->H * e->W * 4, hipMemcpyDeviceToDevice, main));
+        if (fetch->sigm) HCK(hipMemcpyAsync(fetch->sigm, e->sigm, (size_t)B * e->H * e->W * 4, hipMemcpyDeviceToDevice, main));
+    }
+    e->launches_step = g_cmpc_launches - e->l0;
+    return CMPC_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// backward: reverse stage order; a stage output consumed by several stages gets the SUM of their input gradients
+// (add_n), exactly what tf.gradients' AddN nodes do for CMPC_model.py:447.
+// ------------------------------------------------------------------------------------------
+extern "C" int cmpc_backward(cmpc_handle e, void* stream) {
+    if (!e) { cmpc_set_error("backward: null handle"); return CMPC_EINVAL; }
+    if (!e->have_target || !e->seq_len_feed) { cmpc_set_error("backward: the last cmpc_forward had no target_fine"); return CMPC_EINVAL; }
+    CK(set_device(e));
+    hipStream_t main = (hipStream_t)stream;
+    t_cur = e;
+    const int B = e->B, T = e->T, Cp = e->Cp, Mp = e->Mp, dt = e->dt;
+    const long nmap = (long)e->R * Mp;
+    const float* target = e->target_feed;
+    HCK(hipMemsetAsync(e->ws + e->zf_bytes, 0, e->zb_bytes, main));
+    HCK(hipMemsetAsync(e->grads, 0, (size_t)e->total * sizeof(float), main));
+    // final score head + ConvLSTM
+    CK(cmpc_upsample_loss_bwd(e->up, target, e->dscore, e->cfg.loss_w[0] / B, B, e->h, e->w, e->H, e->W, main));
+    CK(cmpc_score_conv_bwd(dt, e->dscore, e->cl[2].h_new, pptr(e, "score/DW"), e->dfused, 0, gptr(e, "score/DW"), gptr(e, "score/biases"),
+                           B, e->h, e->w, Mp, e->M, main));
+    CK(clstm_bwd(e, main));
+    const int o1[3] = {1, 0, 0}, o2[3] = {2, 2, 1};
+    const void* fz[3] = {e->lv[2].F, e->lv[1].F, e->lv[0].F};
+    const void* ez[3] = {e->ex[0].out, e->ex[1].out, e->ex[2].out};
+    hipStream_t st[3];
+    // exchange round 2
+    CK(fork_lanes(e, main, st));
+    for (int i = 0; i < 3; ++i) CK(exchange_bwd(e, st[i], 3 + i, e->cl[i].dx, ez[i], ez[o1[i]], ez[o2[i]]));
+    CK(join_lanes(e, main));
+    // gradient of input j of a round = dfeat of module j + the f1 / f2 gradients of the two modules that read it
+    auto fan_in = [&](int base, int j, const void* (&src)[3]) {
+        int n = 0;
+        src[n++] = e->ex[base + j].dfeat;
+        for (int i = 0; i < 3; ++i) {
+            if (i == j) continue;
+            if (o1[i] == j) src[n++] = e->ex[base + i].dfs[0];
+            if (o2[i] == j) src[n++] = e->ex[base + i].dfs[1];
+        }
+        return n;
+    };
+    // exchange round 1
+    CK(fork_lanes(e, main, st));
+    for (int j = 0; j < 3; ++j) {
+        const void* src[3];
+        if (fan_in(3, j, src) != 3) { cmpc_set_error("backward: exchange fan-in"); return CMPC_EINVAL; }
+        CK(add_n(st[j], dt, e->de1[j], {src[0], src[1], src[2]}, false, nmap));
+        CK(exchange_bwd(e, st[j], j, e->de1[j], fz[j], fz[o1[j]], fz[o2[j]]));
+    }
+    CK(join_lanes(e, main));
+    // pyramid levels (lane i = level i = c5, c4, c3 = exchange input 2 - i); the language-side sums run on main meanwhile
+    CK(fork_lanes(e, main, st));
+    CK(add_n(main, DT_F32, e->dnec, {e->ex[0].dnec, e->ex[1].dnec, e->ex[2].dnec, e->ex[3].dnec, e->ex[4].dnec, e->ex[5].dnec}, false, (long)B * Cp));
+    CK(cmpc_lang_pool_bwd(e->dnec, e->nec, e->nec_rstd, e->parse, e->wf, e->dparse, e->dwf, B, T, Cp, e->RNN, 3, main));
+    for (int i = 0; i < 3; ++i) {
+        const void* src[3];
+        fan_in(0, 2 - i, src);
+        CK(add_n(st[i], dt, e->lv[i].dfus, {src[0], src[1], src[2]}, false, nmap));
+        CK(level_bwd(e, st[i], i, target));
+    }
+    CK(join_lanes(e, main));
+    CK(add_n(main, DT_F32, e->dvl, {e->lv[0].dvl, e->lv[1].dvl, e->lv[2].dvl}, false, (long)B * Cp));
+    CK(cmpc_lang_pool_bwd(e->dvl, e->vl, e->vl_rstd, e->parse, e->wf, e->dparse, e->dwf, B, T, Cp, e->RNN, 2, main));
+    hipLaunchKernelGGL(col_add3_kernel, dim3((B * T + 255) / 256), dim3(256), 0, main, e->dparse, 4, 2, e->lv[0].dpr, e->lv[1].dpr, e->lv[2].dpr, B * T);
+    CK(cmpc_check_launch("col_add3"));
+    CK(add_n(main, DT_F32, e->dwf, {e->lv[0].dwf, e->lv[1].dwf, e->lv[2].dwf}, true, (long)B * T * Cp));
+    CK(parser_bwd(e, main));
+    CK(text_bwd(e, main, e->seq_len_feed));
+    CK(flush_wgrad(e, main));
+    e->last_main = main;
+    e->launches_step = g_cmpc_launches - e->l0;
+    return CMPC_OK;
+}
+
+// tf.train.polynomial_decay + AdamOptimizer.apply_gradients (CMPC_model.py:450-478), then repack of the operands
+extern "C" int cmpc_optimizer_step(cmpc_handle e, float gscale, void* stream, double* lr_used) {
+    if (!e) { cmpc_set_error("optimizer_step: null handle"); return CMPC_EINVAL; }
+    CK(set_device(e));
+    hipStream_t st = (hipStream_t)stream;
+    if (e->last_main != st) {                      // optimizer on a stream of its own: order it after the backward pass
+        hipEvent_t ev = next_event(e);
+        HCK(hipEventRecord(ev, e->last_main));
+        HCK(hipStreamWaitEvent(st, ev, 0));
+    }
+    const cmpc_cfg& c = e->cfg;
+    const double gs = (double)std::min<int64_t>(e->step, c.lr_decay_step);
+    const double lr = ((double)c.start_lr - (double)c.end_lr) * pow(1.0 - gs / (double)c.lr_decay_step, (double)c.lr_power) + (double)c.end_lr;
+    const double t = (double)(e->step + 1), b1 = 0.9, b2 = 0.999;
+    const double lr_t = lr * sqrt(1.0 - pow(b2, t)) / (1.0 - pow(b1, t));
+    CK(cmpc_adam_step(e->params, e->grads, e->adam_m, e->adam_v, e->segs_dev, e->nseg, (float)lr_t, (float)b1, (float)b2, 1e-8f, gscale, st));
+    e->step += 1;
+    CK(cmpc_pack_weights_range(e->params, e->arena, e->descs_dev, e->tile_prefix_dev, e->tile_desc_dev, e->ndesc, 0, e->stage0_tiles, st));
+    HCK(hipEventRecord(e->ev_opt0, st));           // the text encoder's and parser's operands are final
+    CK(cmpc_pack_weights_range(e->params, e->arena, e->descs_dev, e->tile_prefix_dev, e->tile_desc_dev, e->ndesc, e->stage0_tiles, e->total_tiles, st));
+    HCK(hipEventRecord(e->ev_opt1, st));
+    e->opt_pending = true;
+    if (lr_used) *lr_used = lr;
+    e->launches_step = g_cmpc_launches - e->l0;
+    return CMPC_OK;
+}

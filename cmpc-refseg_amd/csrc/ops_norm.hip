@@ -14,7 +14,9 @@ static thread_local char g_err[512] = "";
 void cmpc_set_error(const char* fmt, ...) {
     va_list ap; va_start(ap, fmt); vsnprintf(g_err, sizeof(g_err), fmt, ap); va_end(ap);
 }
+long g_cmpc_launches = 0;          // host-side count of checked launches (cmpc_launch_count)
 int cmpc_check_launch(const char* what) {
+    ++g_cmpc_launches;
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { cmpc_set_error("%s: %s", what, hipGetErrorString(e)); return CMPC_EHIP; }
     return CMPC_OK;

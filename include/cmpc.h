@@ -251,6 +251,108 @@ typedef struct { int64_t off; int count; float wd; float gmult; } cmpc_adam_seg;
 int cmpc_adam_step(float* params, const float* grads, float* m, float* v, const cmpc_adam_seg* segs_dev, int nseg,
                    float lr_t, float beta1, float beta2, float eps, float gscale, void* stream);
 
+/* =====================================================================================================
+ * Whole-path entry points (SURVEY.md 8b, row "C-ABI"): one handle = one LSTM_model graph
+ * (CMPC_model.py:13-492) on one GPU.  The handle owns the parameters (fp32 masters, gradients, Adam moments),
+ * the packed GEMM operands, every intermediate of a step (one static workspace: nothing is allocated after
+ * cmpc_create), the statistics saved for backward, three lane streams and their events.  One call per
+ * reference sess.run:
+ *     sess.run([pred, up, sigm], feed)                 (test.py:286-296)          -> cmpc_forward
+ *     sess.run([train, train_step, merged], feed)      (trainval_model.py:98-107) -> cmpc_forward (with target_fine),
+ *                                                                                    cmpc_backward, [all-reduce of
+ *                                                                                    cmpc_buffers().grads], cmpc_optimizer_step
+ * No Python, no per-launch environment lookups: the host cost of a step is its hipLaunchKernel calls.
+ * The handle is single-caller (not re-entrant); a step's calls must be issued in the order above.
+ * ===================================================================================================== */
+typedef struct cmpc_engine_s* cmpc_handle;
+
+typedef struct {
+    /* graph-shaping constructor arguments of LSTM_model (CMPC_model.py:15-40) */
+    int batch_size, num_steps, vf_h, vf_w, H, W;
+    int vf_dim, c4_dim, c3_dim;         /* channels of res5c / res4b22 / res3b3 (2048, 1024, 512: CMPC_model.py:108-112) */
+    int vocab_size, v_emb_dim, mlp_dim, rnn_size, glove_dim, parse_dim;
+    /* train_op() (CMPC_model.py:446-456) */
+    double start_lr, end_lr, lr_power;  /* host-side arithmetic of tf.train.polynomial_decay, kept in double */
+    int lr_decay_step;
+    float weight_decay;
+    float loss_w[4];                    /* weights of the BCE terms: final, c5, c4, c3 = 0.7, 0.1, 0.1, 0.1 (:444-445) */
+    int dtype;                          /* storage of feature maps and visual GEMM operands: 0 f32 (parity mode), 1 bf16 */
+    int n_lanes;                        /* 3: pyramid levels / exchange modules on three lane streams; 1: one stream */
+    int device;                         /* HIP device ordinal; -1 = planning only (manifest, operand plan, workspace size:
+                                           no GPU is touched; every compute entry point then returns CMPC_EINVAL) */
+} cmpc_cfg;
+/* fills *cfg with the reference's defaults (CMPC_model.py:15-40), bf16, 3 lanes, device 0 */
+int cmpc_default_cfg(cmpc_cfg* cfg);
+int cmpc_create(const cmpc_cfg* cfg, cmpc_handle* out);
+int cmpc_destroy(cmpc_handle h);
+
+/* parameter manifest in the reference's variable order and names ("text_objseg/c5_lateral/DW", ...):
+ * index 0..n-1 -> name, element offset into the flat buffers, rank and shape (<= 4 dims, HWIO for convolutions) */
+int cmpc_param_count(cmpc_handle h);
+int cmpc_param_info(cmpc_handle h, int index, const char** name, int64_t* offset, int* rank, int64_t shape[4]);
+/* the flat fp32 device buffers (total elements incl. 16-B alignment gaps): masters, gradients (what a data-parallel
+ * caller all-reduces between cmpc_backward and cmpc_optimizer_step), Adam m and v */
+int cmpc_buffers(cmpc_handle h, float** params, float** grads, float** adam_m, float** adam_v, int64_t* total);
+/* tf.train.Saver.restore / save by variable name (trainval_model.py:46-63,136-142): host pointers, `count` must
+ * equal the variable's element count.  cmpc_set_weights does NOT repack; call cmpc_pack after the last one. */
+int cmpc_set_weights(cmpc_handle h, const char* name, const float* host_src, int64_t count);
+int cmpc_get_weights(cmpc_handle h, const char* name, float* host_dst, int64_t count);
+/* masters -> padded GEMM operands (after cmpc_set_weights, or after the caller modified the master buffer) */
+int cmpc_pack(cmpc_handle h, void* stream);
+/* global_step (CMPC_model.py:450) get / set (checkpoint resume, trainval_model.py:82 -lastiter) */
+int cmpc_get_step(cmpc_handle h, int64_t* step);
+int cmpc_set_step(cmpc_handle h, int64_t step);
+
+typedef struct {
+    const int32_t* words;       /* [B, T] token ids, 0-padded at the end (CMPC_model.py:67; util/text_processing.py:55-67) */
+    const int32_t* seq_len;     /* [B] (CMPC_model.py:71) */
+    const void* c3;             /* res3b3_relu  [B, vf_h, vf_w, c3_dim] NHWC, cfg.dtype (CMPC_model.py:76) */
+    const void* c4;             /* res4b22_relu [B, vf_h, vf_w, c4_dim] (:75) */
+    const void* c5;             /* res5c_relu   [B, vf_h, vf_w, vf_dim] (:74) */
+    const float* target_fine;   /* [B, H, W, 1] or NULL for inference (:69) */
+    void* feats_ready;          /* optional hipEvent_t recorded (on any stream) once c3/c4/c5 are complete: the text encoder
+                                   is enqueued first and only the pyramid levels wait for it; NULL = ordered on `stream` */
+} cmpc_feeds;
+typedef struct {                /* optional caller-owned device buffers the fetches are copied into (NULL = skip) */
+    float* pred;                /* [B, vf_h, vf_w, 1] logits (CMPC_model.py:140) */
+    float* up;                  /* [B, H, W, 1] logits (:141) */
+    float* sigm;                /* [B, H, W, 1] (:142) */
+} cmpc_fetches;
+/* build_graph() on one batch (CMPC_model.py:89-142); with target_fine also the four BCE terms, cls_loss_all and the
+ * in-graph mIoU (:438-447,486-490).  Everything is enqueued on `stream` and the handle's lane streams (which fork
+ * from and join into `stream`); nothing synchronises the host. */
+int cmpc_forward(cmpc_handle h, const cmpc_feeds* feeds, const cmpc_fetches* fetches, void* stream);
+/* tf.gradients(cost) of the last cmpc_forward (which must have had target_fine) into the flat gradient buffer:
+ * d cls_loss_all / d theta; the L2 term (:433,446) and the x2 on biases (:462-475) are applied by the optimizer. */
+int cmpc_backward(cmpc_handle h, void* stream);
+/* TF-Adam with polynomial LR decay, L2 on 'DW', x2 on 'biases' (CMPC_model.py:450-478), then repack of the operands.
+ * gscale multiplies the gradients first (1/world after a summing all-reduce).  May be enqueued on a stream of its
+ * own: the next cmpc_forward waits (on the device) for the events this call records.  *lr_used = the step's LR. */
+int cmpc_optimizer_step(cmpc_handle h, float gscale, void* stream, double* lr_used);
+
+/* Named intermediate of the last forward / backward ("words_parse", "gw_w_c3", "up_c4", "scalars", ...: the fetches
+ * of the reference's visualisers, test_visualize_graph.py:243-253, plus every stage output the parity tests compare).
+ * dtype: 0 f32, 1 bf16, 2 int32, 3 f64.  The pointer stays valid for the handle's lifetime; its contents are those of
+ * the most recent step once the work enqueued by that step has finished. */
+int cmpc_tap(cmpc_handle h, const char* name, void** ptr, int* dtype, int* rank, int64_t shape[4]);
+int cmpc_tap_count(cmpc_handle h);
+int cmpc_tap_name(cmpc_handle h, int index, const char** name);
+/* the handle's host-side plan: the pack descriptors (host array of ndesc entries, owned by the handle), the operand arena
+ * and workspace sizes, how many leading descriptors belong to the text encoder / parser (packed and published first);
+ * and one packed operand by key ("lstm.t", "mutan_c5.t", "fus_c3.n", ...: byte offset in the arena, dtype, rows, ld) */
+int cmpc_plan_info(cmpc_handle h, const cmpc_pack_desc** descs, int* ndesc, int64_t* arena_bytes, int64_t* workspace_bytes, int* stage0_ndesc);
+int cmpc_operand_info(cmpc_handle h, const char* key, int64_t* byte_off, int* dt, int* rows, int* ld);
+/* Live timing of the dominant kernel family (the bf16 MFMA gemm_nt launches: every 1x1-conv and dX product of the head):
+ * while enabled, every such launch of cmpc_forward / cmpc_backward is bracketed by a hipEvent pair on the stream it is
+ * launched on.  cmpc_kernel_timing_read synchronises the device and returns the summed durations (ms), algorithmic FLOPs
+ * (2 * rows * valid columns * valid K: padding not counted) and algorithmic bytes (A and C once per row, the weight once)
+ * since it was enabled.  Use with n_lanes = 1: with lanes, an interval also contains other streams' kernels. */
+int cmpc_set_lanes(cmpc_handle h, int n_lanes);      /* 1 or 3; takes effect from the next cmpc_forward */
+int cmpc_kernel_timing(cmpc_handle h, int enable);
+int cmpc_kernel_timing_read(cmpc_handle h, double* ms, double* flops, double* bytes, int64_t* launches);
+/* number of kernel launches / memsets the last forward+backward+optimizer_step issued (host-side counter) */
+int cmpc_launch_count(cmpc_handle h, int64_t* n);
+
 #ifdef __cplusplus
 }
 #endif

@@ -34,9 +34,10 @@ def test_library_exports_every_declared_symbol(pkg):
         fn = getattr(lib, name)                      # raises if not exported
         if name == "cmpc_abi_version":
             continue
-        assert name in pkg._lib.SIGNATURES, f"{name} missing from the ctypes binding"
-        assert len(pkg._lib.SIGNATURES[name]) == nargs, f"{name}: header has {nargs} args, binding {len(pkg._lib.SIGNATURES[name])}"
-    assert set(pkg._lib.SIGNATURES) <= set(protos)
+        sig = pkg._lib.SIGNATURES.get(name, pkg._lib.COUNTS.get(name))
+        assert sig is not None, f"{name} missing from the ctypes binding"
+        assert len(sig) == nargs, f"{name}: header has {nargs} args, binding {len(sig)}"
+    assert set(pkg._lib.SIGNATURES) | set(pkg._lib.COUNTS) <= set(protos)
     assert lib.cmpc_abi_version() == 1
     assert isinstance(lib.cmpc_last_error(), bytes)
 
@@ -122,3 +123,62 @@ def test_pack_tables_cover_operands_without_overlap(pkg):
                                          "offsets": [0, 8, 12, 16], "itemsize": ctypes.sizeof(pkg._lib.AdamSeg)}))
     assert int(segs["count"].sum()) == sum(int(np.prod(s)) for _, s, _, _ in st.specs)
     assert set(np.unique(segs["gm"])) == {1.0, 2.0} and set(np.unique(segs["wd"])) == {0.0, np.float32(0.0005)}
+
+
+def _plan_only_handle(pkg, hc, dt):
+    lib = pkg._lib.load()
+    c = pkg._lib.EngineCfg()
+    assert lib.cmpc_default_cfg(ctypes.byref(c)) == 0
+    for k in ("batch_size", "num_steps", "vf_h", "vf_w", "H", "W", "vf_dim", "c4_dim", "c3_dim", "vocab_size", "v_emb_dim",
+              "mlp_dim", "rnn_size", "glove_dim", "parse_dim"):
+        setattr(c, k, getattr(hc, k))
+    c.dtype, c.device = dt, -1                      # planning only: no GPU is touched
+    h = ctypes.c_void_p()
+    assert lib.cmpc_create(ctypes.byref(c), ctypes.byref(h)) == 0, lib.cmpc_last_error()
+    return lib, h
+
+
+@pytest.mark.parametrize("full", [False, True])
+def test_engine_plan_equals_python_plan(pkg, full):
+    """The whole-path handle (cmpc_create, C++) plans the SAME parameter manifest, packed operands and pack descriptors
+    as the Python ParamStore the op-level tests use -- checked without a GPU through a planning-only handle."""
+    hc = pkg.HeadCfg() if full else pkg.HeadCfg(batch_size=2, num_steps=6, vf_h=8, vf_w=8, H=64, W=64, vf_dim=256, c4_dim=128,
+                                                 c3_dim=64, vocab_size=50, v_emb_dim=40, mlp_dim=24, rnn_size=40, glove_dim=12, parse_dim=20)
+    for dt in (0, 1):
+        lib, h = _plan_only_handle(pkg, hc, dt)
+        st = pkg.ParamStore(hc, "cpu", dt)
+        n = lib.cmpc_param_count(h)
+        assert n == len(st.specs)
+        name, off, rank, shape = ctypes.c_char_p(), ctypes.c_int64(), ctypes.c_int(), (ctypes.c_int64 * 4)()
+        for i, (pn, pshape, _, _) in enumerate(st.specs):
+            assert lib.cmpc_param_info(h, i, ctypes.byref(name), ctypes.byref(off), ctypes.byref(rank), ctypes.byref(shape)) == 0
+            assert name.value.decode() == pn and off.value == st.index[pn][0]
+            assert tuple(shape[k] for k in range(rank.value)) == tuple(pshape)
+        descs, nd, ab, wb, s0 = ctypes.POINTER(pkg._lib.PackDesc)(), ctypes.c_int(), ctypes.c_int64(), ctypes.c_int64(), ctypes.c_int()
+        assert lib.cmpc_plan_info(h, ctypes.byref(descs), ctypes.byref(nd), ctypes.byref(ab), ctypes.byref(wb), ctypes.byref(s0)) == 0
+        assert nd.value == len(st._descs) and ab.value == st._arena_bytes and s0.value == st.stage0_ndesc and wb.value > 0
+        for i, d in enumerate(st._descs):
+            assert bytes(descs[i]) == bytes(d), i
+        bo, odt, rows, ld = ctypes.c_int64(), ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+        for key, op in st.ops.items():
+            assert lib.cmpc_operand_info(h, key.encode(), ctypes.byref(bo), ctypes.byref(odt), ctypes.byref(rows), ctypes.byref(ld)) == 0, key
+            assert (bo.value, odt.value, rows.value, ld.value) == (op.off, op.dt, op.rows, op.ld), key
+        # compute entry points refuse a planning-only handle, and nothing crashes
+        assert lib.cmpc_backward(h, None) == -1
+        assert lib.cmpc_destroy(h) == 0
+
+
+def test_engine_rejects_bad_configs(pkg):
+    lib = pkg._lib.load()
+    c = pkg._lib.EngineCfg()
+    lib.cmpc_default_cfg(ctypes.byref(c))
+    h = ctypes.c_void_p()
+    c.device = -1
+    for field, bad in (("vf_dim", 2000), ("rnn_size", 900), ("num_steps", 0), ("num_steps", 65), ("dtype", 7), ("n_lanes", 2), ("v_emb_dim", 4000)):
+        old = getattr(c, field)
+        setattr(c, field, bad)
+        assert lib.cmpc_create(ctypes.byref(c), ctypes.byref(h)) == -1, field
+        assert lib.cmpc_last_error()
+        setattr(c, field, old)
+    assert lib.cmpc_create(None, ctypes.byref(h)) == -1
+    assert lib.cmpc_tap(None, b"up", None, None, None, None) == -1
