@@ -89,7 +89,10 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=8, help="images per GPU")
-    ap.add_argument("--dtype", default="bf16", choices=("bf16", "f32"))
+    ap.add_argument("--dtype", default="f16", choices=("f16", "bf16", "f32"),
+                    help="storage of maps / visual GEMM operands. f16 and bf16 run the same MFMA pipelines at the same rate; f16 (default) is "
+                         "the one that meets BASELINE's 1e-4 mean-IoU bar (bf16 storage: up to 1.6e-4), see tests/test_gpu_parity.py")
+    ap.add_argument("--no-alt-dtype", action="store_true", help="skip the bf16-storage rate reported next to the f16 one")
     ap.add_argument("--cpu-images", type=int, default=8)
     ap.add_argument("--cpu-steps", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -152,6 +155,7 @@ def main():
         _, scal = model.train_step(words, im, target, seq_len, ready=ready)
     barrier()
     dt = time.perf_counter() - t0
+    loss = float(scal["loss_all"])
     launches = model.eng.launch_count()            # library launches of the last forward + backward + optimizer step
     # Per-launch timing of the dominant kernel family: in the timed region above the three pyramid levels run on three
     # lane streams, so a kernel's start->end event interval also contains other streams' kernels.  The event pairs
@@ -180,11 +184,27 @@ def main():
             model.forward(words, im, seq_len)
         barrier()
         dt_fwd = time.perf_counter() - t0
+    # the same train step with bf16 storage (BASELINE config 2 names bf16): same kernels, same rate, misses the IoU bar
+    alt = None
+    if world == 1 and args.dtype == "f16" and not args.no_alt_dtype:
+        del model
+        torch.cuda.empty_cache()
+        m2 = pkg.LSTM_model(batch_size=B, num_steps=T, H=H, W=W, mode="train", dtype="bf16", device=str(dev))
+        for _ in range(SETUP_STEPS + args.warmup):
+            m2.train_step(words, im, target, seq_len, ready=ready)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            m2.train_step(words, im, target, seq_len, ready=ready)
+        torch.cuda.synchronize()
+        d2 = time.perf_counter() - t0
+        alt = {"dtype": "bf16", "images_per_sec": B * args.steps / d2, "ms_per_step": 1e3 * d2 / args.steps,
+               "note": "bf16 storage: same MFMA pipelines; mean-IoU delta vs the oracle up to 1.6e-4 (bar 1e-4), f16 storage <= 3.5e-5"}
+        del m2
     tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
     if world > 1:
         torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
     dt = float(tmax.item())
-    loss = float(scal["loss_all"])
     log(f"timed {args.steps} steps in {dt:.3f} s")
 
     if rank == 0:
@@ -203,19 +223,21 @@ def main():
         out["head_launches_per_step"] = launches
         if ktime is not None and ktime[3] > 0:
             t, f, by, n = ktime
-            peak = 2500.0 if args.dtype == "bf16" else 157.3
+            peak = 2500.0 if args.dtype != "f32" else 157.3          # dense 16-bit MFMA peak (f16 = bf16 rate), fp32 MFMA peak
             # HBM-side bytes per launch from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE on this
             # same command, scripts/pmc_traffic.py); bench.py cannot run the profiler on itself
             traffic = None
             tp = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r02_gemm_nt_traffic.json")
-            if args.dtype == "bf16" and B == 8 and os.path.exists(tp):
+            if args.dtype != "f32" and B == 8 and os.path.exists(tp):
                 traffic = json.load(open(tp))["hbm_bytes_per_launch"]
             out["roofline"] = {"bound": "mfma", "achieved": f / t / 1e12, "peak": peak, "unit": "TFLOP/s",
                                "frac": f / t / 1e12 / peak, "traffic": traffic,
                                "algorithmic_bytes_per_launch": by / n,
-                               "kernel": "gemm_nt_v5/v4/v3_kernel<bf16> (every 1x1-conv / dX product of the head)",
+                               "kernel": "gemm_nt_v5/v4/v3_kernel<%s> (every 1x1-conv / dX product of the head)" % args.dtype,
                                "measured": "hipEvent pairs around every launch (cmpc_kernel_timing, on the launch stream) over the same K steps re-run on ONE stream (in the timed region the lane streams overlap, so a start->end interval there also contains other streams' kernels)",
                                "launches_per_step": n / args.steps, "ms_per_step_in_kernel": 1e3 * t / args.steps}
+        if alt is not None:
+            out["alt_dtype"] = alt
         if world == 1 and not args.no_cpu_baseline:
             log("cpu baseline (oracle on host cores)")
             out["cpu_baseline"] = cpu_baseline(args)

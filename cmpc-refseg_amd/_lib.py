@@ -12,7 +12,7 @@ import subprocess
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libcmpc_hip.so")
 
-DT_F32, DT_BF16 = 0, 1
+DT_F32, DT_BF16, DT_F16 = 0, 1, 2
 ACT_NONE, ACT_RELU, ACT_TANH, ACT_SIGMOID = 0, 1, 2, 3
 
 
@@ -99,7 +99,7 @@ class EngineCfg(C.Structure):
         ("parse_dim", C.c_int),
         ("start_lr", C.c_double), ("end_lr", C.c_double), ("lr_power", C.c_double), ("lr_decay_step", C.c_int),
         ("weight_decay", C.c_float), ("loss_w", C.c_float * 4),
-        ("dtype", C.c_int), ("n_lanes", C.c_int), ("device", C.c_int),
+        ("dtype", C.c_int), ("loss_scale", C.c_float), ("n_lanes", C.c_int), ("device", C.c_int),
     ]
 
 
@@ -172,6 +172,7 @@ SIGNATURES = {
     "cmpc_default_cfg": [C.POINTER(EngineCfg)],
     "cmpc_create": [C.POINTER(EngineCfg), _PP],
     "cmpc_destroy": [_P],
+    "cmpc_get_cfg": [_P, C.POINTER(EngineCfg)],
     "cmpc_param_info": [_P, _I, C.POINTER(C.c_char_p), C.POINTER(_L), C.POINTER(_I), C.POINTER(_L * 4)],
     "cmpc_buffers": [_P, _PP, _PP, _PP, _PP, C.POINTER(_L)],
     "cmpc_set_weights": [_P, C.c_char_p, _P, _L],

@@ -22,6 +22,9 @@ import torch.nn.functional as F
 from . import _lib
 
 
+_DT = {torch.float32: 0, torch.bfloat16: 1, torch.float16: 2}        # dtype codes of include/cmpc.h
+
+
 def _same_pad(size, k, stride, dil):
     out = -(-size // stride)
     total = max((out - 1) * stride + (k - 1) * dil + 1 - size, 0)
@@ -123,7 +126,7 @@ class _ConvBN(nn.Module):
             Ho, Wo, Cout = -(-H // s), -(-W // s), self.weight.shape[0]
             y = torch.empty((B, Ho, Wo, Cout), dtype=x.dtype, device=x.device)
             a = _lib.ConvArgs()
-            a.dtype = 0 if x.dtype == torch.float32 else 1
+            a.dtype = _DT[x.dtype]
             a.X, a.ldx = x.data_ptr(), Cin
             a.Wt, a.ldw = self.w_ohwi.data_ptr(), k * k * Cin
             a.bias, a.res = self.bias32.data_ptr(), (res.data_ptr() if res is not None else None)
@@ -144,7 +147,7 @@ class _ConvBN(nn.Module):
             if res is not None:
                 y = y + res
             return F.relu(y, inplace=True) if self.relu else y
-        dt = 0 if y.dtype == torch.float32 else 1
+        dt = _DT[y.dtype]
         _lib.call("cmpc_bias_act_res", dt, y.data_ptr(), self.bias32.data_ptr(), res.data_ptr() if res is not None else None,
                   int(self.relu), B * H * W, C, ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
         return y

@@ -13,8 +13,10 @@ typedef __attribute__((ext_vector_type(4))) short s4;
 typedef __attribute__((ext_vector_type(8))) short s8;
 
 typedef uint16_t bf16_t;   // storage type of a bf16 element
+typedef _Float16 f16_t;    // IEEE half: same MFMA rate as bf16, 3 more mantissa bits (2^-12 against 2^-9 rounding), range +-65504
+typedef __attribute__((ext_vector_type(8))) _Float16 h8v;
 
-enum { DT_F32 = 0, DT_BF16 = 1 };
+enum { DT_F32 = 0, DT_BF16 = 1, DT_F16 = 2 };
 enum { ACT_NONE = 0, ACT_RELU = 1, ACT_TANH = 2, ACT_SIGMOID = 3 };
 
 void cmpc_set_error(const char* fmt, ...);
@@ -44,6 +46,11 @@ template <> struct Elem<bf16_t> {
     static __device__ __forceinline__ void st(bf16_t* p, float v) { *p = f2bf(v); }
 };
 
+template <> struct Elem<f16_t> {
+    static __device__ __forceinline__ float ld(const f16_t* p) { return (float)*p; }
+    static __device__ __forceinline__ void st(f16_t* p, float v) { *p = (f16_t)v; }      // v_cvt_f16_f32: RNE, overflow -> inf
+};
+
 // 8 consecutive elements <-> float[8] (16-byte vector accesses; p must be 16-B aligned for
 // bf16 and 32-B aligned for f32).
 template <typename T> __device__ __forceinline__ void ld8(const T* p, float (&v)[8]);
@@ -59,6 +66,11 @@ template <> __device__ __forceinline__ void ld8<bf16_t>(const bf16_t* p, float (
     v[4] = __uint_as_float(a.z << 16); v[5] = __uint_as_float(a.z & 0xffff0000u);
     v[6] = __uint_as_float(a.w << 16); v[7] = __uint_as_float(a.w & 0xffff0000u);
 }
+template <> __device__ __forceinline__ void ld8<f16_t>(const f16_t* p, float (&v)[8]) {
+    const h8v a = *reinterpret_cast<const h8v*>(p);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = (float)a[e];
+}
 template <typename T> __device__ __forceinline__ void st8(T* p, const float (&v)[8]);
 template <> __device__ __forceinline__ void st8<float>(float* p, const float (&v)[8]) {
     *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
@@ -73,10 +85,18 @@ template <> __device__ __forceinline__ void st8<bf16_t>(bf16_t* p, const float (
     *reinterpret_cast<uint4*>(p) = a;
 }
 
+template <> __device__ __forceinline__ void st8<f16_t>(f16_t* p, const float (&v)[8]) {
+    h8v a;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) a[e] = (f16_t)v[e];
+    *reinterpret_cast<h8v*>(p) = a;
+}
+
 // the value a stored element will read back as (bf16 storage rounds; fp32 storage is exact)
 template <typename T> __device__ __forceinline__ float stored_value(float v);
 template <> __device__ __forceinline__ float stored_value<float>(float v) { return v; }
 template <> __device__ __forceinline__ float stored_value<bf16_t>(float v) { return bf2f(f2bf(v)); }
+template <> __device__ __forceinline__ float stored_value<f16_t>(float v) { return (float)(f16_t)v; }
 
 // wave64 reductions via cross-lane shuffles
 __device__ __forceinline__ float wave_sum(float v) {
@@ -145,5 +165,6 @@ __device__ __forceinline__ void ln_stats(const double* sums, double count, float
     do {                                                           \
         if ((dt) == DT_F32) { typedef float T; __VA_ARGS__; }      \
         else if ((dt) == DT_BF16) { typedef bf16_t T; __VA_ARGS__; } \
+        else if ((dt) == DT_F16) { typedef f16_t T; __VA_ARGS__; } \
         else { cmpc_set_error("bad dtype %d", (int)(dt)); return CMPC_EINVAL; } \
     } while (0)

@@ -507,7 +507,7 @@ void plan_workspace(E* e, Bump& zf, Bump& zb, Bump& g) {
     e->scalars = (float*)g.take(256);
     tap(e, "fused", e->cl[2].h_new, vd, {R, Mp});
     tap(e, "pred", e->score, 0, {B, e->h, e->w, 1}); tap(e, "up", e->up, 0, {B, H, W, 1}); tap(e, "sigm", e->sigm, 0, {B, H, W, 1});
-    tap(e, "iu", e->iu, 2, {2, B}); tap(e, "loss_vec", e->loss, 0, {B}); tap(e, "scalars", e->scalars, 0, {6});
+    tap(e, "iu", e->iu, 3, {2, B}); tap(e, "loss_vec", e->loss, 0, {B}); tap(e, "scalars", e->scalars, 0, {6});
 }
 
 // ------------------------------------------------------------------------------------------
@@ -546,7 +546,7 @@ inline int valid_extent(const E* e, int x) {
 
 int gemm_nt(hipStream_t st, int dt, std::initializer_list<Seg> segs, void* C, int ldc, int M, int N, const GemmOpt& o = GemmOpt()) {
     E* te = t_cur;
-    if (te && te->timing && dt == DT_BF16 && N >= 128 && M >= 512) {        // the launches that dispatch to the bf16 MFMA pipelines
+    if (te && te->timing && dt != DT_F32 && N >= 128 && M >= 512) {        // the launches that dispatch to the 16-bit MFMA pipelines
         te->timing = false;
         hipEvent_t e0 = nullptr, e1 = nullptr;
         if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) { cmpc_set_error("timing: hipEventCreate"); return CMPC_EHIP; }
@@ -586,7 +586,7 @@ int gemm_tn(E* e, hipStream_t st, int dt, const void* A, int lda, int Ka, const 
     for (size_t i = 0; i < offs.size(); ++i) { a.a_off[i] = offs[i][0]; a.d_off[i] = offs[i][1]; a.o_off[i] = offs[i][2]; }
     a.nb2 = o.nb2; a.a_bs = o.a_bs; a.d_bs = o.d_bs; a.o_bs = o.o_bs;
     const int tiles = ((Kv + 127) / 128) * ((Nv + 127) / 128) * a.nb * a.nb2;
-    const int br = dt == DT_BF16 ? 64 : 32;
+    const int br = dt != DT_F32 ? 64 : 32;
     a.rsplit = std::max(1, std::min((R + 4 * br - 1) / (4 * br), (512 + tiles - 1) / tiles));
     a.alpha = o.alpha; a.zeros = e->zero_page;
     if (o.defer) { e->deferred.push_back(a); return CMPC_OK; }
@@ -615,7 +615,8 @@ int add_n(hipStream_t st, int dt, void* dst, std::initializer_list<const void*> 
     const long n8 = n / 8;
     const int grid = (int)std::min<long>((n8 + 255) / 256, 2048);
     if (dt == DT_F32) hipLaunchKernelGGL((add_n_kernel<float>), dim3(grid), dim3(256), 0, st, (float*)dst, a, acc ? 1 : 0, n8);
-    else hipLaunchKernelGGL((add_n_kernel<bf16_t>), dim3(grid), dim3(256), 0, st, (bf16_t*)dst, a, acc ? 1 : 0, n8);
+    else if (dt == DT_BF16) hipLaunchKernelGGL((add_n_kernel<bf16_t>), dim3(grid), dim3(256), 0, st, (bf16_t*)dst, a, acc ? 1 : 0, n8);
+    else hipLaunchKernelGGL((add_n_kernel<f16_t>), dim3(grid), dim3(256), 0, st, (f16_t*)dst, a, acc ? 1 : 0, n8);
     return cmpc_check_launch("add_n");
 }
 
@@ -762,7 +763,7 @@ int level_bwd(E* e, hipStream_t st, int li, const float* target) {
     const int es = e->esz;
     TnOpt d; d.defer = true;
     // -- score head: dfus += score-conv backward of w_lv/B * (sigmoid(up) - target)
-    CK(cmpc_upsample_loss_bwd(L.up, target, L.dscore, e->cfg.loss_w[1 + li] / B, B, e->h, e->w, e->H, e->W, st));
+    CK(cmpc_upsample_loss_bwd(L.up, target, L.dscore, e->cfg.loss_w[1 + li] * e->cfg.loss_scale / B, B, e->h, e->w, e->H, e->W, st));
     CK(cmpc_score_conv_bwd(dt, L.dscore, L.F, pptr(e, fmt("score_%s/DW", lv)), L.dfus, 1, gptr(e, fmt("score_%s/DW", lv)),
                            gptr(e, fmt("score_%s/biases", lv)), B, e->h, e->w, Mp, M, st));
     // -- fusion
@@ -1014,7 +1015,7 @@ extern "C" int cmpc_default_cfg(cmpc_cfg* c) {
     c->vocab_size = 12112; c->v_emb_dim = 1000; c->mlp_dim = 500; c->rnn_size = 1000; c->glove_dim = 300; c->parse_dim = 500;
     c->start_lr = 0.00025; c->end_lr = 0.00001; c->lr_power = 0.9; c->lr_decay_step = 800000; c->weight_decay = 0.0005f;
     c->loss_w[0] = 0.7f; c->loss_w[1] = c->loss_w[2] = c->loss_w[3] = 0.1f;
-    c->dtype = DT_BF16; c->n_lanes = 3; c->device = 0;
+    c->dtype = DT_BF16; c->n_lanes = 3; c->device = 0; c->loss_scale = 0.f;
     return CMPC_OK;
 }
 
@@ -1040,7 +1041,8 @@ extern "C" int cmpc_create(const cmpc_cfg* c, cmpc_handle* out) {
     if (c->batch_size < 1 || c->num_steps < 1 || c->num_steps > 64 || c->vf_h < 1 || c->vf_w < 1 || c->H < c->vf_h || c->W < c->vf_w) {
         cmpc_set_error("create: need batch_size >= 1, 1 <= num_steps <= 64, H >= vf_h >= 1, W >= vf_w >= 1"); return CMPC_EINVAL;
     }
-    if (c->dtype != DT_F32 && c->dtype != DT_BF16) { cmpc_set_error("create: dtype must be 0 (f32) or 1 (bf16)"); return CMPC_EINVAL; }
+    if (c->dtype != DT_F32 && c->dtype != DT_BF16 && c->dtype != DT_F16) { cmpc_set_error("create: dtype must be 0 (f32), 1 (bf16) or 2 (f16)"); return CMPC_EINVAL; }
+    if (c->loss_scale < 0.f) { cmpc_set_error("create: loss_scale must be >= 0 (0 = default)"); return CMPC_EINVAL; }
     if (c->rnn_size != c->v_emb_dim) { cmpc_set_error("create: rnn_size must equal v_emb_dim (the affinity contracts them, CMPC_model.py:384)"); return CMPC_EINVAL; }
     if (c->vf_dim % 64 || c->c4_dim % 64 || c->c3_dim % 64) { cmpc_set_error("create: vf_dim / c4_dim / c3_dim must be multiples of 64 (MFMA K tile)"); return CMPC_EINVAL; }
     if (c->v_emb_dim < 8 || c->mlp_dim < 8 || c->glove_dim < 1 || c->parse_dim < 4 || c->vocab_size < 1) {
@@ -1058,6 +1060,17 @@ extern "C" int cmpc_create(const cmpc_cfg* c, cmpc_handle* out) {
     }
     E* e = new E();
     e->cfg = *c;
+    // Static loss scaling, f16 storage only (range 6e-8 .. 65504).  The reference's loss is a SUM over the H x W pixels
+    // (util/loss.py:6-16), so the upstream gradients are large, not small: a low-resolution logit receives up to
+    // w * (H/h) * (W/w) / B (45 at B = 1).  The scale is the power of two that puts that maximum at <= 16; every gradient the
+    // backward pass writes carries it and the optimizer divides it out again.  bf16 / f32 storage: 1.
+    if (e->cfg.loss_scale == 0.f) {
+        e->cfg.loss_scale = 1.f;
+        if (c->dtype == DT_F16) {
+            const double top = (double)c->loss_w[0] * ((double)c->H / c->vf_h) * ((double)c->W / c->vf_w) / c->batch_size;
+            e->cfg.loss_scale = (float)exp2(floor(log2(16.0 / top)));
+        }
+    }
     e->B = c->batch_size; e->T = c->num_steps; e->h = c->vf_h; e->w = c->vf_w; e->N = e->h * e->w; e->R = e->B * e->N;
     e->H = c->H; e->W = c->W; e->V = c->vocab_size;
     e->C = c->v_emb_dim; e->Cp = pad64(e->C); e->M = c->mlp_dim; e->Mp = pad64(e->M); e->G = c->glove_dim; e->Gp = pad64(e->G);
@@ -1100,7 +1113,7 @@ extern "C" int cmpc_create(const cmpc_cfg* c, cmpc_handle* out) {
         ECK(hipMalloc(&tmp, (size_t)e->R * 64 * sizeof(float)));
         for (int b = 0; b < e->B; ++b) ECK(hipMemcpy(tmp + (size_t)b * e->N * 64, sp.data(), sp.size() * sizeof(float), hipMemcpyHostToDevice));
         if (e->dt == DT_F32) ECK(hipMemcpy(e->spatial, tmp, (size_t)e->R * 64 * sizeof(float), hipMemcpyDeviceToDevice));
-        else if (cmpc_cast(DT_F32, tmp, DT_BF16, e->spatial, (int64_t)e->R * 64, nullptr) != CMPC_OK) { (void)hipFree(tmp); return fail(CMPC_EHIP); }
+        else if (cmpc_cast(DT_F32, tmp, e->dt, e->spatial, (int64_t)e->R * 64, nullptr) != CMPC_OK) { (void)hipFree(tmp); return fail(CMPC_EHIP); }
         ECK(hipDeviceSynchronize());
         (void)hipFree(tmp);
     }
@@ -1203,6 +1216,11 @@ extern "C" int cmpc_operand_info(cmpc_handle e, const char* key, int64_t* byte_o
     if (ld) *ld = it->second.ld;
     return CMPC_OK;
 }
+extern "C" int cmpc_get_cfg(cmpc_handle e, cmpc_cfg* out) {
+    if (!e || !out) { cmpc_set_error("get_cfg: null argument"); return CMPC_EINVAL; }
+    *out = e->cfg;
+    return CMPC_OK;
+}
 extern "C" int cmpc_set_lanes(cmpc_handle e, int n_lanes) {
     if (!e || (n_lanes != 1 && n_lanes != 3)) { cmpc_set_error("set_lanes: n_lanes must be 1 or 3"); return CMPC_EINVAL; }
     e->cfg.n_lanes = n_lanes;
@@ -1300,7 +1318,7 @@ extern "C" int cmpc_backward(cmpc_handle e, void* stream) {
     HCK(hipMemsetAsync(e->ws + e->zf_bytes, 0, e->zb_bytes, main));
     HCK(hipMemsetAsync(e->grads, 0, (size_t)e->total * sizeof(float), main));
     // final score head + ConvLSTM
-    CK(cmpc_upsample_loss_bwd(e->up, target, e->dscore, e->cfg.loss_w[0] / B, B, e->h, e->w, e->H, e->W, main));
+    CK(cmpc_upsample_loss_bwd(e->up, target, e->dscore, e->cfg.loss_w[0] * e->cfg.loss_scale / B, B, e->h, e->w, e->H, e->W, main));
     CK(cmpc_score_conv_bwd(dt, e->dscore, e->cl[2].h_new, pptr(e, "score/DW"), e->dfused, 0, gptr(e, "score/DW"), gptr(e, "score/biases"),
                            B, e->h, e->w, Mp, e->M, main));
     CK(clstm_bwd(e, main));
@@ -1371,7 +1389,7 @@ extern "C" int cmpc_optimizer_step(cmpc_handle e, float gscale, void* stream, do
     const double lr = ((double)c.start_lr - (double)c.end_lr) * pow(1.0 - gs / (double)c.lr_decay_step, (double)c.lr_power) + (double)c.end_lr;
     const double t = (double)(e->step + 1), b1 = 0.9, b2 = 0.999;
     const double lr_t = lr * sqrt(1.0 - pow(b2, t)) / (1.0 - pow(b1, t));
-    CK(cmpc_adam_step(e->params, e->grads, e->adam_m, e->adam_v, e->segs_dev, e->nseg, (float)lr_t, (float)b1, (float)b2, 1e-8f, gscale, st));
+    CK(cmpc_adam_step(e->params, e->grads, e->adam_m, e->adam_v, e->segs_dev, e->nseg, (float)lr_t, (float)b1, (float)b2, 1e-8f, gscale / e->cfg.loss_scale, st));
     e->step += 1;
     CK(cmpc_pack_weights_range(e->params, e->arena, e->descs_dev, e->tile_prefix_dev, e->tile_desc_dev, e->ndesc, 0, e->stage0_tiles, st));
     HCK(hipEventRecord(e->ev_opt0, st));           // the text encoder's and parser's operands are final

@@ -31,6 +31,11 @@ template <> struct Mma<bf16_t> {
         return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf8v, a), __builtin_bit_cast(bf8v, b), acc, 0, 0, 0);
     }
 };
+template <> struct Mma<f16_t> {
+    static __device__ __forceinline__ f4 run(const uint4& a, const uint4& b, f4 acc) {
+        return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h8v, a), __builtin_bit_cast(h8v, b), acc, 0, 0, 0);
+    }
+};
 template <> struct Mma<float> {
     static __device__ __forceinline__ f4 run(const uint4& a, const uint4& b, f4 acc) {
         // lane (r, q) holds k = 4*(chunk)+e, e = 0..3: MFMA step e pairs element e of both operands.
@@ -108,15 +113,15 @@ __device__ __forceinline__ void gemm_nt_epilogue_act(const cmpc_gemm_nt_args& p,
             *reinterpret_cast<float4*>(Cp) = make_float4(v[0], v[1], v[2], v[3]);
             if (full) *reinterpret_cast<float4*>(Cp + 4) = make_float4(v[4], v[5], v[6], v[7]);
         } else {
-            bf16_t* Cb = reinterpret_cast<bf16_t*>(Ct) + off;
+            T* Cb = Ct + off;                      // 16-bit storage (bf16 or f16)
             if (full && ((reinterpret_cast<uintptr_t>(Cb) & 15) == 0)) {
-                if (p.accumulate) { float o[8]; ld8<bf16_t>(Cb, o);
+                if (p.accumulate) { float o[8]; ld8<T>(Cb, o);
 #pragma unroll
                     for (int e = 0; e < 8; ++e) v[e] += o[e]; }
-                st8<bf16_t>(Cb, v);
+                st8<T>(Cb, v);
             } else {                               // ragged right edge / odd ldc: rare
                 const int ne = full ? 8 : 4;
-                for (int e = 0; e < ne; ++e) { float x = v[e]; if (p.accumulate) x += bf2f(Cb[e]); Cb[e] = f2bf(x); }
+                for (int e = 0; e < ne; ++e) { float x = v[e]; if (p.accumulate) x += Elem<T>::ld(Cb + e); Elem<T>::st(Cb + e, x); }
             }
         }
     }
@@ -258,17 +263,6 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const cmpc_gemm_nt_args p)
 // the loads of tile t+1 stay in flight across the barrier while tile t is multiplied.
 // LDS image identical to v1 (linear destination, XOR applied to the per-lane SOURCE chunk).
 // ------------------------------------------------------------------------------------------
-#ifdef CMPC_GEMM_TRACE
-// per-workgroup phase timestamps (100 MHz wall clock) for scripts/gemm_trace.py; not part of the product build
-__device__ long long g_gemm_trace[8 * 4096];
-#define TRACE_MARK(i) do { const int tb_ = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z); \
-                           if (threadIdx.x == 0 && tb_ < 4096) g_gemm_trace[tb_ * 8 + (i)] = wall_clock64(); } while (0)
-extern "C" int cmpc_debug_gemm_trace(long long* dst, int n) {
-    return hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_gemm_trace), sizeof(long long) * n) == hipSuccess ? 0 : -2;
-}
-#else
-#define TRACE_MARK(i) do {} while (0)
-#endif
 
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
@@ -289,122 +283,6 @@ __device__ __forceinline__ void glds16s(const void* sbase, uint32_t voff, uint32
                  : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds_dst) : "memory");
 }
 
-template <typename T, int BM>
-__global__ __launch_bounds__(512) void gemm_nt_v2_kernel(const cmpc_gemm_nt_args p) {
-    constexpr int BN = 128;
-    constexpr int EPC = 16 / (int)sizeof(T);
-    constexpr int BK = BKB / (int)sizeof(T);
-    constexpr int WAVES_N = 2, WAVES_M = 4;
-    constexpr int TM = BM / WAVES_M / 16, TN = BN / WAVES_N / 16;
-    constexpr int STAGE = (BM + BN) * BKB;
-    constexpr int APW = BM / 8 / 8;                // A wave-instructions (8 rows x 128 B = 1 KiB) per wave per stage
-    constexpr int BPW = BN / 8 / 8;
-    constexpr int LPT = APW + BPW;                 // LDS-DMA instructions per wave per tile
-
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    TRACE_MARK(0);
-    const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wid / WAVES_N, wn = wid % WAVES_N;
-    const int gx = (p.N + BN - 1) / BN, nwg = gridDim.x;
-    const int xq = nwg >> 3, xr = nwg & 7, xcd = blockIdx.x & 7, xi = blockIdx.x >> 3;
-    const int tix = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + xi;
-    const int m0 = (tix / gx) * BM, n0 = (tix % gx) * BN;
-    const long bz = blockIdx.z;
-
-    int ntile[3], ntot = 0;
-#pragma unroll
-    for (int s = 0; s < 3; ++s) { ntile[s] = (s < p.nseg) ? p.K[s] / BK : 0; ntot += ntile[s]; }
-
-    f4 acc[TM][TN];
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j) acc[i][j] = f4{0.f, 0.f, 0.f, 0.f};
-
-    const int r8 = lane >> 3, slot = lane & 7;
-    const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
-    auto issue = [&](int tile, int buf) {
-        int s = 0, t = tile;
-        if (t >= ntile[0]) { t -= ntile[0]; s = 1; if (t >= ntile[1]) { t -= ntile[1]; s = 2; } }
-        const T* Ap = reinterpret_cast<const T*>(p.A[s]) + bz * p.sA[s];
-        const T* Bp = reinterpret_cast<const T*>(p.Bt[s]) + bz * p.sB[s];
-        const long lda = p.lda[s], ldb = p.ldb[s];
-        const int k0 = t * BK;
-        const uint32_t base = lds0 + buf * STAGE;
-#pragma unroll
-        for (int j = 0; j < APW; ++j) {
-            const int blk = wid * APW + j, row = blk * 8 + r8;
-            const int c = slot ^ ((row >> 1) & 7);
-            const int gm = min(m0 + row, p.M - 1);           // rows past M: any valid address (never stored)
-            glds16(Ap + gm * lda + k0 + c * EPC, __builtin_amdgcn_readfirstlane(base + blk * 1024));
-        }
-#pragma unroll
-        for (int j = 0; j < BPW; ++j) {
-            const int blk = wid * BPW + j, row = blk * 8 + r8;
-            const int c = slot ^ ((row >> 1) & 7);
-            const int gn = min(n0 + row, p.N - 1);
-            glds16(Bp + gn * ldb + k0 + c * EPC, __builtin_amdgcn_readfirstlane(base + BM * BKB + blk * 1024));
-        }
-    };
-
-    if (ntot > 0) issue(0, 0);
-    if (ntot > 1) issue(1, 1);
-    const int fr = lane & 15, fq = lane >> 4;
-    int cur = 0;
-    for (int kt = 0; kt < ntot; ++kt) {
-        if (kt + 1 < ntot) wait_vmcnt<LPT>(); else wait_vmcnt<0>();
-        __builtin_amdgcn_s_barrier();
-        if (kt == 0) TRACE_MARK(1);
-        if (kt + 2 < ntot) issue(kt + 2, cur == 0 ? 2 : cur - 1);
-        const char* sA = smem + cur * STAGE;
-        const char* sB = sA + BM * BKB;
-#pragma unroll
-        for (int s = 0; s < 2; ++s) {
-            uint4 a[TM], b[TN];
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-                a[i] = *reinterpret_cast<const uint4*>(sA + nt_lds_off(wm * TM * 16 + i * 16 + fr, 4 * s + fq));
-#pragma unroll
-            for (int j = 0; j < TN; ++j)
-                b[j] = *reinterpret_cast<const uint4*>(sB + nt_lds_off(wn * TN * 16 + j * 16 + fr, 4 * s + fq));
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int j = 0; j < TN; ++j) acc[i][j] = Mma<T>::run(a[i], b[j], acc[i][j]);
-        }
-        cur = (cur == 2) ? 0 : cur + 1;
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    TRACE_MARK(2);
-
-    constexpr int WR = TM * 16, WC = TN * 16;
-    float* slab = reinterpret_cast<float*>(smem) + wid * (WR * WC);
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int row = i * 16 + fq * 4 + r, col = j * 16 + fr;
-                slab[row * WC + (col ^ (((row >> 2) & 3) << 4))] = acc[i][j][r];
-            }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_wave_barrier();
-    TRACE_MARK(3);
-
-    gemm_nt_epilogue<T, WR, WC>(p, slab, lane, m0 + wm * WR, n0 + wn * WC, bz);
-    TRACE_MARK(4);
-#ifdef CMPC_GEMM_TRACE
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    TRACE_MARK(5);
-    if (threadIdx.x == 0 && blockIdx.x < 4096) {
-        unsigned hw; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
-        unsigned xcc; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-        g_gemm_trace[blockIdx.x * 8 + 6] = hw; g_gemm_trace[blockIdx.x * 8 + 7] = xcc;
-    }
-#endif
-}
 
 // ------------------------------------------------------------------------------------------
 // gemm_nt v4: v2's tile and LDS-DMA pipeline with
@@ -428,7 +306,6 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     constexpr int LPT = APW + BPW;
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    TRACE_MARK(0);
     const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wid / WAVES_N, wn = wid % WAVES_N;
     const int gx = (p.N + BN - 1) / BN, nwg = gridDim.x;
@@ -521,10 +398,6 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     if (ntot > 2) issue_next(2);
     if (ntot > 2) wait_vmcnt<2 * LPT>(); else if (ntot > 1) wait_vmcnt<LPT>(); else wait_vmcnt<0>();
     __builtin_amdgcn_s_barrier();
-    TRACE_MARK(1);
-#ifdef CMPC_GEMM_TRACE
-    if (threadIdx.x == 0 && blockIdx.x < 4096) g_gemm_trace[blockIdx.x * 8 + 6] = clock64();
-#endif
     uint4 a0[TM], b0[TN], a1[TM], b1[TN];
     if (ntot > 0) read_frags(0, 0, a0, b0);
     int cur = 0;
@@ -554,10 +427,6 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-    TRACE_MARK(2);
-#ifdef CMPC_GEMM_TRACE
-    if (threadIdx.x == 0 && blockIdx.x < 4096) g_gemm_trace[blockIdx.x * 8 + 7] = clock64();
-#endif
 
     constexpr int WR = TM * 16, WC = TN * 16;
     float* slab = reinterpret_cast<float*>(smem) + wid * (WR * WC);
@@ -572,13 +441,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_wave_barrier();
-    TRACE_MARK(3);
     gemm_nt_epilogue<T, WR, WC>(p, slab, lane, m0 + wm * WR, n0 + wn * WC, bz);
-    TRACE_MARK(4);
-#ifdef CMPC_GEMM_TRACE
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    TRACE_MARK(5);
-#endif
 }
 
 // ------------------------------------------------------------------------------------------
@@ -606,7 +469,6 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     constexpr int LPT = APW + BPW;
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    TRACE_MARK(0);
     const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wid / WAVES_N, wn = wid % WAVES_N;
     const int gx = (p.N + BN - 1) / BN, nwg = gridDim.x;
@@ -692,7 +554,6 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     if (ntot > 2) issue_next(2);
     if (ntot > 2) wait_vmcnt<2 * LPT>(); else if (ntot > 1) wait_vmcnt<LPT>(); else wait_vmcnt<0>();
     __builtin_amdgcn_s_barrier();
-    TRACE_MARK(1);
     uint4 alo[4], ahi[4], bb[TN];
     if (ntot > 0) { read_b(0, bb); read_a(0, 0, alo); }
     int cur = 0;
@@ -720,7 +581,6 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-    TRACE_MARK(2);
 
     constexpr int WR = 64, WC = TN * 16;                   // slab = half of the wave's rows
     float* slab = reinterpret_cast<float*>(smem) + wid * (WR * WC);
@@ -737,16 +597,10 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_wave_barrier();
-        if (half == 0) TRACE_MARK(3);
         gemm_nt_epilogue<T, WR, WC, 1>(p, slab, lane, m0 + wm * (TM * 16) + half * 64, n0 + wn * WC, bz);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // slab reads of this half are done before it is overwritten
         __builtin_amdgcn_wave_barrier();
     }
-    TRACE_MARK(4);
-#ifdef CMPC_GEMM_TRACE
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    TRACE_MARK(5);
-#endif
 }
 
 // gemm_nt v3 = v2 with producer / consumer wave specialisation.
@@ -866,149 +720,14 @@ __global__ __launch_bounds__(512) void gemm_nt_v3_kernel(const cmpc_gemm_nt_args
     gemm_nt_epilogue<T, WR, WC>(p, slab, lane, m0 + wm * WR, n0 + wn * WC, bz);
 }
 
+
 // ------------------------------------------------------------------------------------------
-// conv_v2: NHWC convolution (1x1 or 3x3, stride 1/2, dilation d, TF 'SAME') as an implicit GEMM on
-// the gemm_nt v2 pipeline: K walks (tap, Cin-slice); the weight side is a plain [Cout][taps*Cin]
+// conv_v3: NHWC convolution (1x1 or 3x3, stride 1/2, dilation d, TF 'SAME') as an implicit GEMM on
+// the gemm_nt v4 pipeline: K walks (tap, Cin-slice); the weight side is a plain [Cout][taps*Cin]
 // K-contiguous matrix, the activation side re-addresses each output pixel's row per tap and points
 // out-of-image lanes at a page of zeros (LDS-DMA cannot zero-fill).  Epilogue: + folded-BN shift,
 // + residual, ReLU  (deeplab_resnet/model.py bottlenecks; kaffe/tensorflow/network.py:105-188,260-270).
 // ------------------------------------------------------------------------------------------
-template <typename T, int BM>
-__global__ __launch_bounds__(512) void conv_v2_kernel(const cmpc_conv_args p) {
-    constexpr int BN = 128;
-    constexpr int EPC = 16 / (int)sizeof(T);
-    constexpr int BK = BKB / (int)sizeof(T);
-    constexpr int WAVES_N = 2, WAVES_M = 4;
-    constexpr int TM = BM / WAVES_M / 16, TN = BN / WAVES_N / 16;
-    constexpr int STAGE = (BM + BN) * BKB;
-    constexpr int APW = BM / 8 / 8, BPW = BN / 8 / 8, LPT = APW + BPW;
-
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wid / WAVES_N, wn = wid % WAVES_N;
-    const int Ho = (p.H + p.stride - 1) / p.stride, Wo = (p.W + p.stride - 1) / p.stride;
-    const int M = p.B * Ho * Wo, N = p.Cout;
-    const int gx = (N + BN - 1) / BN, nwg = gridDim.x;
-    const int xq = nwg >> 3, xr = nwg & 7, xcd = blockIdx.x & 7, xi = blockIdx.x >> 3;
-    const int tix = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + xi;
-    const int m0 = (tix / gx) * BM, n0 = (tix % gx) * BN;
-    const int kpt = p.Cin / BK;                       // K-tiles per tap
-    const int ntot = p.ksize * p.ksize * kpt;
-    // TF SAME: total pad = max((out-1)*stride + (k-1)*dil + 1 - in, 0), before = total / 2
-    const int padh = max((Ho - 1) * p.stride + (p.ksize - 1) * p.dil + 1 - p.H, 0) / 2;
-    const int padw = max((Wo - 1) * p.stride + (p.ksize - 1) * p.dil + 1 - p.W, 0) / 2;
-
-    f4 acc[TM][TN];
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j) acc[i][j] = f4{0.f, 0.f, 0.f, 0.f};
-
-    const int r8 = lane >> 3, slot = lane & 7;
-    const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
-    // this lane's output pixel for each of the wave's A pieces
-    int pb[APW], py[APW], px[APW], pc[APW];
-#pragma unroll
-    for (int j = 0; j < APW; ++j) {
-        const int blk = wid * APW + j, row = blk * 8 + r8;
-        const int gm = min(m0 + row, M - 1);
-        pb[j] = gm / (Ho * Wo);
-        const int rem = gm - pb[j] * (Ho * Wo);
-        py[j] = (rem / Wo) * p.stride - padh;
-        px[j] = (rem % Wo) * p.stride - padw;
-        pc[j] = (slot ^ ((row >> 1) & 7)) * EPC;
-    }
-    const T* X = reinterpret_cast<const T*>(p.X);
-    const T* Wt = reinterpret_cast<const T*>(p.Wt);
-    const T* Z = reinterpret_cast<const T*>(p.zeros);
-    auto issue = [&](int tile, int buf) {
-        const int tap = tile / kpt, k0 = (tile - tap * kpt) * BK;
-        const int dy = (tap / p.ksize) * p.dil, dx = (tap % p.ksize) * p.dil;
-        const uint32_t base = lds0 + buf * STAGE;
-#pragma unroll
-        for (int j = 0; j < APW; ++j) {
-            const int blk = wid * APW + j;
-            const int yi = py[j] + dy, xi2 = px[j] + dx;
-            const bool ok = yi >= 0 && yi < p.H && xi2 >= 0 && xi2 < p.W;
-            const T* g = ok ? X + ((long)(pb[j] * p.H + yi) * p.W + xi2) * p.ldx + k0 + pc[j] : Z + pc[j];
-            glds16(g, __builtin_amdgcn_readfirstlane(base + blk * 1024));
-        }
-#pragma unroll
-        for (int j = 0; j < BPW; ++j) {
-            const int blk = wid * BPW + j, row = blk * 8 + r8;
-            const int c = slot ^ ((row >> 1) & 7);
-            const int gn = min(n0 + row, N - 1);
-            glds16(Wt + (long)gn * p.ldw + tap * p.Cin + k0 + c * EPC, __builtin_amdgcn_readfirstlane(base + BM * BKB + blk * 1024));
-        }
-    };
-
-    if (ntot > 0) issue(0, 0);
-    if (ntot > 1) issue(1, 1);
-    const int fr = lane & 15, fq = lane >> 4;
-    int cur = 0;
-    for (int kt = 0; kt < ntot; ++kt) {
-        if (kt + 1 < ntot) wait_vmcnt<LPT>(); else wait_vmcnt<0>();
-        __builtin_amdgcn_s_barrier();
-        if (kt + 2 < ntot) issue(kt + 2, cur == 0 ? 2 : cur - 1);
-        const char* sA = smem + cur * STAGE;
-        const char* sB = sA + BM * BKB;
-#pragma unroll
-        for (int s = 0; s < 2; ++s) {
-            uint4 a[TM], b[TN];
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-                a[i] = *reinterpret_cast<const uint4*>(sA + nt_lds_off(wm * TM * 16 + i * 16 + fr, 4 * s + fq));
-#pragma unroll
-            for (int j = 0; j < TN; ++j)
-                b[j] = *reinterpret_cast<const uint4*>(sB + nt_lds_off(wn * TN * 16 + j * 16 + fr, 4 * s + fq));
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int j = 0; j < TN; ++j) acc[i][j] = Mma<T>::run(a[i], b[j], acc[i][j]);
-        }
-        cur = (cur == 2) ? 0 : cur + 1;
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-
-    constexpr int WR = TM * 16, WC = TN * 16;
-    float* slab = reinterpret_cast<float*>(smem) + wid * (WR * WC);
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int row = i * 16 + fq * 4 + r, col = j * 16 + fr;
-                slab[row * WC + (col ^ (((row >> 2) & 3) << 4))] = acc[i][j][r];
-            }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_wave_barrier();
-    constexpr int LPR = WC / 8, RPP = 64 / LPR;      // 8 columns per lane (Cout % 8 == 0)
-    T* Y = reinterpret_cast<T*>(p.Y);
-    const T* Rs = reinterpret_cast<const T*>(p.res);
-    const int c8 = (lane % LPR) * 8, gn = n0 + wn * WC + c8, rl = lane / LPR;
-    if (gn >= N) return;
-    float bv[8];
-    ld8<float>(p.bias + gn, bv);                     // column terms once, not once per pass
-    const bool relu = p.relu != 0;
-#pragma unroll
-    for (int pass = 0; pass < WR / RPP; ++pass) {    // fully unrolled: the residual loads of all passes go out together
-        const int row = pass * RPP + rl;
-        const int gm = m0 + wm * WR + row;
-        if (gm >= M) continue;
-        const float4 va = *reinterpret_cast<const float4*>(slab + row * WC + slab_col(row, c8, WC));
-        const float4 vb = *reinterpret_cast<const float4*>(slab + row * WC + slab_col(row, c8 + 4, WC));
-        float v[8] = {va.x, va.y, va.z, va.w, vb.x, vb.y, vb.z, vb.w};
-        const long off = (long)gm * p.ldy + gn;
-        float rv[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        if (Rs) ld8<T>(Rs + off, rv);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) { const float x = v[e] + bv[e] + rv[e]; v[e] = relu ? fmaxf(x, 0.f) : x; }
-        st8<T>(Y + off, v);
-    }
-}
-
 template <typename T, int BM>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv_v3_kernel(const cmpc_conv_args p) {
     constexpr int BN = 128;
@@ -1188,6 +907,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 // ------------------------------------------------------------------------------------------
 template <typename T> struct TnCfg;
 template <> struct TnCfg<bf16_t> { static constexpr int BR = 64; };
+template <> struct TnCfg<f16_t> { static constexpr int BR = 64; };
 template <> struct TnCfg<float> { static constexpr int BR = 32; };
 
 __device__ __forceinline__ int tn_swz(int r, int byte, int rowb) {
@@ -1205,7 +925,6 @@ __device__ __forceinline__ void gemm_tn_body(const cmpc_gemm_tn_args& p, const i
     constexpr int TILE = BR * ROWB;
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    TRACE_MARK(0);
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wm = wid >> 1, wn = wid & 1;
     const int ntn = (p.Nv + 127) / 128;
@@ -1252,7 +971,6 @@ __device__ __forceinline__ void gemm_tn_body(const cmpc_gemm_tn_args& p, const i
 
     if (nt > 0) { gload(0); lstore(0); }
     __syncthreads();
-    TRACE_MARK(1);
     const int fr = lane & 15, fq = lane >> 4;
     for (int t = 0; t < nt; ++t) {
         const int cur = t & 1;
@@ -1292,8 +1010,7 @@ __device__ __forceinline__ void gemm_tn_body(const cmpc_gemm_tn_args& p, const i
                 for (int i = 0; i < 4; ++i)
 #pragma unroll
                     for (int j = 0; j < 4; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
-                            __builtin_bit_cast(bf8v, a[i]), __builtin_bit_cast(bf8v, b[j]), acc[i][j], 0, 0, 0);
+                        acc[i][j] = Mma<T>::run(a[i], b[j], acc[i][j]);
             }
         } else {
 #pragma unroll 2
@@ -1317,8 +1034,6 @@ __device__ __forceinline__ void gemm_tn_body(const cmpc_gemm_tn_args& p, const i
         __syncthreads();
     }
     if (nt == 0) return;
-    TRACE_MARK(2);
-    TRACE_MARK(3);
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -1329,11 +1044,6 @@ __device__ __forceinline__ void gemm_tn_body(const cmpc_gemm_tn_args& p, const i
                 const int n = n0 + wn * 64 + j * 16 + fr;
                 if (k < p.Kv && n < p.Nv) atomicAdd(out + (long)k * p.ldo + n, acc[i][j][r] * p.alpha);
             }
-    TRACE_MARK(4);
-#ifdef CMPC_GEMM_TRACE
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    TRACE_MARK(5);
-#endif
 }
 
 
@@ -1375,253 +1085,12 @@ __global__ __launch_bounds__(256) void gemm_tn_grouped_kernel(const TnGroupDesc*
         const int tiles = d.tiles, rs = d.a.rsplit;
         const int bx = local % tiles, rest = local / tiles;
         if (d.a.dtype == DT_F32) gemm_tn_body<float>(d.a, bx, rest % rs, rest / rs);
-        else gemm_tn_body<bf16_t>(d.a, bx, rest % rs, rest / rs);
+        else if (d.a.dtype == DT_BF16) gemm_tn_body<bf16_t>(d.a, bx, rest % rs, rest / rs);
+        else gemm_tn_body<f16_t>(d.a, bx, rest % rs, rest / rs);
         __syncthreads();                              // the next item reuses the LDS stages
     }
 }
 
-// ------------------------------------------------------------------------------------------
-// gemm_tn v2 (bf16): same product as gemm_tn_kernel, but the [64 rows][128 cols] operand slabs are
-// filled by LDS-DMA into THREE stages with counted vmcnt (tile t+1 in flight while tile t is
-// multiplied), 8 waves (2 x 4 over the 128 x 128 output, 64 x 32 per wave).  The 32-byte-segment XOR
-// of the LDS image is applied to the per-lane SOURCE column block (linear LDS destination).
-// ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(512) void gemm_tn_v2_kernel(const cmpc_gemm_tn_args p) {
-    constexpr int BR = 64, ROWB = 256, TILE = BR * ROWB;      // one operand slab = 16 KiB
-    constexpr int STAGE = 2 * TILE;
-    constexpr int LPT = 4;                                      // 32 pieces (16 A + 16 D) / 8 waves
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wid >> 2, wn = wid & 3;                      // 2 x 4 waves: 64 (k) x 32 (n) per wave
-    const int ntn = (p.Nv + 127) / 128;
-    const int k0 = (blockIdx.x / ntn) * 128, n0 = (blockIdx.x % ntn) * 128;
-    const int b1 = blockIdx.z % p.nb, b2 = blockIdx.z / p.nb;
-    const bf16_t* A = reinterpret_cast<const bf16_t*>(p.A) + p.a_off[b1] + (long)b2 * p.a_bs;
-    const bf16_t* D = reinterpret_cast<const bf16_t*>(p.D) + p.d_off[b1] + (long)b2 * p.d_bs;
-    float* out = p.out + p.o_off[b1] + (long)b2 * p.o_bs;
-    const int per = (p.R + p.rsplit - 1) / p.rsplit;
-    const int rbeg = blockIdx.y * per;
-    const int rend = min(p.R, rbeg + per);
-    const int nt = (rend > rbeg) ? (rend - rbeg + BR - 1) / BR : 0;
-    if (nt == 0) return;
-
-    f4 acc[4][2];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j) acc[i][j] = f4{0.f, 0.f, 0.f, 0.f};
-
-    const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
-    const bf16_t* Z = reinterpret_cast<const bf16_t*>(p.zeros);
-    // a piece = 4 slab rows x 256 B; lane -> (row = lane>>4, 16-B chunk = lane&15).  LDS position of
-    // (row, chunk): row*256 + ((chunk>>1) ^ f(row))*32 + (chunk&1)*16  => the lane that lands on LDS chunk
-    // position c must fetch source chunk  ((c>>1) ^ f(row))*2 + (c&1).
-    auto issue = [&](int t, int buf) {
-        const int r0 = rbeg + t * BR;
-#pragma unroll
-        for (int j = 0; j < LPT; ++j) {
-            const int piece = wid * LPT + j;                    // 0..31 : 0..15 -> A slab, 16..31 -> D slab
-            const bool isA = piece < 16;
-            const int pr = (piece & 15) * 4 + (lane >> 4);       // slab row
-            const int cpos = lane & 15;
-            const int f = (pr & 3) | (((pr >> 3) & 1) << 2);
-            const int csrc = ((((cpos >> 1) ^ f) & 7) << 1) | (cpos & 1);
-            const int gr = r0 + pr;
-            const int col = (isA ? k0 : n0) + csrc * 8;
-            const bool ok = gr < rend && col < (isA ? p.Ka : p.Nd);
-            const bf16_t* g = ok ? (isA ? A + (long)gr * p.lda + col : D + (long)gr * p.ldd + col) : Z;
-            glds16(g, __builtin_amdgcn_readfirstlane(lds0 + buf * STAGE + (isA ? 0 : TILE) + (piece & 15) * 1024));
-        }
-    };
-
-    issue(0, 0);
-    if (nt > 1) issue(1, 1);
-    const int fr = lane & 15, fq = lane >> 4;
-    const int q4 = fr >> 2, p4 = fr & 3;
-    int cur = 0;
-    for (int t = 0; t < nt; ++t) {
-        if (t + 1 < nt) wait_vmcnt<LPT>(); else wait_vmcnt<0>();
-        __builtin_amdgcn_s_barrier();
-        if (t + 2 < nt) issue(t + 2, cur == 0 ? 2 : cur - 1);
-        const char* sA = smem + cur * STAGE;
-        const char* sD = sA + TILE;
-#pragma unroll
-        for (int rs = 0; rs < BR / 32; ++rs) {
-            uint4 a[4], b[2];
-            const int r_lo = rs * 32 + 8 * fq + q4;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int col = wm * 64 + i * 16 + 4 * p4;
-                const s4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s4*)(sA + tn_swz(r_lo, col * 2, ROWB)));
-                const s4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s4*)(sA + tn_swz(r_lo + 4, col * 2, ROWB)));
-                const s8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-                a[i] = __builtin_bit_cast(uint4, v);
-            }
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const int col = wn * 32 + j * 16 + 4 * p4;
-                const s4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s4*)(sD + tn_swz(r_lo, col * 2, ROWB)));
-                const s4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s4*)(sD + tn_swz(r_lo + 4, col * 2, ROWB)));
-                const s8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-                b[j] = __builtin_bit_cast(uint4, v);
-            }
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf8v, a[i]), __builtin_bit_cast(bf8v, b[j]), acc[i][j], 0, 0, 0);
-        }
-        cur = (cur == 2) ? 0 : cur + 1;
-    }
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int k = k0 + wm * 64 + i * 16 + fq * 4 + r;
-                const int n = n0 + wn * 32 + j * 16 + fr;
-                if (k < p.Kv && n < p.Nv) atomicAdd(out + (long)k * p.ldo + n, acc[i][j][r] * p.alpha);
-            }
-}
-
-// ------------------------------------------------------------------------------------------
-// gemm_tn, 256 (k) x 256 (n) output tile -- the weight-gradient counterpart of gemm_nt_v5: 8 waves (2 x 4, 128 x 64 per
-// wave), 32 reduction rows per step, four LDS stages of 32 KiB filled by LDS-DMA (three steps of loads in flight), the
-// step's 32 MFMAs per wave in two halves with the next half's transposing LDS reads issued in front of each.  Twice the
-// output area per operand byte of the 128 x 128 kernel.  Used by the grouped launch for bf16 products with K, N >= 256.
-// ------------------------------------------------------------------------------------------
-__device__ __forceinline__ void gemm_tn_big_body(const cmpc_gemm_tn_args& p, const int bx, const int by, const int bz, char* smem) {
-    constexpr int BR = 32, ROWB = 512, TILE = BR * ROWB, STAGE = 2 * TILE;
-    constexpr int LPT = 4;                                      // 32 one-KiB pieces (16 A + 16 D) / 8 waves
-    const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wid >> 2, wn = wid & 3;
-    const int ntn = (p.Nv + 255) / 256;
-    const int k0 = (bx / ntn) * 256, n0 = (bx % ntn) * 256;
-    const int b1 = bz % p.nb, b2 = bz / p.nb;
-    const bf16_t* A = reinterpret_cast<const bf16_t*>(p.A) + p.a_off[b1] + (long)b2 * p.a_bs;
-    const bf16_t* D = reinterpret_cast<const bf16_t*>(p.D) + p.d_off[b1] + (long)b2 * p.d_bs;
-    float* out = p.out + p.o_off[b1] + (long)b2 * p.o_bs;
-    const int per = (p.R + p.rsplit - 1) / p.rsplit;
-    const int rbeg = by * per;
-    const int rend = min(p.R, rbeg + per);
-    const int nt = (rend > rbeg) ? (rend - rbeg + BR - 1) / BR : 0;
-    if (nt == 0) return;
-
-    f4 acc[8][4];
-#pragma unroll
-    for (int i = 0; i < 8; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = f4{0.f, 0.f, 0.f, 0.f};
-
-    const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
-    const bf16_t* Z = reinterpret_cast<const bf16_t*>(p.zeros);
-    // a piece = 2 slab rows x 512 B; lane -> (row = lane>>5, 16-B chunk position = lane&31).  LDS position of (row, chunk c):
-    // row*512 + ((c>>1) ^ f(row))*32 + (c&1)*16, so the lane that lands on position c fetches source chunk ((c>>1)^f)*2 + (c&1)
-    // (f < 8 flips the low three bits of the 32-B segment index: the row's two 256-B halves are permuted separately).
-    int pr[LPT], csrc[LPT];
-#pragma unroll
-    for (int j = 0; j < LPT; ++j) {
-        const int piece = wid * LPT + j;
-        pr[j] = (piece & 15) * 2 + (lane >> 5);
-        const int cpos = lane & 31, f = (pr[j] & 3) | (((pr[j] >> 3) & 1) << 2);
-        csrc[j] = (((cpos >> 1) ^ f) << 1) | (cpos & 1);
-    }
-    auto issue = [&](int t, int buf) {
-        const int r0 = rbeg + t * BR;
-#pragma unroll
-        for (int j = 0; j < LPT; ++j) {
-            const int piece = wid * LPT + j;                    // 0..15 -> A slab, 16..31 -> D slab (wave-uniform)
-            const bool isA = piece < 16;
-            const int gr = r0 + pr[j];
-            const int col = (isA ? k0 : n0) + csrc[j] * 8;
-            const bool ok = gr < rend && col < (isA ? p.Ka : p.Nd);
-            const bf16_t* g = ok ? (isA ? A + (long)gr * p.lda + col : D + (long)gr * p.ldd + col) : Z;
-            glds16(g, __builtin_amdgcn_readfirstlane(lds0 + buf * STAGE + (isA ? 0 : TILE) + (piece & 15) * 1024));
-        }
-    };
-    const int fr = lane & 15, fq = lane >> 4;
-    const int q4 = fr >> 2, p4 = fr & 3;
-    const int r_lo = 8 * fq + q4;
-    auto trfrag = [&](const char* slab, int col) -> uint4 {
-        const s4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s4*)(slab + tn_swz(r_lo, col * 2, ROWB)));
-        const s4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s4*)(slab + tn_swz(r_lo + 4, col * 2, ROWB)));
-        const s8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-        return __builtin_bit_cast(uint4, v);
-    };
-    auto read_a = [&](int buf, int half, uint4 (&a)[4]) {
-        const char* sA = smem + buf * STAGE;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) a[i] = trfrag(sA, wm * 128 + (half * 4 + i) * 16 + 4 * p4);
-    };
-    auto read_d = [&](int buf, uint4 (&d)[4]) {
-        const char* sD = smem + buf * STAGE + TILE;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) d[j] = trfrag(sD, wn * 64 + j * 16 + 4 * p4);
-    };
-    auto mma_half = [&](int half, const uint4 (&a)[4], const uint4 (&d)[4]) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-                acc[half * 4 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf8v, a[i]), __builtin_bit_cast(bf8v, d[j]), acc[half * 4 + i][j], 0, 0, 0);
-    };
-
-    issue(0, 0);
-    if (nt > 1) issue(1, 1);
-    if (nt > 2) issue(2, 2);
-    if (nt > 2) wait_vmcnt<2 * LPT>(); else if (nt > 1) wait_vmcnt<LPT>(); else wait_vmcnt<0>();
-    __builtin_amdgcn_s_barrier();
-    uint4 alo[4], ahi[4], dd[4];
-    read_d(0, dd); read_a(0, 0, alo);
-    int cur = 0;
-    for (int t = 0; t + 1 < nt; ++t) {
-        if (t + 3 < nt) issue(t + 3, (cur + 3) & 3);             // buffer of step t-1: free since the previous barrier
-        read_a(cur, 1, ahi);
-        __builtin_amdgcn_sched_barrier(0);
-        mma_half(0, alo, dd);
-        __builtin_amdgcn_sched_barrier(0);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // every read of step t is in registers before the barrier
-        if (t + 3 < nt) wait_vmcnt<2 * LPT>(); else if (t + 2 < nt) wait_vmcnt<LPT>(); else wait_vmcnt<0>();
-        __builtin_amdgcn_s_barrier();
-        const int nxt = (cur + 1) & 3;
-        read_a(nxt, 0, alo);
-        __builtin_amdgcn_sched_barrier(0);
-        mma_half(1, ahi, dd);
-        __builtin_amdgcn_sched_barrier(0);
-        read_d(nxt, dd);
-        cur = nxt;
-    }
-    read_a(cur, 1, ahi);
-    mma_half(0, alo, dd);
-    mma_half(1, ahi, dd);
-#pragma unroll
-    for (int i = 0; i < 8; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int k = k0 + wm * 128 + i * 16 + fq * 4 + r;
-                const int n = n0 + wn * 64 + j * 16 + fr;
-                if (k < p.Kv && n < p.Nv) atomicAdd(out + (long)k * p.ldo + n, acc[i][j][r] * p.alpha);
-            }
-    // all waves are past their LDS reads before the next item's DMA overwrites the stages
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-}
-
-__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void gemm_tn_grouped_big_kernel(const TnGroupDesc* __restrict__ table, int ndesc, int total) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    for (int w = blockIdx.x; w < total; w += gridDim.x) {
-        int lo = 0, hi = ndesc;
-        while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (table[mid].item_begin <= w) lo = mid; else hi = mid; }
-        const TnGroupDesc& d = table[lo];
-        const int local = w - d.item_begin;
-        const int tiles = d.tiles, rs = d.a.rsplit;
-        const int bx = local % tiles, rest = local / tiles;
-        gemm_tn_big_body(d.a, bx, rest % rs, rest / rs, smem);
-    }
-}
 
 // ------------------------------------------------------------------------------------------
 // gemm_nt for M <= 16 rows (the language side: [B, .] vectors against whole weight matrices).
@@ -1695,10 +1164,69 @@ __global__ __launch_bounds__(256) void gemm_nt_skinny_f32_kernel(const cmpc_gemm
 
 }  // namespace
 
+// 16-bit operands (T = bf16_t or f16_t): the LDS-DMA MFMA pipelines.  Which pipeline wins where was measured with
+// scripts/gemm_ksweep.py: 256 x 256 tiles (v5) for N >= 1024 (1.1-1.25x), fragment double buffering (v4) for short and
+// medium K, producer / consumer wave specialisation (v3) for long K; 256-row tiles as soon as they fill 3/4 of the CUs.
+template <typename T>
+static int launch_nt16(const cmpc_gemm_nt_args* a, hipStream_t st) {
+    const int gn = (a->N + 127) / 128;
+    int ktot = 0;
+    bool off32 = true;          // every operand addressable with v5's 32-bit byte offsets
+    for (int s = 0; s < a->nseg; ++s) {
+        ktot += a->K[s];
+        off32 = off32 && ((long)a->M * a->lda[s] * 2 < (1L << 32)) && ((long)a->N * a->ldb[s] * 2 < (1L << 32));
+    }
+    if (a->N >= 1024 && a->M >= 2048 && off32) {
+        static const bool attr = ((void)hipFuncSetAttribute((const void*)gemm_nt_v5_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 512 * 64), true);
+        (void)attr;
+        dim3 grid((unsigned)(((a->M + 255) / 256) * ((a->N + 255) / 256)), 1, a->batch);
+        hipLaunchKernelGGL((gemm_nt_v5_kernel<T>), grid, dim3(512), 4 * 512 * 64, st, *a);
+        return cmpc_check_launch("gemm_nt(v5)");
+    }
+    const bool big = (long)((a->M + 255) / 256) * gn * a->batch >= 192;       // one round of 256-row tiles beats two of 128-row ones
+    const bool v4 = ktot < 2048 || (ktot < 4096 && a->N >= 1024);
+    if (big) {
+        constexpr int LDS = 3 * (256 + 128) * BKB;
+        static const bool attr = ((void)hipFuncSetAttribute((const void*)gemm_nt_v4_kernel<T, 256>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS),
+                                  (void)hipFuncSetAttribute((const void*)gemm_nt_v3_kernel<T, 256>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS), true);
+        (void)attr;
+        dim3 grid(((a->M + 255) / 256) * gn, 1, a->batch);
+        if (v4) hipLaunchKernelGGL((gemm_nt_v4_kernel<T, 256>), grid, dim3(512), LDS, st, *a);
+        else hipLaunchKernelGGL((gemm_nt_v3_kernel<T, 256>), grid, dim3(512), LDS, st, *a);
+    } else {
+        constexpr int LDS = 3 * (128 + 128) * BKB;
+        static const bool attr = ((void)hipFuncSetAttribute((const void*)gemm_nt_v4_kernel<T, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS),
+                                  (void)hipFuncSetAttribute((const void*)gemm_nt_v3_kernel<T, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS), true);
+        (void)attr;
+        dim3 grid(((a->M + 127) / 128) * gn, 1, a->batch);
+        if (v4) hipLaunchKernelGGL((gemm_nt_v4_kernel<T, 128>), grid, dim3(512), LDS, st, *a);
+        else hipLaunchKernelGGL((gemm_nt_v3_kernel<T, 128>), grid, dim3(512), LDS, st, *a);
+    }
+    return cmpc_check_launch("gemm_nt(v4/v3)");
+}
+
+template <typename T>
+static int launch_nt_small(const cmpc_gemm_nt_args* a, hipStream_t st) {
+    const int bn = (a->N % 128 == 0 || a->N > 64) ? 128 : 64;
+    const long tiles128 = (long)((a->N + bn - 1) / bn) * ((a->M + 127) / 128) * a->batch;
+    if (sizeof(T) == 4 && tiles128 < 192) {
+        // fp32 MFMA runs at 1/16 of the 16-bit rate: small products need many small tiles to use the chip
+        dim3 grid(((a->N + 63) / 64) * ((a->M + 63) / 64), 1, a->batch);
+        hipLaunchKernelGGL((gemm_nt_kernel<T, 64, 64>), grid, dim3(256), 2 * (64 + 64) * BKB, st, *a);
+        return cmpc_check_launch("gemm_nt(64x64)");
+    }
+    dim3 grid(((a->N + bn - 1) / bn) * ((a->M + 127) / 128), 1, a->batch);
+    const size_t lds = 2 * (128 + bn) * BKB;
+    if (bn == 128) hipLaunchKernelGGL((gemm_nt_kernel<T, 128, 128>), grid, dim3(256), lds, st, *a);
+    else hipLaunchKernelGGL((gemm_nt_kernel<T, 128, 64>), grid, dim3(256), lds, st, *a);
+    return cmpc_check_launch("gemm_nt");
+}
+
 extern "C" int cmpc_gemm_nt(const cmpc_gemm_nt_args* a, void* stream) {
     if (!a || a->nseg < 1 || a->nseg > 3 || a->M <= 0 || a->N <= 0 || a->batch <= 0) {
         cmpc_set_error("gemm_nt: bad args"); return CMPC_EINVAL;
     }
+    if (a->dtype != DT_F32 && a->dtype != DT_BF16 && a->dtype != DT_F16) { cmpc_set_error("gemm_nt: bad dtype"); return CMPC_EINVAL; }
     const int esz = a->dtype == DT_F32 ? 4 : 2;
     const int bk = BKB / esz;
     for (int s = 0; s < a->nseg; ++s) {
@@ -1709,78 +1237,18 @@ extern "C" int cmpc_gemm_nt(const cmpc_gemm_nt_args* a, void* stream) {
     }
     if (a->N % 4 || a->ldc % 4 || !a->C) { cmpc_set_error("gemm_nt: N/ldc must be multiples of 4"); return CMPC_EINVAL; }
     hipStream_t st = (hipStream_t)stream;
-    if (a->dtype == DT_F32 && a->M <= 16 && a->batch == 1) {
-        dim3 grid((a->N + 3) / 4);
-        if (a->M <= 8) hipLaunchKernelGGL((gemm_nt_skinny_f32_kernel<8>), grid, dim3(256), 0, st, *a);
-        else hipLaunchKernelGGL((gemm_nt_skinny_f32_kernel<16>), grid, dim3(256), 0, st, *a);
-        return cmpc_check_launch("gemm_nt(skinny)");
-    }
-    if (a->dtype == DT_BF16 && a->N >= 128 && a->M >= 512 && !getenv("CMPC_GEMM_V1")) {
-        const int gn = (a->N + 127) / 128;
-        int ktot = 0;
-        for (int s2 = 0; s2 < a->nseg; ++s2) ktot += a->K[s2];      // long K: producer/consumer waves (v3) win; short K: v2
-        const bool big = (long)((a->M + 255) / 256) * gn * a->batch >= 192 || getenv("CMPC_GEMM_BM256");   // one round of 256-row tiles beats two of 128-row ones
-        // v4 (fragment double buffering, hoisted row pointers) wins for short and medium K, v3 (producer /
-        // consumer waves) for long K (scripts/gemm_ksweep.py); v2 is kept as the plain reference structure.
-        const char* e4 = getenv("CMPC_GEMM_V4");
-        const bool v4 = e4 ? atoi(e4) != 0 : (!getenv("CMPC_GEMM_V2") && !getenv("CMPC_GEMM_V3") && (ktot < 2048 || (ktot < 4096 && a->N >= 1024)));
-        {
-            bool k32 = true;        // and every operand addressable with the kernel's 32-bit byte offsets
-            for (int s2 = 0; s2 < a->nseg; ++s2)
-                k32 = k32 && (a->K[s2] % 32 == 0) && ((long)a->M * a->lda[s2] * esz < (1L << 32)) && ((long)a->N * a->ldb[s2] * esz < (1L << 32));
-            const char* e5 = getenv("CMPC_GEMM_V5");
-            const bool use5 = e5 ? atoi(e5) != 0 : (a->N >= 1024 && a->M >= 2048);   // 256 x 256 tiles: 1.1-1.25x for N >= 1024 (scripts/gemm_ksweep.py), slower below (too few workgroups)
-            if (use5 && k32) {
-                static bool attr5 = false;
-                if (!attr5) { (void)hipFuncSetAttribute((const void*)gemm_nt_v5_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 512 * 64); attr5 = true; }
-                dim3 grid((unsigned)(((a->M + 255) / 256) * ((a->N + 255) / 256)), 1, a->batch);
-                hipLaunchKernelGGL((gemm_nt_v5_kernel<bf16_t>), grid, dim3(512), 4 * 512 * 64, st, *a);
-                return cmpc_check_launch("gemm_nt(v5)");
-            }
-        }   // register-epilogue variant: not faster end to end (8-B stores), kept for study
-        if (big) {
-            dim3 grid(((a->M + 255) / 256) * gn, 1, a->batch);
-            static bool attr256 = false;
-            if (!attr256) { (void)hipFuncSetAttribute((const void*)gemm_nt_v2_kernel<bf16_t, 256>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * (256 + 128) * BKB); attr256 = true; }
-            static bool attr256c = false;
-            if (!attr256c) { (void)hipFuncSetAttribute((const void*)gemm_nt_v3_kernel<bf16_t, 256>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * (256 + 128) * BKB); attr256c = true; }
-            static bool attr256d = false;
-            if (!attr256d) { (void)hipFuncSetAttribute((const void*)gemm_nt_v4_kernel<bf16_t, 256>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * (256 + 128) * BKB); attr256d = true; }
-            if (v4) hipLaunchKernelGGL((gemm_nt_v4_kernel<bf16_t, 256>), grid, dim3(512), 3 * (256 + 128) * BKB, st, *a);
-            else if (ktot < 2048 || getenv("CMPC_GEMM_V2")) hipLaunchKernelGGL((gemm_nt_v2_kernel<bf16_t, 256>), grid, dim3(512), 3 * (256 + 128) * BKB, st, *a);
-            else hipLaunchKernelGGL((gemm_nt_v3_kernel<bf16_t, 256>), grid, dim3(512), 3 * (256 + 128) * BKB, st, *a);
-        } else {
-            dim3 grid(((a->M + 127) / 128) * gn, 1, a->batch);
-            static bool attr128 = false;
-            if (!attr128) { (void)hipFuncSetAttribute((const void*)gemm_nt_v2_kernel<bf16_t, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * (128 + 128) * BKB); attr128 = true; }
-            static bool attr128c = false;
-            if (!attr128c) { (void)hipFuncSetAttribute((const void*)gemm_nt_v3_kernel<bf16_t, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * (128 + 128) * BKB); attr128c = true; }
-            static bool attr128d = false;
-            if (!attr128d) { (void)hipFuncSetAttribute((const void*)gemm_nt_v4_kernel<bf16_t, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * (128 + 128) * BKB); attr128d = true; }
-            if (v4) hipLaunchKernelGGL((gemm_nt_v4_kernel<bf16_t, 128>), grid, dim3(512), 3 * (128 + 128) * BKB, st, *a);
-            else if (ktot < 2048 || getenv("CMPC_GEMM_V2")) hipLaunchKernelGGL((gemm_nt_v2_kernel<bf16_t, 128>), grid, dim3(512), 3 * (128 + 128) * BKB, st, *a);
-            else hipLaunchKernelGGL((gemm_nt_v3_kernel<bf16_t, 128>), grid, dim3(512), 3 * (128 + 128) * BKB, st, *a);
-        }
-        return cmpc_check_launch("gemm_nt(v2)");
-    }
-    const int bn = (a->N % 128 == 0 || a->N > 64) ? 128 : 64;
-    const long tiles128 = (long)((a->N + bn - 1) / bn) * ((a->M + 127) / 128) * a->batch;
-    if (a->dtype == DT_F32 && tiles128 < 192) {
-        // fp32 MFMA runs at 1/16 of the bf16 rate: small products need many small tiles to use the chip
-        dim3 grid(((a->N + 63) / 64) * ((a->M + 63) / 64), 1, a->batch);
-        hipLaunchKernelGGL((gemm_nt_kernel<float, 64, 64>), grid, dim3(256), 2 * (64 + 64) * BKB, st, *a);
-        return cmpc_check_launch("gemm_nt(64x64)");
-    }
-    dim3 grid(((a->N + bn - 1) / bn) * ((a->M + 127) / 128), 1, a->batch);
-    const size_t lds = 2 * (128 + bn) * BKB;
     if (a->dtype == DT_F32) {
-        if (bn == 128) hipLaunchKernelGGL((gemm_nt_kernel<float, 128, 128>), grid, dim3(256), lds, st, *a);
-        else hipLaunchKernelGGL((gemm_nt_kernel<float, 128, 64>), grid, dim3(256), lds, st, *a);
-    } else if (a->dtype == DT_BF16) {
-        if (bn == 128) hipLaunchKernelGGL((gemm_nt_kernel<bf16_t, 128, 128>), grid, dim3(256), lds, st, *a);
-        else hipLaunchKernelGGL((gemm_nt_kernel<bf16_t, 128, 64>), grid, dim3(256), lds, st, *a);
-    } else { cmpc_set_error("gemm_nt: bad dtype"); return CMPC_EINVAL; }
-    return cmpc_check_launch("gemm_nt");
+        if (a->M <= 16 && a->batch == 1) {
+            dim3 grid((a->N + 3) / 4);
+            if (a->M <= 8) hipLaunchKernelGGL((gemm_nt_skinny_f32_kernel<8>), grid, dim3(256), 0, st, *a);
+            else hipLaunchKernelGGL((gemm_nt_skinny_f32_kernel<16>), grid, dim3(256), 0, st, *a);
+            return cmpc_check_launch("gemm_nt(skinny)");
+        }
+        return launch_nt_small<float>(a, st);
+    }
+    const bool pipe = a->N >= 128 && a->M >= 512;
+    if (a->dtype == DT_BF16) return pipe ? launch_nt16<bf16_t>(a, st) : launch_nt_small<bf16_t>(a, st);
+    return pipe ? launch_nt16<f16_t>(a, st) : launch_nt_small<f16_t>(a, st);
 }
 
 
@@ -1789,25 +1257,16 @@ static int launch_conv(const cmpc_conv_args* a, hipStream_t st) {
     const int Ho = (a->H + a->stride - 1) / a->stride, Wo = (a->W + a->stride - 1) / a->stride;
     const long M = (long)a->B * Ho * Wo;
     const int gn = (a->Cout + 127) / 128;
-    const bool big = ((M + 255) / 256) * gn >= 192;       // as in cmpc_gemm_nt
-    if (big) {
-        static bool attr = false;
-        if (!attr) { (void)hipFuncSetAttribute((const void*)conv_v2_kernel<T, 256>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * (256 + 128) * BKB); attr = true; }
-        if (!getenv("CMPC_CONV_V2")) {
-            static bool attr3 = false;
-            if (!attr3) { (void)hipFuncSetAttribute((const void*)conv_v3_kernel<T, 256>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * (256 + 128) * BKB); attr3 = true; }
-            hipLaunchKernelGGL((conv_v3_kernel<T, 256>), dim3((unsigned)(((M + 255) / 256) * gn)), dim3(512), 3 * (256 + 128) * BKB, st, *a);
-        } else
-        hipLaunchKernelGGL((conv_v2_kernel<T, 256>), dim3((unsigned)(((M + 255) / 256) * gn)), dim3(512), 3 * (256 + 128) * BKB, st, *a);
+    if (((M + 255) / 256) * gn >= 192) {       // as in cmpc_gemm_nt
+        constexpr int LDS = 3 * (256 + 128) * BKB;
+        static const bool attr = ((void)hipFuncSetAttribute((const void*)conv_v3_kernel<T, 256>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS), true);
+        (void)attr;
+        hipLaunchKernelGGL((conv_v3_kernel<T, 256>), dim3((unsigned)(((M + 255) / 256) * gn)), dim3(512), LDS, st, *a);
     } else {
-        static bool attr = false;
-        if (!attr) { (void)hipFuncSetAttribute((const void*)conv_v2_kernel<T, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * (128 + 128) * BKB); attr = true; }
-        if (!getenv("CMPC_CONV_V2")) {
-            static bool attr3 = false;
-            if (!attr3) { (void)hipFuncSetAttribute((const void*)conv_v3_kernel<T, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * (128 + 128) * BKB); attr3 = true; }
-            hipLaunchKernelGGL((conv_v3_kernel<T, 128>), dim3((unsigned)(((M + 127) / 128) * gn)), dim3(512), 3 * (128 + 128) * BKB, st, *a);
-        } else
-        hipLaunchKernelGGL((conv_v2_kernel<T, 128>), dim3((unsigned)(((M + 127) / 128) * gn)), dim3(512), 3 * (128 + 128) * BKB, st, *a);
+        constexpr int LDS = 3 * (128 + 128) * BKB;
+        static const bool attr = ((void)hipFuncSetAttribute((const void*)conv_v3_kernel<T, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS), true);
+        (void)attr;
+        hipLaunchKernelGGL((conv_v3_kernel<T, 128>), dim3((unsigned)(((M + 127) / 128) * gn)), dim3(512), LDS, st, *a);
     }
     return cmpc_check_launch("conv_nhwc");
 }
@@ -1821,6 +1280,7 @@ extern "C" int cmpc_conv_nhwc(const cmpc_conv_args* a, void* stream) {
     }
     if (a->dtype == DT_F32) return launch_conv<float>(a, (hipStream_t)stream);
     if (a->dtype == DT_BF16) return launch_conv<bf16_t>(a, (hipStream_t)stream);
+    if (a->dtype == DT_F16) return launch_conv<f16_t>(a, (hipStream_t)stream);
     cmpc_set_error("conv_nhwc: bad dtype"); return CMPC_EINVAL;
 }
 
@@ -1829,6 +1289,7 @@ static int tn_validate(const cmpc_gemm_tn_args* a) {
     if (!a || a->R < 0 || a->Kv <= 0 || a->Nv <= 0 || a->nb < 1 || a->nb > 8 || a->nb2 < 1) {
         cmpc_set_error("gemm_tn: bad args"); return CMPC_EINVAL;
     }
+    if (a->dtype != DT_F32 && a->dtype != DT_BF16 && a->dtype != DT_F16) { cmpc_set_error("gemm_tn: bad dtype"); return CMPC_EINVAL; }
     if (a->R == 0) return CMPC_OK;
     if (!a->A || !a->D || !a->out) { cmpc_set_error("gemm_tn: null operand"); return CMPC_EINVAL; }
     const int esz = a->dtype == DT_F32 ? 4 : 2;
@@ -1838,102 +1299,66 @@ static int tn_validate(const cmpc_gemm_tn_args* a) {
     for (int i = 0; i < a->nb; ++i)
         if ((a->a_off[i] * esz) % 16 || (a->d_off[i] * esz) % 16) { cmpc_set_error("gemm_tn: offsets must be 16-B aligned"); return CMPC_EINVAL; }
     if ((a->a_bs * esz) % 16 || (a->d_bs * esz) % 16) { cmpc_set_error("gemm_tn: batch strides must be 16-B aligned"); return CMPC_EINVAL; }
-    if (a->dtype != DT_F32 && a->dtype != DT_BF16) { cmpc_set_error("gemm_tn: bad dtype"); return CMPC_EINVAL; }
     return CMPC_OK;
 }
 
 extern "C" int cmpc_gemm_tn_grouped(const cmpc_gemm_tn_args* args, int n, void* stream) {
     if (n < 0 || (n > 0 && !args)) { cmpc_set_error("gemm_tn_grouped: bad args"); return CMPC_EINVAL; }
     hipStream_t st = (hipStream_t)stream;
-    // two lists: bf16 products with a large output (256 x 256 tiles, gemm_tn_grouped_big_kernel) and the rest
-    std::vector<int> order[2];
-    long tiles_tot[2] = {0, 0};
-    // CMPC_TN_BIG=1: 256 x 256 tiles for the large bf16 products.  Off by default: measured 2.5 ms against 2.2 ms for the
-    // whole flush with 128 x 128 tiles (400-step items leave a long tail on 256 slots); kept for the next round.
-    const bool use_big = getenv("CMPC_TN_BIG") && atoi(getenv("CMPC_TN_BIG")) != 0;
+    std::vector<int> order;
+    long tiles_tot = 0;
     for (int i = 0; i < n; ++i) {
         const int rc = tn_validate(&args[i]);
         if (rc != CMPC_OK) return rc;
         if (args[i].R == 0) continue;
-        const int big = (use_big && args[i].dtype == DT_BF16 && args[i].zeros && args[i].Kv >= 256 && args[i].Nv >= 256 && args[i].R >= 1024) ? 1 : 0;
-        const int ts = big ? 256 : 128;
-        order[big].push_back(i);
-        tiles_tot[big] += (long)((args[i].Kv + ts - 1) / ts) * ((args[i].Nv + ts - 1) / ts) * args[i].nb * args[i].nb2;
+        order.push_back(i);
+        tiles_tot += (long)((args[i].Kv + 127) / 128) * ((args[i].Nv + 127) / 128) * args[i].nb * args[i].nb2;
     }
-    const int m0 = (int)order[0].size(), m1 = (int)order[1].size();
-    if (m0 + m1 == 0) return CMPC_OK;
-    TnGroupDesc* table = (TnGroupDesc*)cmpc_ws((size_t)(m0 + m1) * sizeof(TnGroupDesc), st);
+    const int m = (int)order.size();
+    if (m == 0) return CMPC_OK;
+    TnGroupDesc* table = (TnGroupDesc*)cmpc_ws((size_t)m * sizeof(TnGroupDesc), st);
     if (!table) return CMPC_EHIP;
-    int base = 0;
-    for (int big = 1; big >= 0; --big) {                 // the long launch first
-        const int m = (int)order[big].size();
-        if (m == 0) continue;
-        const int ts = big ? 256 : 128;
-        // split reductions only as far as needed to fill the persistent grid twice
-        const int slots = big ? 256 : 512;
-        const int want = (int)((2 * slots + tiles_tot[big] - 1) / tiles_tot[big]);
-        std::vector<TnGroupDesc> descs(m);
-        std::vector<long> len(m);
-        for (int j = 0; j < m; ++j) {
-            TnGroupDesc& d = descs[j];
-            d.a = args[order[big][j]];
-            const int br = big ? 32 : (d.a.dtype == DT_F32 ? TnCfg<float>::BR : TnCfg<bf16_t>::BR);
-            d.a.rsplit = std::max(1, std::min(want, std::max(1, d.a.R / (16 * br))));
-            d.tiles = ((d.a.Kv + ts - 1) / ts) * ((d.a.Nv + ts - 1) / ts);
-            len[j] = ((d.a.R + d.a.rsplit - 1) / d.a.rsplit + br - 1) / br;     // steps of one item
-        }
-        std::vector<int> idx(m);
-        for (int j = 0; j < m; ++j) idx[j] = j;
-        std::stable_sort(idx.begin(), idx.end(), [&](int x, int y) { return len[x] > len[y]; });   // long items first
-        int items = 0;
-        for (int c0 = 0; c0 < m; c0 += TN_UPLOAD) {
-            TnUploadArgs ua;
-            ua.n = std::min(TN_UPLOAD, m - c0);
-            ua.base = base + c0;
-            for (int i = 0; i < ua.n; ++i) {
-                ua.d[i] = descs[idx[c0 + i]];
-                ua.d[i].item_begin = items;
-                items += ua.d[i].tiles * ua.d[i].a.rsplit * ua.d[i].a.nb * ua.d[i].a.nb2;
-            }
-            hipLaunchKernelGGL(tn_desc_upload_kernel, dim3(1), dim3(256), 0, st, ua, table);
-        }
-        if (big) {
-            static bool attr = false;
-            if (!attr) { (void)hipFuncSetAttribute((const void*)gemm_tn_grouped_big_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 2 * 32 * 512); attr = true; }
-            hipLaunchKernelGGL(gemm_tn_grouped_big_kernel, dim3(std::min(items, slots)), dim3(512), 4 * 2 * 32 * 512, st, table + base, m, items);
-        } else {
-            hipLaunchKernelGGL(gemm_tn_grouped_kernel, dim3(std::min(items, slots)), dim3(256), 2 * 2 * TnCfg<bf16_t>::BR * 128 * 2, st, table + base, m, items);
-        }
-        base += m;
+    // split reductions only as far as needed to fill the persistent grid twice
+    const int slots = 512;
+    const int want = (int)((2 * slots + tiles_tot - 1) / tiles_tot);
+    std::vector<TnGroupDesc> descs(m);
+    std::vector<long> len(m);
+    for (int j = 0; j < m; ++j) {
+        TnGroupDesc& d = descs[j];
+        d.a = args[order[j]];
+        const int br = d.a.dtype == DT_F32 ? TnCfg<float>::BR : TnCfg<bf16_t>::BR;
+        d.a.rsplit = std::max(1, std::min(want, std::max(1, d.a.R / (16 * br))));
+        d.tiles = ((d.a.Kv + 127) / 128) * ((d.a.Nv + 127) / 128);
+        len[j] = ((d.a.R + d.a.rsplit - 1) / d.a.rsplit + br - 1) / br;     // steps of one item
     }
+    std::vector<int> idx(m);
+    for (int j = 0; j < m; ++j) idx[j] = j;
+    std::stable_sort(idx.begin(), idx.end(), [&](int x, int y) { return len[x] > len[y]; });   // long items first
+    int items = 0;
+    for (int c0 = 0; c0 < m; c0 += TN_UPLOAD) {
+        TnUploadArgs ua;
+        ua.n = std::min(TN_UPLOAD, m - c0);
+        ua.base = c0;
+        for (int i = 0; i < ua.n; ++i) {
+            ua.d[i] = descs[idx[c0 + i]];
+            ua.d[i].item_begin = items;
+            items += ua.d[i].tiles * ua.d[i].a.rsplit * ua.d[i].a.nb * ua.d[i].a.nb2;
+        }
+        hipLaunchKernelGGL(tn_desc_upload_kernel, dim3(1), dim3(256), 0, st, ua, table);
+    }
+    hipLaunchKernelGGL(gemm_tn_grouped_kernel, dim3(std::min(items, slots)), dim3(256), 2 * 2 * TnCfg<bf16_t>::BR * 128 * 2, st, table, m, items);
     return cmpc_check_launch("gemm_tn_grouped");
 }
 
 extern "C" int cmpc_gemm_tn(const cmpc_gemm_tn_args* a, void* stream) {
-    if (!a || a->R < 0 || a->Kv <= 0 || a->Nv <= 0 || a->nb < 1 || a->nb > 8 || a->nb2 < 1 || a->rsplit < 1) {
-        cmpc_set_error("gemm_tn: bad args"); return CMPC_EINVAL;
-    }
+    const int rc = tn_validate(a);
+    if (rc != CMPC_OK) return rc;
+    if (a->rsplit < 1) { cmpc_set_error("gemm_tn: rsplit must be >= 1"); return CMPC_EINVAL; }
     if (a->R == 0) return CMPC_OK;              // empty reduction: out += 0
-    if (!a->A || !a->D || !a->out) { cmpc_set_error("gemm_tn: null operand"); return CMPC_EINVAL; }
-    const int esz = a->dtype == DT_F32 ? 4 : 2;
-    if ((a->lda * esz) % 16 || (a->ldd * esz) % 16 || (a->Ka * esz) % 16 || (a->Nd * esz) % 16) {
-        cmpc_set_error("gemm_tn: rows must be 16-B aligned"); return CMPC_EINVAL;
-    }
-    for (int i = 0; i < a->nb; ++i)
-        if ((a->a_off[i] * esz) % 16 || (a->d_off[i] * esz) % 16) { cmpc_set_error("gemm_tn: offsets must be 16-B aligned"); return CMPC_EINVAL; }
-    if ((a->a_bs * esz) % 16 || (a->d_bs * esz) % 16) { cmpc_set_error("gemm_tn: batch strides must be 16-B aligned"); return CMPC_EINVAL; }
     dim3 grid(((a->Kv + 127) / 128) * ((a->Nv + 127) / 128), a->rsplit, a->nb * a->nb2);
     hipStream_t st = (hipStream_t)stream;
-    if (a->dtype == DT_F32) {
-        const size_t lds = 2 * 2 * TnCfg<float>::BR * 128 * 4;
-        hipLaunchKernelGGL((gemm_tn_kernel<float>), grid, dim3(256), lds, st, *a);
-    } else if (a->dtype == DT_BF16 && a->zeros && a->R >= 256 && getenv("CMPC_TN_V2")) {
-        static bool attr = false;
-        if (!attr) { (void)hipFuncSetAttribute((const void*)gemm_tn_v2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 2 * 64 * 256); attr = true; }
-        hipLaunchKernelGGL(gemm_tn_v2_kernel, grid, dim3(512), 3 * 2 * 64 * 256, st, *a);
-    } else if (a->dtype == DT_BF16) {
-        const size_t lds = 2 * 2 * TnCfg<bf16_t>::BR * 128 * 2;
-        hipLaunchKernelGGL((gemm_tn_kernel<bf16_t>), grid, dim3(256), lds, st, *a);
-    } else { cmpc_set_error("gemm_tn: bad dtype"); return CMPC_EINVAL; }
+    if (a->dtype == DT_F32) hipLaunchKernelGGL((gemm_tn_kernel<float>), grid, dim3(256), 2 * 2 * TnCfg<float>::BR * 128 * 4, st, *a);
+    else if (a->dtype == DT_BF16) hipLaunchKernelGGL((gemm_tn_kernel<bf16_t>), grid, dim3(256), 2 * 2 * TnCfg<bf16_t>::BR * 128 * 2, st, *a);
+    else hipLaunchKernelGGL((gemm_tn_kernel<f16_t>), grid, dim3(256), 2 * 2 * TnCfg<f16_t>::BR * 128 * 2, st, *a);
     return cmpc_check_launch("gemm_tn");
 }

@@ -425,7 +425,7 @@ __global__ __launch_bounds__(256) void clstm_peephole_grad_kernel(const T* __res
 
 bool ok(const char* what, int dt, int ld, int M) {
     if (ld <= 0 || M <= 0 || M > ld || ld % 8 || ld > MB * 512) { cmpc_set_error("%s: need 0 < M <= ld <= %d, ld %% 8 == 0", what, MB * 512); return false; }
-    if (dt != DT_F32 && dt != DT_BF16) { cmpc_set_error("%s: bad dtype", what); return false; }
+    if (dt != DT_F32 && dt != DT_BF16 && dt != DT_F16) { cmpc_set_error("%s: bad dtype", what); return false; }
     return true;
 }
 LnP to_lnp(const cmpc_convlstm_ln* l) { LnP p; for (int i = 0; i < 5; ++i) { p.beta[i] = l->beta[i]; p.gamma[i] = l->gamma[i]; } return p; }

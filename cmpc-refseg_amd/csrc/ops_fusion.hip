@@ -490,7 +490,7 @@ bool map_ok(const char* what, int ld, int C, int dt) {
         cmpc_set_error("%s: need 0 < C <= ld <= %d, ld %% 8 == 0 (got C=%d ld=%d)", what, MB * 512, C, ld);
         return false;
     }
-    if (dt != DT_F32 && dt != DT_BF16) { cmpc_set_error("%s: bad dtype %d", what, dt); return false; }
+    if (dt != DT_F32 && dt != DT_BF16 && dt != DT_F16) { cmpc_set_error("%s: bad dtype %d", what, dt); return false; }
     return true;
 }
 

@@ -258,7 +258,11 @@ __global__ __launch_bounds__(256) void pack_kernel(const float* __restrict__ mas
             if (k < Kp && n < Np) {
                 const long o = (long)k * d.ld_dst + n;
                 if (d.dst_dt == DT_F32) *reinterpret_cast<float4*>(reinterpret_cast<float*>(dst) + o) = v;
-                else {
+                else if (d.dst_dt == DT_F16) {
+                    f16_t* q = reinterpret_cast<f16_t*>(dst) + o;
+                    typedef __attribute__((ext_vector_type(4))) _Float16 h4v;
+                    *reinterpret_cast<h4v*>(q) = h4v{(f16_t)v.x, (f16_t)v.y, (f16_t)v.z, (f16_t)v.w};
+                } else {
                     uint2 u;
                     u.x = (uint32_t)f2bf(v.x) | ((uint32_t)f2bf(v.y) << 16);
                     u.y = (uint32_t)f2bf(v.z) | ((uint32_t)f2bf(v.w) << 16);
@@ -289,6 +293,7 @@ __global__ __launch_bounds__(256) void pack_kernel(const float* __restrict__ mas
             const long o = (long)nn * d.ld_dst + k;
             // rows of a destination operand are padded to multiples of 64 elements, so k..k+7 stay inside the row
             if (d.dst_dt == DT_F32) st8<float>(reinterpret_cast<float*>(dst) + o, a);
+            else if (d.dst_dt == DT_F16) st8<f16_t>(reinterpret_cast<f16_t*>(dst) + o, a);
             else st8<bf16_t>(reinterpret_cast<bf16_t*>(dst) + o, a);
         }
     }

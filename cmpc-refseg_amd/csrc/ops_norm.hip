@@ -624,7 +624,7 @@ bool map_ok(const char* what, int ld, int C, int dt) {
         cmpc_set_error("%s: need 0 < C <= ld <= %d, ld %% 8 == 0 (got C=%d ld=%d)", what, MAXBLK * 512, C, ld);
         return false;
     }
-    if (dt != DT_F32 && dt != DT_BF16) { cmpc_set_error("%s: bad dtype %d", what, dt); return false; }
+    if (dt != DT_F32 && dt != DT_BF16 && dt != DT_F16) { cmpc_set_error("%s: bad dtype %d", what, dt); return false; }
     return true;
 }
 
@@ -635,12 +635,13 @@ bool map_ok(const char* what, int ld, int C, int dt) {
 extern "C" int cmpc_cast(int src_dt, const void* src, int dst_dt, void* dst, int64_t n, void* stream) {
     if (n <= 0) return CMPC_OK;
     const int g = (int)((n + 255) / 256 > 4096 ? 4096 : (n + 255) / 256);
-    if (src_dt == DT_F32 && dst_dt == DT_BF16) hipLaunchKernelGGL((cast_kernel<float, bf16_t>), dim3(g), dim3(256), 0, ST, (const float*)src, (bf16_t*)dst, (long)n);
-    else if (src_dt == DT_BF16 && dst_dt == DT_F32) hipLaunchKernelGGL((cast_kernel<bf16_t, float>), dim3(g), dim3(256), 0, ST, (const bf16_t*)src, (float*)dst, (long)n);
-    else if (src_dt == DT_F32 && dst_dt == DT_F32) hipLaunchKernelGGL((cast_kernel<float, float>), dim3(g), dim3(256), 0, ST, (const float*)src, (float*)dst, (long)n);
-    else if (src_dt == DT_BF16 && dst_dt == DT_BF16) hipLaunchKernelGGL((cast_kernel<bf16_t, bf16_t>), dim3(g), dim3(256), 0, ST, (const bf16_t*)src, (bf16_t*)dst, (long)n);
-    else { cmpc_set_error("cast: bad dtypes"); return CMPC_EINVAL; }
-    return cmpc_check_launch("cast");
+#define CAST_CASE(SD, ST_, DD, DT_) if (src_dt == SD && dst_dt == DD) { hipLaunchKernelGGL((cast_kernel<ST_, DT_>), dim3(g), dim3(256), 0, ST, (const ST_*)src, (DT_*)dst, (long)n); return cmpc_check_launch("cast"); }
+    CAST_CASE(DT_F32, float, DT_BF16, bf16_t) CAST_CASE(DT_BF16, bf16_t, DT_F32, float) CAST_CASE(DT_F32, float, DT_F32, float)
+    CAST_CASE(DT_BF16, bf16_t, DT_BF16, bf16_t) CAST_CASE(DT_F32, float, DT_F16, f16_t) CAST_CASE(DT_F16, f16_t, DT_F32, float)
+    CAST_CASE(DT_F16, f16_t, DT_F16, f16_t) CAST_CASE(DT_F16, f16_t, DT_BF16, bf16_t) CAST_CASE(DT_BF16, bf16_t, DT_F16, f16_t)
+#undef CAST_CASE
+    cmpc_set_error("cast: bad dtypes");
+    return CMPC_EINVAL;
 }
 
 extern "C" int cmpc_axpy(int dt, const void* x, void* y, float a, int64_t n, void* stream) {

@@ -16,7 +16,7 @@ from . import _lib
 from ._lib import DT_BF16, DT_F32, EngineCfg, Feeds, Fetches
 from .params import HeadCfg
 
-_TYPESTR = {0: "<f4", 1: "<i2", 2: "<i4", 3: "<f8"}       # cmpc_tap dtype codes; bf16 travels as int16 and is re-viewed
+_TYPESTR = {0: "<f4", 1: "<i2", 2: "<f2", 3: "<i4", 4: "<f8"}      # cmpc_tap dtype codes; bf16 travels as int16 and is re-viewed
 
 
 class _DevMem:
@@ -52,6 +52,9 @@ class Engine:
         h = C.c_void_p()
         _lib.call("cmpc_create", C.byref(c), C.byref(h))
         self.h = h
+        eff = EngineCfg()
+        _lib.call("cmpc_get_cfg", h, C.byref(eff))
+        self.loss_scale = float(eff.loss_scale)           # the gradient buffer carries this factor (f16 storage: 256)
         # manifest
         self.index: Dict[str, Tuple[int, Tuple[int, ...]]] = {}
         self.order: List[str] = []
@@ -119,8 +122,10 @@ class Engine:
         return {n: self.params[o: o + int(np.prod(s))].view(s).detach().cpu().clone() for n, (o, s) in self.index.items()}
 
     def grad_dict(self) -> Dict[str, torch.Tensor]:
+        """d cls_loss_all / d theta by variable name (the loss scale of f16 storage divided out)."""
         torch.cuda.synchronize(self.device)
-        return {n: self.grads[o: o + int(np.prod(s))].view(s).detach().cpu().clone() for n, (o, s) in self.index.items()}
+        inv = 1.0 / self.loss_scale
+        return {n: self.grads[o: o + int(np.prod(s))].view(s).detach().cpu() * inv for n, (o, s) in self.index.items()}
 
     # ---- the three per-step calls --------------------------------------------------------------
     def forward(self, words, seq_len, c3, c4, c5, target=None, feats_ready: Optional[torch.cuda.Event] = None, fetches=None):

@@ -21,7 +21,7 @@ import numpy as np
 import torch
 
 from . import _lib, backbone as bb, dist
-from ._lib import DT_BF16, DT_F32
+from ._lib import DT_BF16, DT_F16, DT_F32
 from .engine import Engine
 from .params import HeadCfg, init_head_params
 
@@ -32,7 +32,7 @@ _EXG = ("c3", "c4", "c5", "c3_2", "c4_2", "c5_2")
 
 
 def tdt(dt: int):
-    return torch.float32 if dt == DT_F32 else torch.bfloat16
+    return {DT_F32: torch.float32, DT_BF16: torch.bfloat16, DT_F16: torch.float16}[dt]
 
 
 class LSTM_model(object):
@@ -53,15 +53,15 @@ class LSTM_model(object):
             raise NotImplementedError("conv5=True (backbone fine-tuning, CMPC_model.py:427-430) is out of scope")
         if keep_prob_rnn != 1.0 or keep_prob_emb != 1.0 or keep_prob_mlp != 1.0 or num_rnn_layers != 1:
             raise NotImplementedError("dropout / stacked LSTM are unused by the reference graph")
-        if dtype not in ("bf16", "f32"):
-            raise ValueError("dtype must be 'bf16' or 'f32'")
+        if dtype not in ("bf16", "f16", "f32"):
+            raise ValueError("dtype must be 'bf16', 'f16' or 'f32'")
         if not torch.cuda.is_available():
             raise RuntimeError("LSTM_model needs an MI355X (gfx950): the CMPC head has no CPU path")
         _lib.load()
         self.mode, self.device = mode, torch.device(device)
         if self.device.index is None:
             self.device = torch.device("cuda", torch.cuda.current_device())
-        self.dt = DT_BF16 if dtype == "bf16" else DT_F32
+        self.dt = {"bf16": DT_BF16, "f16": DT_F16, "f32": DT_F32}[dtype]
         self.batch_size, self.num_steps, self.H, self.W = batch_size, num_steps, H, W
         self.cfg = HeadCfg(batch_size=batch_size, num_steps=num_steps, vf_h=vf_h, vf_w=vf_w, H=H, W=W, vf_dim=vf_dim,
                            c4_dim=c4_dim, c3_dim=c3_dim, vocab_size=vocab_size, v_emb_dim=v_emb_dim, mlp_dim=mlp_dim,

@@ -18,7 +18,7 @@ from typing import List, Optional, Sequence, Tuple
 import torch
 
 from . import _lib
-from ._lib import (ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_TANH, DT_BF16, DT_F32, ConvLstmDln, ConvLstmLn,
+from ._lib import (ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_TANH, DT_BF16, DT_F16, DT_F32, ConvLstmDln, ConvLstmLn,
                    GemmNtArgs, GemmTnArgs)
 from .params import HeadCfg, ParamStore
 
@@ -26,7 +26,7 @@ F32 = DT_F32
 
 
 def tdt(dt: int):
-    return torch.float32 if dt == DT_F32 else torch.bfloat16
+    return {DT_F32: torch.float32, DT_BF16: torch.bfloat16, DT_F16: torch.float16}[dt]
 
 
 def esz(dt: int) -> int:
@@ -120,7 +120,7 @@ def gemm_tn(dt, A, lda, Ka, D, ldd, Nd, out, ldo, R, Kv, Nv, offs=((0, 0, 0),), 
     a.nb2, a.a_bs, a.d_bs, a.o_bs = nb2, a_bs, d_bs, o_bs
     if rsplit is None:
         tiles = ((Kv + 127) // 128) * ((Nv + 127) // 128) * len(offs) * nb2
-        br = 64 if dt == DT_BF16 else 32
+        br = 64 if dt != DT_F32 else 32
         rsplit = max(1, min((R + 4 * br - 1) // (4 * br), (512 + tiles - 1) // tiles))
     a.rsplit, a.alpha = rsplit, alpha
     a.zeros = _zero_page(A.device if torch.is_tensor(A) else torch.device('cuda', torch.cuda.current_device()))

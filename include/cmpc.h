@@ -12,7 +12,7 @@
  *  - `stream` is a hipStream_t passed as void*; all work is enqueued on it, nothing synchronises
  *  - return value: 0 = ok, <0 = error (CMPC_EINVAL -1, CMPC_EHIP -2); cmpc_last_error() gives
  *    the message; nothing throws across the ABI
- *  - dt: 0 = float32, 1 = bfloat16 (storage of feature maps and GEMM operands); statistics,
+ *  - dt: 0 = float32, 1 = bfloat16, 2 = float16 (storage of feature maps and GEMM operands); statistics,
  *    accumulators, logits, losses and parameters are always float32 (sample sums: float64)
  *  - a "map" is a row-major [R = B*N, ld] matrix, rows r = b*N + n (n = y*w + x, NHWC order of the
  *    reference), C valid channels, ld >= C a multiple of 8; producers write pad columns as 0
@@ -276,7 +276,11 @@ typedef struct {
     int lr_decay_step;
     float weight_decay;
     float loss_w[4];                    /* weights of the BCE terms: final, c5, c4, c3 = 0.7, 0.1, 0.1, 0.1 (:444-445) */
-    int dtype;                          /* storage of feature maps and visual GEMM operands: 0 f32 (parity mode), 1 bf16 */
+    int dtype;                          /* storage of feature maps and visual GEMM operands: 0 f32 (exact-fp32 MFMA), 1 bf16,
+                                           2 f16 (same MFMA rate as bf16, 8x smaller rounding: meets the 1e-4 mean-IoU bar) */
+    float loss_scale;                   /* every gradient cmpc_backward writes is multiplied by it and cmpc_optimizer_step divides
+                                           it out again; 0 = default (1; for f16 storage the power of two that keeps the largest upstream
+                                           gradient, loss_w[0] * (H/vf_h) * (W/vf_w) / batch_size, at <= 16) */
     int n_lanes;                        /* 3: pyramid levels / exchange modules on three lane streams; 1: one stream */
     int device;                         /* HIP device ordinal; -1 = planning only (manifest, operand plan, workspace size:
                                            no GPU is touched; every compute entry point then returns CMPC_EINVAL) */
@@ -285,13 +289,15 @@ typedef struct {
 int cmpc_default_cfg(cmpc_cfg* cfg);
 int cmpc_create(const cmpc_cfg* cfg, cmpc_handle* out);
 int cmpc_destroy(cmpc_handle h);
+/* the configuration in effect (defaults resolved, e.g. loss_scale) */
+int cmpc_get_cfg(cmpc_handle h, cmpc_cfg* out);
 
 /* parameter manifest in the reference's variable order and names ("text_objseg/c5_lateral/DW", ...):
  * index 0..n-1 -> name, element offset into the flat buffers, rank and shape (<= 4 dims, HWIO for convolutions) */
 int cmpc_param_count(cmpc_handle h);
 int cmpc_param_info(cmpc_handle h, int index, const char** name, int64_t* offset, int* rank, int64_t shape[4]);
 /* the flat fp32 device buffers (total elements incl. 16-B alignment gaps): masters, gradients (what a data-parallel
- * caller all-reduces between cmpc_backward and cmpc_optimizer_step), Adam m and v */
+ * caller all-reduces between cmpc_backward and cmpc_optimizer_step; they carry the factor cfg.loss_scale), Adam m and v */
 int cmpc_buffers(cmpc_handle h, float** params, float** grads, float** adam_m, float** adam_v, int64_t* total);
 /* tf.train.Saver.restore / save by variable name (trainval_model.py:46-63,136-142): host pointers, `count` must
  * equal the variable's element count.  cmpc_set_weights does NOT repack; call cmpc_pack after the last one. */
@@ -332,7 +338,7 @@ int cmpc_optimizer_step(cmpc_handle h, float gscale, void* stream, double* lr_us
 
 /* Named intermediate of the last forward / backward ("words_parse", "gw_w_c3", "up_c4", "scalars", ...: the fetches
  * of the reference's visualisers, test_visualize_graph.py:243-253, plus every stage output the parity tests compare).
- * dtype: 0 f32, 1 bf16, 2 int32, 3 f64.  The pointer stays valid for the handle's lifetime; its contents are those of
+ * dtype: 0 f32, 1 bf16, 2 f16, 3 int32, 4 f64.  The pointer stays valid for the handle's lifetime; its contents are those of
  * the most recent step once the work enqueued by that step has finished. */
 int cmpc_tap(cmpc_handle h, const char* name, void** ptr, int* dtype, int* rank, int64_t shape[4]);
 int cmpc_tap_count(cmpc_handle h);

@@ -1,7 +1,8 @@
 """GPU parity tests (run on the MI355X box with -m gpu): the HIP path, called through the C ABI,
 against the oracle on identical seeded inputs.  Tolerances: fp32 mode (exact-fp32 MFMA) 2e-5
-relative on every tap and 2e-4 on parameter gradients (fp32 atomics reorder sums); bf16 mode 4e-2
-on taps; mean-IoU delta <= 1e-4 (BASELINE.json) in fp32 mode, reported for bf16."""
+relative on every tap and 2e-4 on parameter gradients (fp32 atomics reorder sums); f16 storage 6e-3 and
+bf16 storage 4e-2 on taps; mean-IoU delta <= 1e-4 (BASELINE.json) asserted in fp32 AND f16 mode at B = 2, 4 and 8
+(bf16 storage misses the bar on some inputs: measured up to 1.6e-4, bounded at 3e-4)."""
 import importlib
 import os
 
@@ -51,7 +52,7 @@ def test_library_is_the_compute_path():
     assert P._lib.load().cmpc_abi_version() == 1
 
 
-@pytest.mark.parametrize("dt,tdt,tol", [(0, torch.float32, 5e-6), (1, torch.bfloat16, 2e-2)])
+@pytest.mark.parametrize("dt,tdt,tol", [(0, torch.float32, 5e-6), (1, torch.bfloat16, 2e-2), (2, torch.float16, 3e-3)])
 def test_gemm_nt_against_torch(dt, tdt, tol):
     ops, dev = _ops(), torch.device("cuda:0")
     torch.manual_seed(0)
@@ -80,13 +81,9 @@ def test_gemm_nt_against_torch(dt, tdt, tol):
     assert U.rel_err(C.float().cpu(), torch.bmm(A.float(), Bt.float().transpose(1, 2)).cpu()) < tol
 
 
-@pytest.mark.parametrize("variant", ["default", "CMPC_TN_V2"])
-@pytest.mark.parametrize("dt,tdt,tol", [(0, torch.float32, 1e-5), (1, torch.bfloat16, 1e-5)])
-def test_gemm_tn_against_torch(dt, tdt, tol, variant, monkeypatch):
-    """A = I-style check with ASYMMETRIC operands plus random cases (exact products of bf16 inputs in fp32); also with
-    the LDS-DMA variant of the kernel forced."""
-    if variant != "default":
-        monkeypatch.setenv(variant, "1")
+@pytest.mark.parametrize("dt,tdt,tol", [(0, torch.float32, 1e-5), (1, torch.bfloat16, 1e-5), (2, torch.float16, 1e-5)])
+def test_gemm_tn_against_torch(dt, tdt, tol):
+    """A = I-style check with ASYMMETRIC operands plus random cases (exact products of 16-bit inputs in fp32)."""
     ops, dev = _ops(), torch.device("cuda:0")
     torch.manual_seed(1)
     R, K, N = 256, 128, 128
@@ -109,12 +106,10 @@ def test_gemm_tn_against_torch(dt, tdt, tol, variant, monkeypatch):
                 d_bs=R * 2 * N, o_bs=K * 2 * N, alpha=2.0)
     assert U.rel_err(out.cpu(), (2.0 * torch.bmm(A.float().transpose(1, 2), D.float())).cpu()) < tol
 
-@pytest.mark.parametrize("big", ["0", "1"])
-def test_gemm_tn_grouped_against_torch(big, monkeypatch):
-    """cmpc_gemm_tn_grouped (big=1: with the optional 256 x 256-tile kernel for the large bf16 products): a mixed bag of deferred products (bf16 and fp32, inner-batch offsets, an outer batch
-    accumulating into one output, two products adding into the SAME output, an empty reduction) in few launches."""
+def test_gemm_tn_grouped_against_torch():
+    """cmpc_gemm_tn_grouped: a mixed bag of deferred products (bf16, f16 and fp32, inner-batch offsets, an outer batch
+    accumulating into one output, two products adding into the SAME output, an empty reduction) in one launch."""
     P, ops, dev = U.pkg(), _ops(), torch.device("cuda:0")
-    monkeypatch.setenv("CMPC_TN_BIG", big)
     torch.manual_seed(3)
 
     class Cx:                      # the two attributes gemm_tn(..., wg=cx) looks at
@@ -124,8 +119,8 @@ def test_gemm_tn_grouped_against_torch(big, monkeypatch):
     for i, (dt, R, K, N) in enumerate(((1, 1500, 256, 128), (1, 4000, 128, 384), (0, 160, 72, 40), (1, 64, 8, 24), (0, 8, 128, 128),
                                        (1, 700, 512, 512), (0, 0, 8, 8), (1, 2500, 64, 1024), (0, 300, 200, 16), (1, 1000, 128, 128),
                                        (1, 999, 136, 264), (1, 130, 128, 64),
-                                       (1, 3000, 512, 768), (1, 1500, 304, 264), (1, 2048, 256, 256), (1, 1100, 1024, 328))):      # 256 x 256-tile kernel
-        tdt = torch.bfloat16 if dt == 1 else torch.float32
+                                       (2, 3000, 512, 768), (1, 1500, 304, 264), (2, 2048, 256, 256), (1, 1100, 1024, 328))):
+        tdt = {0: torch.float32, 1: torch.bfloat16, 2: torch.float16}[dt]
         Kp, Np = (K + 7) // 8 * 8, (N + 7) // 8 * 8
         A = torch.randn(R, Kp, device=dev).to(tdt); D = torch.randn(R, Np, device=dev).to(tdt)
         out = torch.randn(K, N, device=dev); out0 = out.clone()
@@ -152,29 +147,30 @@ def test_gemm_tn_grouped_against_torch(big, monkeypatch):
         assert float((o - r).abs().max()) <= 2e-5 * max(1.0, float(r.abs().max())), i
 
 
-@pytest.mark.parametrize("env", ["CMPC_GEMM_V2", "CMPC_GEMM_V3", "CMPC_GEMM_V4", "CMPC_GEMM_V5", "CMPC_GEMM_V1"])
-def test_gemm_nt_kernel_variants_agree(env, monkeypatch):
-    """Every bf16 gemm_nt kernel variant (forced by its switch) against torch on shapes that reach the tiled
-    pipelines: ragged M and N, three K-segments, per-sample bias, activation, pad-column zeroing, accumulate."""
+@pytest.mark.parametrize("dt,tdt", [(1, torch.bfloat16), (2, torch.float16)])
+def test_gemm_nt_pipelines_agree_with_torch(dt, tdt):
+    """Every 16-bit gemm_nt pipeline (the shapes below dispatch to the 256 x 256-tile kernel, to the fragment-double-buffered
+    one with 256- and 128-row tiles and to the producer / consumer one) against torch: ragged M and N, three K-segments,
+    per-sample bias, activation, pad-column zeroing, accumulate."""
     ops, dev = _ops(), torch.device("cuda:0")
-    monkeypatch.setenv(env, "1")
     torch.manual_seed(5)
-    for (M, N, Ks, nv) in ((3000, 640, (256,), 640), (1111, 1024, (64, 128, 64), 1000), (12800, 512, (512,), 500), (700, 264, (2048, 64), 264)):
+    for (M, N, Ks, nv) in ((3000, 640, (256,), 640), (1111, 1024, (64, 128, 64), 1000), (12800, 512, (512,), 500), (700, 264, (2048, 64), 264),
+                           (4096, 1024, (1024,), 1000), (2500, 2048, (512, 64), 2048), (12800, 512, (4096, 128), 512), (900, 384, (4160,), 380)):
         K = sum(Ks)
-        A = [torch.randn(M, k, device=dev).bfloat16() for k in Ks]
-        Bt = torch.randn(N, K, device=dev).bfloat16()
+        A = [torch.randn(M, k, device=dev).to(tdt) for k in Ks]
+        Bt = (0.25 * torch.randn(N, K, device=dev)).to(tdt)
         bias = torch.randn(N, device=dev); rps = 100 if M % 100 == 0 else M
         sb = torch.randn(M // rps, N, device=dev)
-        C = torch.randn(M, N, device=dev).bfloat16(); C0 = C.clone()
+        C = torch.randn(M, N, device=dev).to(tdt); C0 = C.clone()
         segs, off = [], 0
         for a, k in zip(A, Ks):
             segs.append((a, k, Bt.data_ptr() + 2 * off, K, k)); off += k
-        ops.gemm_nt(1, segs, C, N, M, N, n_valid=nv, bias=bias, sbias=sb, ld_sbias=N, rows_per_sample=rps, act=1, accumulate=True)
+        ops.gemm_nt(dt, segs, C, N, M, N, n_valid=nv, bias=bias, sbias=sb, ld_sbias=N, rows_per_sample=rps, act=1, accumulate=True)
         ref = torch.relu(torch.cat(A, 1).float() @ Bt.float().t() + bias + sb.repeat_interleave(rps, 0))
         ref[:, nv:] = 0
-        ref = (ref + C0.float()).bfloat16().float()
+        ref = (ref + C0.float()).to(tdt).float()
         torch.cuda.synchronize()
-        assert U.rel_err(C.float().cpu(), ref.cpu()) < 1e-2, (env, M, N, Ks)
+        assert U.rel_err(C.float().cpu(), ref.cpu()) < (1e-2 if dt == 1 else 2e-3), (dt, M, N, Ks)
         if nv < N:      # pad columns: the product contributes exact zeros
             assert torch.equal(C[:, nv:], C0[:, nv:])
 
@@ -222,19 +218,24 @@ def test_head_matches_committed_golden(case):
     assert abs(float(o["loss_all"].detach()) - float(g["scal/loss_all"])) <= 1e-4 * float(g["scal/loss_all"])
 
 
-def test_head_bf16_within_tolerance(case):
-    m = _model(case, "bf16")
+@pytest.mark.parametrize("dtype,tap_tol,loss_tol,grad_tol", [("bf16", 4e-2, 2e-2, 0.1), ("f16", 6e-3, 3e-3, 2e-2)])
+def test_head_16bit_within_tolerance(case, dtype, tap_tol, loss_tol, grad_tol):
+    """bf16 / f16 storage of maps and visual operands (fp32 accumulation, statistics and language side): every tap, the loss
+    and a gradient of every stage family against the oracle; f16 (11-bit significand, static loss scale 256) is ~8x tighter."""
+    m = _model(case, dtype)
     feats = [f.to(m.device) for f in case["feats"]]
     o = m.loss_and_grads(feats, case["words"], case["tgt"], case["sl"])
     torch.cuda.synchronize()
     pt = U.product_taps_as_oracle(o, case["cfg"])
     for k, ref in case["taps"].items():
-        assert U.rel_err(pt[k], ref) < 4e-2, k
-    assert abs(float(o["loss_all"].detach()) - case["scal"]["loss_all"]) <= 2e-2 * abs(case["scal"]["loss_all"])
+        assert U.rel_err(pt[k], ref) < tap_tol, k
+    assert abs(float(o["loss_all"].detach()) - case["scal"]["loss_all"]) <= loss_tol * abs(case["scal"]["loss_all"])
     g = m.store.grad_dict()
+    assert all(torch.isfinite(v).all() for v in g.values())
     for n in ("text_objseg/fusion_c5/DW", "text_objseg/rnn/conv_lstm_cell/kernel", "text_objseg/vis_trans_c4_head3/DW",
-              "text_objseg/trans_feat_c3_2_f1/DW", "text_objseg/score/DW", "text_objseg/rnn/lstm_cell/kernel"):
-        assert U.rel_err(g[n], _ref_grad(case, n)) < 0.1, n
+              "text_objseg/trans_feat_c3_2_f1/DW", "text_objseg/score/DW", "text_objseg/rnn/lstm_cell/kernel",
+              "text_objseg/c3_lateral/DW", "text_objseg/gconv_update_spa_graph_c4/DW", "text_objseg/words_trans_c5/DW"):
+        assert U.rel_err(g[n], _ref_grad(case, n)) < grad_tol, n
 
 
 def test_train_steps_match_tf_adam(case):
@@ -370,9 +371,9 @@ def test_full_size_properties():
 
 def test_full_size_mean_iou_delta_vs_oracle():
     """BASELINE.json's parity bar at the benchmark's sizes (320x320, L=20, C=1000, M=500, ResNet-101):
-    |mean-IoU(HIP) - mean-IoU(oracle)| <= 1e-4 on identical inputs and weights.  fp32 mode must meet
-    it; bf16 mode is measured and bounded at 5e-3 (its value is recorded in DESIGN.md).  B=2 keeps the
-    CPU oracle to ~15 s."""
+    |mean-IoU(HIP) - mean-IoU(oracle)| <= 1e-4 on identical inputs and weights.  fp32 and f16 storage must meet
+    it; bf16 storage is measured (1.6e-4 on this seed: ~150 of 204,800 mask pixels flip, all with |logit| below the
+    8-bit rounding of the 1000-channel sums) and bounded at 3e-4.  B=2 keeps the CPU oracle to ~15 s."""
     from bench import synth_batch
     torch.set_num_threads(16)
     B = 2
@@ -386,7 +387,7 @@ def test_full_size_mean_iou_delta_vs_oracle():
         ref = O.losses(hp, taps, tg, cfg)
     P = U.pkg()
     res = {}
-    for dtype in ("f32", "bf16"):
+    for dtype in ("f32", "f16", "bf16"):
         m = P.LSTM_model(batch_size=B, mode="train", dtype=dtype, head_params=hp, backbone_params=bp)
         with torch.no_grad():
             o = m.head(m.features(im), w, sl, tg)
@@ -398,14 +399,15 @@ def test_full_size_mean_iou_delta_vs_oracle():
         torch.cuda.empty_cache()
     print("full-size parity:", {k: f"dIoU={v[0]:.2e} flipped_px={v[1]} up_rel_err={v[2]:.2e}" for k, v in res.items()}, "oracle mIoU", float(ref["mIoU"]))
     assert res["f32"][0] <= 1e-4 and res["f32"][2] < 1e-3
-    assert res["bf16"][0] <= 5e-3
+    assert res["f16"][0] <= 1e-4 and res["f16"][2] < 5e-3
+    assert res["bf16"][0] <= 3e-4
 
 
 def test_full_size_gradients_vs_oracle():
     """Backward at the benchmark's sizes (B=1): the full-width kernel paths (256 x 256 GEMM tiles, the grouped
     weight-gradient launch with unsplit 1600-row reductions, full-width mutan / ConvLSTM / score kernels) are not reached
     by the tiny case.  fp32 mode: a parameter gradient of every stage within 2e-3 of the oracle's (fp32 sums over
-    1600 x 1000 terms in a different order); bf16 mode: within 0.12."""
+    1600 x 1000 terms in a different order); f16 storage: within 2e-2; bf16 storage: within 0.12."""
     from bench import synth_batch
     torch.set_num_threads(16)
     B = 1
@@ -429,11 +431,11 @@ def test_full_size_gradients_vs_oracle():
              "text_objseg/gconv_feat_ln_spa_graph_c5/gamma"]
     P = U.pkg()
     worst = {}
-    for dtype, tol in (("f32", 2e-3), ("bf16", 0.12)):
+    for dtype, tol in (("f32", 2e-3), ("f16", 2e-2), ("bf16", 0.12)):
         m = P.LSTM_model(batch_size=B, mode="train", dtype=dtype, head_params=hp, backbone_params=bp)
         o = m.loss_and_grads([f.to(m.device) for f in feats], w, tg, sl)
         torch.cuda.synchronize()
-        assert abs(float(o["loss_all"].detach()) - scal["loss_all"]) <= (2e-4 if dtype == "f32" else 3e-2) * abs(scal["loss_all"])
+        assert abs(float(o["loss_all"].detach()) - scal["loss_all"]) <= {"f32": 2e-4, "f16": 5e-3, "bf16": 3e-2}[dtype] * abs(scal["loss_all"])
         g = m.store.grad_dict()
         errs = {n: U.rel_err(g[n], ref(n)) for n in names}
         worst[dtype] = max(errs.items(), key=lambda kv: kv[1])
@@ -442,3 +444,62 @@ def test_full_size_gradients_vs_oracle():
         del m, o, g
         torch.cuda.empty_cache()
     print("full-size gradient parity, worst relative error:", worst)
+
+
+@pytest.mark.parametrize("B,seed", [(8, 0), (4, 7)])
+def test_benchmark_configurations_vs_oracle(B, seed):
+    """BASELINE.json configs 2 (B=8: what bench.py times) and 1 (B=4) at full size, on bench.py's own synthetic batch:
+    the batch matters here -- l2_normalize(gv_lang) couples the samples of a batch (CMPC_model.py:241) and the GEMM dispatch
+    switches tile shapes with B.  fp32 mode: `up` within 1e-3 of the oracle and the SAME mean IoU; f16 storage: mean-IoU delta
+    <= 1e-4 (the north_star bar); bf16 storage: reported, bounded at 3e-4.  Plus the size-independent properties, and at B=8 a
+    gradient of five stage families against the oracle's (fp32 mode)."""
+    from bench import synth_batch
+    torch.set_num_threads(16)
+    cfg = O.Cfg(batch_size=B)
+    hp, bp = O.init_head_params(cfg), O.init_backbone_params(cfg)
+    w, im, sl, tg = map(torch.from_numpy, synth_batch(B, 20, 320, 320, cfg.vocab_size, seed))
+    with torch.no_grad():
+        feats = O.backbone_forward(bp, im, cfg)
+    if B == 8:
+        scal, grads, taps = O.grads_of(hp, feats, w, sl, tg, cfg)
+        ref_miou = scal["mIoU"]
+    else:
+        with torch.no_grad():
+            taps = O.head_forward(hp, feats, w, sl, cfg)
+            ref_miou = float(O.losses(hp, taps, tg, cfg)["mIoU"])
+    P = U.pkg()
+    res = {}
+    for dtype in ("f32", "f16", "bf16"):
+        m = P.LSTM_model(batch_size=B, mode="train", dtype=dtype, head_params=hp, backbone_params=bp)
+        o = m.loss_and_grads(m.features(im), w, tg, sl)
+        torch.cuda.synchronize()
+        up = o["up"].float().cpu()
+        res[dtype] = (abs(float(o["mIoU"]) - ref_miou), int(((up > 0) != (taps["up"] > 0)).sum()), U.rel_err(up, taps["up"]))
+        # properties (any dtype): adjacency rows sum to 1, padded words carry nothing, unit channel norms, exact-zero pads
+        T = 20
+        gw_w, gw_v = o["gw_w_c4"][:, :, :T].float(), o["gw_v_c4"][:, :, :T].float()
+        assert torch.allclose(gw_w.sum(2), torch.ones_like(gw_w.sum(2)), atol=1e-4)
+        for b in range(B):
+            n = int(sl[b])
+            assert torch.all(gw_v[b, :, n:] == 0) and torch.all(gw_w[b, :, n:] == 0)
+        for k, c in (("vis_la_sp_c3", 1000), ("exg_c4_2", 500)):
+            x = o[k].float()
+            assert torch.all(x[:, c:] == 0), k
+            assert torch.allclose(x.pow(2).sum(1), torch.ones(x.shape[0], device=x.device), atol=2e-2), k
+        # sigmoid(up) rounds to exactly 0.5 for |up| < 6e-8: compare away from that sliver
+        assert torch.all((o["sigm"] > 0.5) <= (o["up"] > 0)) and torch.all((o["up"] > 1e-6) <= (o["sigm"] > 0.5))
+        if dtype == "f32" and B == 8:
+            flags = {k: f for k, _, _, f in O.head_param_specs(cfg)}
+            g = m.store.grad_dict()
+            for n in ("text_objseg/c5_lateral/DW", "text_objseg/vis_trans_c3_head2/DW", "text_objseg/fusion_c4/DW",
+                      "text_objseg/trans_feat_c5_2_f2/DW", "text_objseg/rnn/conv_lstm_cell/kernel"):
+                r = grads[n] / (2.0 if "x2" in flags[n] else 1.0)
+                r = r - cfg.weight_decay * hp[n] if "reg" in flags[n] else r
+                assert U.rel_err(g[n], r) < 2e-3, n
+            assert abs(float(o["loss_all"]) - scal["loss_all"]) <= 2e-4 * abs(scal["loss_all"])
+        del m, o
+        torch.cuda.empty_cache()
+    print(f"B={B} parity:", {k: f"dIoU={v[0]:.2e} flipped_px={v[1]} up_rel_err={v[2]:.2e}" for k, v in res.items()}, "oracle mIoU", ref_miou)
+    assert res["f32"][0] <= 1e-4 and res["f32"][2] < 1e-3
+    assert res["f16"][0] <= 1e-4
+    assert res["bf16"][0] <= 3e-4
