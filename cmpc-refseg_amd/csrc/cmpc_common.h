@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <vector>
 
 #define CMPC_OK 0
 #define CMPC_EINVAL (-1)
@@ -27,6 +28,23 @@ void* cmpc_ws(size_t bytes, hipStream_t st);
 // out[o*ld_out + seg*out_seg + c] (+)= sum_{i<ninner} part[(o*ninner+i)*part_stride + seg*seg_ld + c], c < seg_C
 int cmpc_reduce_parts_f32(const float* part, long part_stride, int nouter, int ninner, int nseg, int seg_ld, int seg_C,
                           float* out, long ld_out, long out_seg, int accumulate, hipStream_t st);
+// cmpc_gemm_tn_grouped with a caller-owned persistent descriptor table (device) and a host copy of its contents: uploaded only when
+// the descriptors change
+int cmpc_gemm_tn_grouped_cached(const void* args /* cmpc_gemm_tn_args[n] */, int n, void* table_dev, size_t table_bytes, std::vector<char>* shadow, hipStream_t st);
+// Deferred folds.  Column sums whose target lies in [lo, hi) (the flat gradient buffer: bias, LayerNorm and peephole gradients, read by
+// nothing before the optimizer) need not be folded right behind their producer: between cmpc_fold_begin and cmpc_fold_flush (same host
+// thread) cmpc_ws hands out NON-recycled pieces of `arena`, cmpc_reduce_parts_f32 records such folds instead of launching them, and
+// cmpc_fold_flush folds them all in ONE launch.  table_dev: device buffer for the descriptors (>= 64 B each); it is re-uploaded only
+// when the recorded list differs from the previous flush (shapes are static, so after the first step it never does).
+struct cmpc_fold_desc { const float* part; long part_stride; int nouter, ninner, nseg, seg_ld, seg_C, blk_begin; float* out; long ld_out, out_seg; };
+struct cmpc_fold_ctx {
+    char* arena = nullptr; size_t cap = 0, off = 0; const float* lo = nullptr; const float* hi = nullptr;
+    cmpc_fold_desc* table_dev = nullptr; int table_cap = 0;
+    cmpc_fold_desc* descs = nullptr; int n = 0;            // host list of this step (table_cap entries)
+    cmpc_fold_desc* shadow = nullptr; int shadow_n = -1;   // what table_dev holds
+};
+void cmpc_fold_begin(cmpc_fold_ctx* ctx);
+int cmpc_fold_flush(cmpc_fold_ctx* ctx, hipStream_t st);
 // out[o*nval + v] = sum_{i<ninner} part[(o*ninner+i)*nval + v]
 int cmpc_reduce_parts_f64(const double* part, int nouter, int ninner, int nval, double* out, hipStream_t st);
 

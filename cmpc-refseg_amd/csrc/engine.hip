@@ -62,6 +62,25 @@ __global__ __launch_bounds__(256) void add_n_kernel(T* __restrict__ dst, AddArgs
     }
 }
 
+// dst[c][r] = (T) src[r][c]  (src f32 [rows][cols], dst [cols][rows]); 32 x 32 tiles through LDS
+template <typename T>
+__global__ __launch_bounds__(256) void transpose_cast_kernel(const float* __restrict__ src, T* __restrict__ dst, int rows, int cols) {
+    __shared__ float tile[32][33];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const int r0 = blockIdx.y * 32, c0 = blockIdx.x * 32;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int r = r0 + ty + 8 * i, c = c0 + tx;
+        tile[ty + 8 * i][tx] = (r < rows && c < cols) ? src[(long)r * cols + c] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = c0 + ty + 8 * i, r = r0 + tx;
+        if (c < cols && r < rows) Elem<T>::st(dst + (long)c * rows + r, tile[tx][ty + 8 * i]);
+    }
+}
+
 __global__ void transpose_i32_kernel(const int* __restrict__ src, int* __restrict__ dst, int rows, int cols) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;          // dst[c][r] = src[r][c]
     if (i < rows * cols) { const int r = i / cols, c = i - r * cols; dst[c * rows + r] = src[i]; }
@@ -114,7 +133,7 @@ struct LevelBuf {          // one pyramid level (c5 / c4 / c3), forward then bac
     int cin;
     const void* feat;
     void *X0, *P, *X1, *PT, *PTt, *gw_w_t, *gw_v_t, *Zt, *Y, *G, *U, *X2, *F;
-    float *lat_rstd, *g, *mut_rstd, *Wd, *PTf, *PTtf, *k0s, *A0, *pr, *gw_w, *gw_v, *gsc, *Ztf, *rrow, *sb;
+    float *lat_rstd, *g, *mut_rstd, *Wd, *PTf, *k0s, *A0, *pr, *gw_w, *gw_v, *gsc, *Ztf, *rrow, *sb;
     double *sums1, *sums2;
     float *score, *up, *loss; int* iu;
     // backward
@@ -159,7 +178,7 @@ struct cmpc_engine_s {
     // buffers
     void* spatial = nullptr;
     int* words_tb; float *emb, *xg, *gates, *h_all, *c_all, *outs, *wf, *wf_rstd, *mask;
-    float *douts, *dh, *dc, *dgt, *demb;
+    float *douts, *dh, *dc, *dgt, *demb, *demb_parts;
     float *h1, *lg, *parse, *dlg, *dh1;
     float *vl, *vl_rstd, *nec, *nec_rstd, *dparse, *dwf, *dvl, *dnec;
     LevelBuf lv[3];                 // c5, c4, c3
@@ -172,6 +191,9 @@ struct cmpc_engine_s {
     const int32_t* seq_len_feed = nullptr; const float* target_feed = nullptr;      // caller-owned feeds the backward pass re-reads
     hipStream_t last_main = nullptr; long l0 = 0;
     std::vector<cmpc_gemm_tn_args> deferred;
+    void* tn_table = nullptr; size_t tn_table_bytes = 0; std::vector<char> tn_shadow;      // descriptor table of the grouped dW launch
+    cmpc_fold_ctx fold;                 // deferred bias / LayerNorm / peephole gradient folds (one launch per backward pass)
+    std::vector<cmpc_fold_desc> fold_descs, fold_shadow;
     std::vector<Tap> taps;
     std::unordered_map<std::string, int> tapindex;
     long launches_step = 0;
@@ -409,7 +431,7 @@ void plan_workspace(E* e, Bump& zf, Bump& zb, Bump& g) {
     e->dh = (float*)zb.take((size_t)B * Cp * F);
     e->dc = (float*)zb.take((size_t)B * Cp * F);
     e->dgt = (float*)g.take((size_t)T * B * 4 * Cp * F);
-    e->demb = (float*)g.take((size_t)T * B * Gp * F);
+    e->demb = (float*)g.take((size_t)T * B * Gp * F); e->demb_parts = (float*)g.take((size_t)8 * T * B * Gp * F);
     e->h1 = (float*)g.take((size_t)B * T * Pp * F);
     e->lg = (float*)g.take((size_t)B * T * 64 * F);
     e->parse = (float*)g.take((size_t)B * T * 4 * F);
@@ -434,7 +456,7 @@ void plan_workspace(E* e, Bump& zf, Bump& zb, Bump& g) {
         L.X1 = g.take((size_t)R * Cp * es); L.mut_rstd = (float*)g.take((size_t)R * F);
         L.Wd = (float*)zf.take((size_t)B * Tp * Cp * F);
         L.PTf = (float*)g.take((size_t)B * Tp * Cp * F); L.PT = g.take((size_t)B * Tp * Cp * es);
-        L.PTtf = (float*)g.take((size_t)Cp * B * Tp * F); L.PTt = g.take((size_t)Cp * B * Tp * es);
+        L.PTt = g.take((size_t)Cp * B * Tp * es);
         L.k0s = (float*)g.take((size_t)B * Tp * F);
         L.A0 = (float*)g.take((size_t)B * N * Tp * F); L.pr = (float*)g.take((size_t)B * T * F);
         L.gw_w = (float*)g.take((size_t)B * N * Tp * F); L.gw_v = (float*)g.take((size_t)B * N * Tp * F);
@@ -505,6 +527,11 @@ void plan_workspace(E* e, Bump& zf, Bump& zb, Bump& g) {
     e->loss = (float*)zf.take((size_t)B * F); e->iu = (int*)zf.take((size_t)2 * B * 4);
     e->dscore = (float*)g.take((size_t)B * e->h * e->w * F); e->dfused = g.take((size_t)R * Mp * es);
     e->scalars = (float*)g.take(256);
+    e->tn_table_bytes = (size_t)256 << 10; e->tn_table = g.take(e->tn_table_bytes);
+    e->fold.cap = (size_t)512 << 20;                       // partial rows of the deferred folds (~2 MB each, ~110 per step)
+    e->fold.arena = (char*)g.take(e->fold.cap);
+    e->fold.table_cap = 1024;
+    e->fold.table_dev = (cmpc_fold_desc*)g.take(sizeof(cmpc_fold_desc) * e->fold.table_cap);
     tap(e, "fused", e->cl[2].h_new, vd, {R, Mp});
     tap(e, "pred", e->score, 0, {B, e->h, e->w, 1}); tap(e, "up", e->up, 0, {B, H, W, 1}); tap(e, "sigm", e->sigm, 0, {B, H, W, 1});
     tap(e, "iu", e->iu, 3, {2, B}); tap(e, "loss_vec", e->loss, 0, {B}); tap(e, "scalars", e->scalars, 0, {6});
@@ -608,6 +635,14 @@ int colsum(hipStream_t st, int dt, const void* dy, int R, int stride, int ld, in
     return CMPC_OK;
 }
 
+int transpose_cast(hipStream_t st, const float* src, int dt, void* dst, int rows, int cols) {
+    dim3 grid((cols + 31) / 32, (rows + 31) / 32);
+    if (dt == DT_F32) hipLaunchKernelGGL((transpose_cast_kernel<float>), grid, dim3(256), 0, st, src, (float*)dst, rows, cols);
+    else if (dt == DT_BF16) hipLaunchKernelGGL((transpose_cast_kernel<bf16_t>), grid, dim3(256), 0, st, src, (bf16_t*)dst, rows, cols);
+    else hipLaunchKernelGGL((transpose_cast_kernel<f16_t>), grid, dim3(256), 0, st, src, (f16_t*)dst, rows, cols);
+    return cmpc_check_launch("transpose_cast");
+}
+
 int add_n(hipStream_t st, int dt, void* dst, std::initializer_list<const void*> srcs, bool acc, long n) {
     AddArgs a; a.n = 0;
     for (const void* s : srcs) a.src[a.n++] = s;
@@ -668,8 +703,14 @@ int text_bwd(E* e, hipStream_t st, const int32_t* seq_len) {
     CK(gemm_tn(e, st, DT_F32, e->h_all, Cp, Cp, e->dgt, 4 * Cp, Cp, gk, 4 * R, T * B, R, R, o1, d));
     float* gb = gptr(e, "rnn/lstm_cell/bias");
     for (int g = 0; g < 4; ++g) CK(colsum(st, DT_F32, e->dgt + (size_t)g * Cp, T * B, 4 * Cp, Cp, R, gb + (size_t)g * R));
-    GemmOpt o; o.n_valid = G;
-    CK(gemm_nt(st, DT_F32, {{e->dgt, 4 * Cp, opp(e, "lstm.n"), 4 * Cp, 4 * Cp}}, e->demb, Gp, T * B, Gp, o));
+    {   // demb = dg . W_x^T: a small output ([T*B, G]) over a long reduction (4 Cp) -> split-K as a batched product + one sum
+        const int ks = (4 * Cp) % (8 * 32) == 0 ? 8 : 1, kc = 4 * Cp / ks;
+        GemmOpt o; o.n_valid = G; o.batch = ks; o.sC = (int64_t)T * B * Gp;
+        CK(gemm_nt(st, DT_F32, {{e->dgt, 4 * Cp, opp(e, "lstm.n"), 4 * Cp, kc, (int64_t)kc, (int64_t)kc}}, e->demb_parts, Gp, T * B, Gp, o));
+        const float* p = e->demb_parts; const size_t sl = (size_t)T * B * Gp;
+        if (ks == 8) CK(add_n(st, DT_F32, e->demb, {p, p + sl, p + 2 * sl, p + 3 * sl, p + 4 * sl, p + 5 * sl, p + 6 * sl, p + 7 * sl}, false, (long)sl));
+        else CK(add_n(st, DT_F32, e->demb, {p}, false, (long)sl));
+    }
     return cmpc_embed_scatter(e->demb, Gp, e->words_tb, gptr(e, "Variable"), T * B, G, e->V, st);
 }
 
@@ -724,8 +765,7 @@ int level_fwd(E* e, hipStream_t st, int li, const float* target) {
       GemmOpt b; b.n_valid = C;
       CK(gemm_nt(st, DT_F32, {{L.Wd, Cp, opp(e, t2n), Cp, Cp}}, L.PTf, Cp, B * Tp, Cp, b));
       CK(cmpc_cast(DT_F32, L.PTf, dt, L.PT, (int64_t)B * Tp * Cp, st));
-      CK(gemm_nt(st, DT_F32, {{opp(e, t2n), Cp, L.Wd, Cp, Cp}}, L.PTtf, B * Tp, Cp, B * Tp));
-      CK(cmpc_cast(DT_F32, L.PTtf, dt, L.PTt, (int64_t)Cp * B * Tp, st));
+      CK(transpose_cast(st, L.PTf, dt, L.PTt, B * Tp, Cp));                 // PT^T [Cp][B*Tp] (operand of dX1 += dA0 . PT)
       CK(cmpc_rowdot1(DT_F32, L.Wd, pptr(e, fmt("spa_graph_trans2_%s/biases", lv)), 0, L.k0s, 1, B * Tp, Cp, C, scale, st));
       GemmOpt c; c.batch = B; c.sC = (int64_t)N * Tp; c.c_f32 = 1; c.alpha = scale; c.sbias = L.k0s; c.ld_sbias = Tp; c.rows_per_sample = N;
       CK(gemm_nt(st, dt, {{L.X1, Cp, L.PT, Cp, Cp, (int64_t)N * Cp, (int64_t)Tp * Cp}}, L.A0, Tp, N, Tp, c));
@@ -933,7 +973,7 @@ void clstm_ln(E* e, cmpc_convlstm_ln& ln, cmpc_convlstm_dln& dln) {
         dln.dbeta[i] = gptr(e, p + "/beta"); dln.dgamma[i] = gptr(e, p + "/gamma");
     }
 }
-int clstm_fwd(E* e, hipStream_t st) {
+int clstm_fwd(E* e, hipStream_t st, hipEvent_t* x_ready) {
     const int B = e->B, N = e->N, R = e->R, M = e->M, Mp = e->Mp, dt = e->dt;
     cmpc_convlstm_ln ln; cmpc_convlstm_dln dln; clstm_ln(e, ln, dln);
     const std::string pre = "rnn/conv_lstm_cell/";
@@ -941,6 +981,7 @@ int clstm_fwd(E* e, hipStream_t st) {
     const void *hcur = nullptr, *ccur = nullptr;
     for (int s = 0; s < 3; ++s) {
         ClstmStep& S = e->cl[s];
+        if (x_ready && x_ready[s]) HCK(hipStreamWaitEvent(st, x_ready[s], 0));
         if (s == 0) CK(gemm_nt(st, dt, {{xs[s], Mp, opp(e, "clstm.t"), 2 * Mp, Mp}}, S.Yg, 4 * Mp, R, 4 * Mp));
         else CK(gemm_nt(st, dt, {{xs[s], Mp, opp(e, "clstm.t"), 2 * Mp, Mp}, {hcur, Mp, opp(e, "clstm.t", 0, Mp), 2 * Mp, Mp}}, S.Yg, 4 * Mp, R, 4 * Mp));
         CK(cmpc_convlstm_a(dt, S.Yg, ccur, pptr(e, pre + "W_ci"), pptr(e, pre + "W_cf"), S.sums, B, N, Mp, M, st));
@@ -951,7 +992,7 @@ int clstm_fwd(E* e, hipStream_t st) {
     return CMPC_OK;
 }
 // in: e->dfused (gradient of the last h); out: cl[s].dx = gradient of exg_*_2
-int clstm_bwd(E* e, hipStream_t st) {
+int clstm_bwd(E* e, hipStream_t st, hipEvent_t* dx_ready) {
     const int B = e->B, N = e->N, R = e->R, M = e->M, Mp = e->Mp, dt = e->dt;
     cmpc_convlstm_ln ln; cmpc_convlstm_dln dln; clstm_ln(e, ln, dln);
     const std::string pre = "rnn/conv_lstm_cell/";
@@ -971,6 +1012,7 @@ int clstm_bwd(E* e, hipStream_t st) {
         CK(gemm_tn(e, st, dt, xs[s], Mp, Mp, S.dYg, 4 * Mp, Mp, gk, 4 * M, R, M, M, ox, d));
         GemmOpt o; o.n_valid = M;
         CK(gemm_nt(st, dt, {{S.dYg, 4 * Mp, opp(e, "clstm.n"), 4 * Mp, 4 * Mp}}, S.dx, Mp, R, Mp, o));
+        if (dx_ready && dx_ready[s]) HCK(hipEventRecord(dx_ready[s], st));
         if (s > 0) {
             CK(gemm_tn(e, st, dt, h_prev, Mp, Mp, S.dYg, 4 * Mp, Mp, gk, 4 * M, R, M, M, oh, d));
             CK(gemm_nt(st, dt, {{S.dYg, 4 * Mp, opp(e, "clstm.n", Mp, 0), 4 * Mp, 4 * Mp}}, S.dh, Mp, R, Mp, o));
@@ -982,7 +1024,7 @@ int clstm_bwd(E* e, hipStream_t st) {
 
 int flush_wgrad(E* e, hipStream_t st) {
     if (e->deferred.empty()) return CMPC_OK;
-    const int rc = cmpc_gemm_tn_grouped(e->deferred.data(), (int)e->deferred.size(), st);
+    const int rc = cmpc_gemm_tn_grouped_cached(e->deferred.data(), (int)e->deferred.size(), e->tn_table, e->tn_table_bytes, &e->tn_shadow, st);
     e->deferred.clear();
     return rc;
 }
@@ -1124,6 +1166,9 @@ extern "C" int cmpc_create(const cmpc_cfg* c, cmpc_handle* out) {
     ECK(hipEventCreateWithFlags(&e->ev_opt1, hipEventDisableTiming));
 #undef ECK
     e->deferred.reserve(256);
+    e->fold_descs.resize(e->fold.table_cap); e->fold_shadow.resize(e->fold.table_cap);
+    e->fold.descs = e->fold_descs.data(); e->fold.shadow = e->fold_shadow.data();
+    e->fold.lo = e->grads; e->fold.hi = e->grads + e->total;
     *out = e;
     return CMPC_OK;
 }
@@ -1283,9 +1328,12 @@ extern "C" int cmpc_forward(cmpc_handle e, const cmpc_feeds* f, const cmpc_fetch
     CK(join_lanes(e, main));
     const void* ez[3] = {e->ex[0].out, e->ex[1].out, e->ex[2].out};
     CK(fork_lanes(e, main, st));
-    for (int i = 0; i < 3; ++i) CK(exchange_fwd(e, st[i], 3 + i, ez[i], ez[o1[i]], ez[o2[i]]));
-    CK(join_lanes(e, main));
-    CK(clstm_fwd(e, main));
+    hipEvent_t ex2_done[3] = {nullptr, nullptr, nullptr};
+    for (int i = 0; i < 3; ++i) {
+        CK(exchange_fwd(e, st[i], 3 + i, ez[i], ez[o1[i]], ez[o2[i]]));
+        if (e->cfg.n_lanes > 1) { ex2_done[i] = next_event(e); HCK(hipEventRecord(ex2_done[i], st[i])); }
+    }
+    CK(clstm_fwd(e, main, ex2_done));            // ConvLSTM step s only waits for the round-2 module s that feeds it
     CK(cmpc_score_conv_fwd(e->dt, e->cl[2].h_new, pptr(e, "score/DW"), pptr(e, "score/biases"), e->score, B, e->h, e->w, e->Mp, e->M, main));
     CK(cmpc_upsample_fwd(e->score, e->up, e->sigm, f->target_fine, e->loss, e->iu, e->iu + B, B, e->h, e->w, e->H, e->W, main));
     if (e->have_target) {
@@ -1317,18 +1365,26 @@ extern "C" int cmpc_backward(cmpc_handle e, void* stream) {
     const float* target = e->target_feed;
     HCK(hipMemsetAsync(e->ws + e->zf_bytes, 0, e->zb_bytes, main));
     HCK(hipMemsetAsync(e->grads, 0, (size_t)e->total * sizeof(float), main));
+    cmpc_fold_begin(&e->fold);
+    struct FoldGuard { ~FoldGuard() { cmpc_fold_begin(nullptr); } } fold_guard;      // an early error return must not leave the collector on
     // final score head + ConvLSTM
     CK(cmpc_upsample_loss_bwd(e->up, target, e->dscore, e->cfg.loss_w[0] * e->cfg.loss_scale / B, B, e->h, e->w, e->H, e->W, main));
     CK(cmpc_score_conv_bwd(dt, e->dscore, e->cl[2].h_new, pptr(e, "score/DW"), e->dfused, 0, gptr(e, "score/DW"), gptr(e, "score/biases"),
                            B, e->h, e->w, Mp, e->M, main));
-    CK(clstm_bwd(e, main));
     const int o1[3] = {1, 0, 0}, o2[3] = {2, 2, 1};
     const void* fz[3] = {e->lv[2].F, e->lv[1].F, e->lv[0].F};
     const void* ez[3] = {e->ex[0].out, e->ex[1].out, e->ex[2].out};
     hipStream_t st[3];
-    // exchange round 2
-    CK(fork_lanes(e, main, st));
-    for (int i = 0; i < 3; ++i) CK(exchange_bwd(e, st[i], 3 + i, e->cl[i].dx, ez[i], ez[o1[i]], ez[o2[i]]));
+    // ConvLSTM backward (steps 2, 1, 0 on main); the round-2 exchange module s starts on its lane as soon as step s has
+    // produced its input gradient
+    hipEvent_t dx_ready[3] = {nullptr, nullptr, nullptr};
+    if (e->cfg.n_lanes > 1) for (int i = 0; i < 3; ++i) dx_ready[i] = next_event(e);
+    CK(clstm_bwd(e, main, dx_ready));
+    for (int i = 0; i < 3; ++i) {
+        st[i] = e->cfg.n_lanes > 1 ? e->lane[i] : main;
+        if (dx_ready[i]) HCK(hipStreamWaitEvent(st[i], dx_ready[i], 0));
+        CK(exchange_bwd(e, st[i], 3 + i, e->cl[i].dx, ez[i], ez[o1[i]], ez[o2[i]]));
+    }
     CK(join_lanes(e, main));
     // gradient of input j of a round = dfeat of module j + the f1 / f2 gradients of the two modules that read it
     auto fan_in = [&](int base, int j, const void* (&src)[3]) {
@@ -1369,6 +1425,7 @@ extern "C" int cmpc_backward(cmpc_handle e, void* stream) {
     CK(parser_bwd(e, main));
     CK(text_bwd(e, main, e->seq_len_feed));
     CK(flush_wgrad(e, main));
+    CK(cmpc_fold_flush(&e->fold, main));
     e->last_main = main;
     e->launches_step = g_cmpc_launches - e->l0;
     return CMPC_OK;

@@ -499,7 +499,9 @@ extern "C" int cmpc_convlstm_bwd(int dt, const void* dh, const void* dc_new, con
         if (cmpc_reduce_parts_f32(part + (2 * q) * ld, 4 * ld, 1, (int)nwg, 1, ld, M, dln->dgamma[3 + q], 0, 0, 1, ST)) return CMPC_EHIP;
         if (cmpc_reduce_parts_f32(part + (2 * q + 1) * ld, 4 * ld, 1, (int)nwg, 1, ld, M, dln->dbeta[3 + q], 0, 0, 1, ST)) return CMPC_EHIP;
     }
-    // pass 2: finish o, c; cell update; LN(j,i,f) dxhat + statistics
+    // pass 2: finish o, c; cell update; LN(j,i,f) dxhat + statistics.  Fresh partial rows: pass 1's may still be waiting for
+    // a deferred fold (cmpc_fold_begin); without a collector this returns the same per-stream block, as before.
+    if (clstm_ws(nwg, 6, 3, ld, &part, &dpart, ST)) return CMPC_EHIP;
     CLSTM_NB(ld, CMPC_DISPATCH_DT(dt, hipLaunchKernelGGL((clstm_bwd2_kernel<T, NBX>), dim3(gx, B), dim3(256), lds, ST,
                            (const T*)Yg, (const T*)c_prev, (const T*)c_pre, W_co, to_lnp(ln), sums, bsums, (T*)dYg, (const T*)scr, (T*)dc_prev,
                            part, dpart, B, N, ld, M)));

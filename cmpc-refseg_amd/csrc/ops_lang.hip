@@ -160,53 +160,66 @@ __global__ void parse_softmax_bwd_kernel(const float* __restrict__ dparse, const
     for (int k = 4; k < ld; ++k) dlogits[(long)r * ld + k] = 0.f;
 }
 
-__global__ __launch_bounds__(256) void lang_pool_fwd_kernel(const float* __restrict__ parse, const float* __restrict__ wf, float* __restrict__ v,
-                                                           float* __restrict__ rstd, int T, int ld, int R, int ncls) {
-    __shared__ float red[4];
-    const int b = blockIdx.x;
+// valid_lang / nec_lang (CMPC_model.py:166-192): v[b] = l2norm(sum_t w[b,t] wf[b,t,:]), w = sum of the first ncls parser classes.
+// One 1024-thread block per sample: thread = 1..4 columns, the T word weights staged in LDS, the T loads of a column independent.
+__global__ __launch_bounds__(1024) void lang_pool_fwd_kernel(const float* __restrict__ parse, const float* __restrict__ wf, float* __restrict__ v,
+                                                            float* __restrict__ rstd, int T, int ld, int R, int ncls) {
+    __shared__ float wgt[64];
+    __shared__ float red[16];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    if (tid < T) {
+        float w = 0.f;
+        for (int k = 0; k < ncls; ++k) w += parse[((long)b * T + tid) * 4 + k];
+        wgt[tid] = w;
+    }
+    __syncthreads();
+    float mine[2] = {0.f, 0.f};                 // ld <= 2048
     float ss = 0.f;
-    for (int c = threadIdx.x; c < ld; c += 256) {
+    for (int i = 0, c = tid; c < ld; c += 1024, ++i) {
         float acc = 0.f;
         if (c < R) {
-            for (int t = 0; t < T; ++t) {
-                float wgt = 0.f;
-                for (int k = 0; k < ncls; ++k) wgt += parse[((long)b * T + t) * 4 + k];
-                acc += wgt * wf[((long)b * T + t) * ld + c];
-            }
+            const float* col = wf + (long)b * T * ld + c;
+#pragma unroll 4
+            for (int t = 0; t < T; ++t) acc += wgt[t] * col[(long)t * ld];
         }
-        v[(long)b * ld + c] = acc;
+        mine[i] = acc;
         ss += acc * acc;
     }
-    ss = block_sum_256(ss, red);
+    ss = wave_sum(ss);
+    if ((tid & 63) == 0) red[tid >> 6] = ss;
+    __syncthreads();
+    ss = 0.f;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) ss += red[w];
     const float rs = rsqrtf(fmaxf(ss, 1e-12f));
-    for (int c = threadIdx.x; c < ld; c += 256) v[(long)b * ld + c] *= rs;
-    if (threadIdx.x == 0) rstd[b] = (ss < 1e-12f) ? -rs : rs;
+    for (int i = 0, c = tid; c < ld; c += 1024, ++i) v[(long)b * ld + c] = mine[i] * rs;
+    if (tid == 0) rstd[b] = (ss < 1e-12f) ? -rs : rs;
 }
 
+// backward: one block per (sample, word).  draw = |rstd| (dv - v (v.dv)) is recomputed per word (R values);
+// dparse[b,t,k<ncls] += draw . wf[b,t,:];  dwf[b,t,:] += w[b,t] draw.   (both accumulate: the two pools share the buffers)
 __global__ __launch_bounds__(256) void lang_pool_bwd_kernel(const float* __restrict__ dv, const float* __restrict__ v, const float* __restrict__ rstd,
                                                            const float* __restrict__ parse, const float* __restrict__ wf,
                                                            float* __restrict__ dparse, float* __restrict__ dwf, int T, int ld, int R, int ncls) {
     __shared__ float red[4];
-    const int b = blockIdx.x;
+    const int b = blockIdx.x, t = blockIdx.y;
     float dot = 0.f;
     for (int c = threadIdx.x; c < R; c += 256) dot += dv[(long)b * ld + c] * v[(long)b * ld + c];
     dot = block_sum_256(dot, red);
     const float rs = rstd[b], a = fabsf(rs);
     if (rs < 0.f) dot = 0.f;
-    for (int t = 0; t < T; ++t) {
-        float wgt = 0.f;
-        for (int k = 0; k < ncls; ++k) wgt += parse[((long)b * T + t) * 4 + k];
-        float dw = 0.f;
-        for (int c = threadIdx.x; c < R; c += 256) {
-            const float draw = a * (dv[(long)b * ld + c] - v[(long)b * ld + c] * dot);
-            const long o = ((long)b * T + t) * ld + c;
-            dw += draw * wf[o];
-            dwf[o] += wgt * draw;
-        }
-        dw = block_sum_256(dw, red);
-        if (threadIdx.x == 0)
-            for (int k = 0; k < ncls; ++k) dparse[((long)b * T + t) * 4 + k] += dw;
+    float wgt = 0.f;
+    for (int k = 0; k < ncls; ++k) wgt += parse[((long)b * T + t) * 4 + k];
+    float dw = 0.f;
+    for (int c = threadIdx.x; c < R; c += 256) {
+        const float draw = a * (dv[(long)b * ld + c] - v[(long)b * ld + c] * dot);
+        const long o = ((long)b * T + t) * ld + c;
+        dw += draw * wf[o];
+        dwf[o] += wgt * draw;
     }
+    dw = block_sum_256(dw, red);
+    if (threadIdx.x == 0)
+        for (int k = 0; k < ncls; ++k) dparse[((long)b * T + t) * 4 + k] += dw;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -357,13 +370,14 @@ extern "C" int cmpc_parse_softmax_bwd(const float* dparse, const float* parse, c
 }
 extern "C" int cmpc_lang_pool_fwd(const float* parse, const float* wf, float* v, float* rstd, int B, int T, int ld, int R, int ncls, void* stream) {
     if (ncls < 1 || ncls > 4) { cmpc_set_error("lang_pool: ncls must be 1..4"); return CMPC_EINVAL; }
-    hipLaunchKernelGGL(lang_pool_fwd_kernel, dim3(B), dim3(256), 0, ST, parse, wf, v, rstd, T, ld, R, ncls);
+    if (T > 64 || ld > 2048) { cmpc_set_error("lang_pool: T <= 64 and ld <= 2048"); return CMPC_EINVAL; }
+    hipLaunchKernelGGL(lang_pool_fwd_kernel, dim3(B), dim3(1024), 0, ST, parse, wf, v, rstd, T, ld, R, ncls);
     return cmpc_check_launch("lang_pool_fwd");
 }
 extern "C" int cmpc_lang_pool_bwd(const float* dv, const float* v, const float* rstd, const float* parse, const float* wf,
                                   float* dparse, float* dwf, int B, int T, int ld, int R, int ncls, void* stream) {
     if (ncls < 1 || ncls > 4) { cmpc_set_error("lang_pool: ncls must be 1..4"); return CMPC_EINVAL; }
-    hipLaunchKernelGGL(lang_pool_bwd_kernel, dim3(B), dim3(256), 0, ST, dv, v, rstd, parse, wf, dparse, dwf, T, ld, R, ncls);
+    hipLaunchKernelGGL(lang_pool_bwd_kernel, dim3(B, T), dim3(256), 0, ST, dv, v, rstd, parse, wf, dparse, dwf, T, ld, R, ncls);
     return cmpc_check_launch("lang_pool_bwd");
 }
 

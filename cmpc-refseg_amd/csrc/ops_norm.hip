@@ -6,6 +6,7 @@
 #include "../../include/cmpc.h"
 #include <stdarg.h>
 #include <stdio.h>
+#include <string.h>
 
 // ------------------------------------------------------------------------------------------
 // error plumbing shared by all translation units
@@ -25,7 +26,13 @@ extern "C" const char* cmpc_last_error(void) { return g_err; }
 
 struct WsSlot { hipStream_t st; void* p; size_t bytes; bool used; };
 static WsSlot g_ws[64];
+static thread_local cmpc_fold_ctx* t_fold = nullptr;
+void cmpc_fold_begin(cmpc_fold_ctx* ctx) { t_fold = ctx; if (ctx) { ctx->off = 0; ctx->n = 0; } }
 void* cmpc_ws(size_t bytes, hipStream_t st) {
+    if (t_fold) {                       // collecting deferred folds: partial rows must survive until cmpc_fold_flush
+        const size_t need = (bytes + 255) / 256 * 256;
+        if (t_fold->off + need <= t_fold->cap) { void* p = t_fold->arena + t_fold->off; t_fold->off += need; return p; }
+    }
     WsSlot* slot = nullptr;
     for (auto& w : g_ws) if (w.used && w.st == st) { slot = &w; break; }
     if (!slot) {
@@ -88,10 +95,67 @@ __global__ __launch_bounds__(64) void reduce_parts_f64_kernel(const double* __re
         if (lane == 0) out[(long)o * nval + v] = s;
     }
 }
+// every recorded fold in one launch: a block owns 64 columns of one (fold, outer index) and walks ALL its partial rows in a fixed
+// order (no split of a column between blocks), so a fold's result does not depend on scheduling; folds that share a target meet
+// in the final atomic add
+__global__ __launch_bounds__(256) void reduce_parts_grouped_kernel(const cmpc_fold_desc* __restrict__ table, int ndesc) {
+    __shared__ float red[4][64];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    int lo = 0, hi = ndesc;
+    const int blk = blockIdx.x;
+    while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (table[mid].blk_begin <= blk) lo = mid; else hi = mid; }
+    const cmpc_fold_desc d = table[lo];
+    const int cols = d.nseg * d.seg_ld, cb = (cols + 63) / 64;
+    const int local = blk - d.blk_begin, o = local / cb, j = (local % cb) * 64 + lane;
+    const bool ok = j < cols;
+    const int seg = ok ? j / d.seg_ld : 0, c = ok ? j - seg * d.seg_ld : 0;
+    const bool valid = ok && c < d.seg_C;
+    const float* p = d.part + (long)o * d.ninner * d.part_stride + j;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    if (valid) {
+        int i = w;
+        for (; i + 12 < d.ninner; i += 16) {
+            s0 += p[(long)i * d.part_stride]; s1 += p[(long)(i + 4) * d.part_stride];
+            s2 += p[(long)(i + 8) * d.part_stride]; s3 += p[(long)(i + 12) * d.part_stride];
+        }
+        for (; i < d.ninner; i += 4) s0 += p[(long)i * d.part_stride];
+    }
+    red[w][lane] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    if (w == 0 && valid) {
+        const float s = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+        if (s != 0.f) atomicAdd(d.out + (long)o * d.ld_out + (long)seg * d.out_seg + c, s);
+    }
+}
+int cmpc_fold_flush(cmpc_fold_ctx* ctx, hipStream_t st) {
+    t_fold = nullptr;
+    if (!ctx || ctx->n == 0) return CMPC_OK;
+    int blocks = 0;
+    for (int i = 0; i < ctx->n; ++i) {
+        cmpc_fold_desc& d = ctx->descs[i];
+        d.blk_begin = blocks;
+        blocks += ((d.nseg * d.seg_ld + 63) / 64) * d.nouter;
+    }
+    if (ctx->shadow_n != ctx->n || memcmp(ctx->shadow, ctx->descs, sizeof(cmpc_fold_desc) * ctx->n) != 0) {
+        if (hipMemcpyAsync(ctx->table_dev, ctx->descs, sizeof(cmpc_fold_desc) * ctx->n, hipMemcpyHostToDevice, st) != hipSuccess) {
+            cmpc_set_error("fold_flush: descriptor upload failed"); return CMPC_EHIP;
+        }
+        memcpy(ctx->shadow, ctx->descs, sizeof(cmpc_fold_desc) * ctx->n);
+        ctx->shadow_n = ctx->n;
+    }
+    hipLaunchKernelGGL(reduce_parts_grouped_kernel, dim3(blocks), dim3(256), 0, st, ctx->table_dev, ctx->n);
+    return cmpc_check_launch("reduce_parts_grouped");
+}
 int cmpc_reduce_parts_f32(const float* part, long part_stride, int nouter, int ninner, int nseg, int seg_ld, int seg_C,
                           float* out, long ld_out, long out_seg, int accumulate, hipStream_t st) {
     const int cols = nseg * seg_ld;
     if (!accumulate) { cmpc_set_error("reduce_parts_f32: only the accumulating form is implemented"); return CMPC_EINVAL; }
+    if (t_fold && out >= t_fold->lo && out < t_fold->hi && t_fold->n < t_fold->table_cap &&
+        (const char*)part >= t_fold->arena && (const char*)part < t_fold->arena + t_fold->cap) {
+        // the target is read by nothing before the optimizer and the partial rows are not recycled: fold later, with all the others
+        t_fold->descs[t_fold->n++] = cmpc_fold_desc{part, part_stride, nouter, ninner, nseg, seg_ld, seg_C, 0, out, ld_out, out_seg};
+        return CMPC_OK;
+    }
     int nz = ninner / 32; nz = nz < 1 ? 1 : (nz > 16 ? 16 : nz);
     hipLaunchKernelGGL(reduce_parts_f32_kernel, dim3((cols + 63) / 64, nouter, nz), dim3(256), 0, st, part, part_stride, ninner, nseg, seg_ld, seg_C,
                        out, ld_out, out_seg);
