@@ -186,6 +186,8 @@ SIGNATURES = {
     "cmpc_tap": [_P, C.c_char_p, _PP, C.POINTER(_I), C.POINTER(_I), C.POINTER(_L * 4)],
     "cmpc_tap_name": [_P, _I, C.POINTER(C.c_char_p)],
     "cmpc_launch_count": [_P, C.POINTER(_L)],
+    "cmpc_phase_marks": [_P, _I],
+    "cmpc_phase_marks_read": [_P, _I, C.POINTER(C.c_char_p), C.POINTER(C.c_float)],
     "cmpc_set_lanes": [_P, _I],
     "cmpc_kernel_timing": [_P, _I],
     "cmpc_kernel_timing_read": [_P, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(_L)],

@@ -28,9 +28,10 @@ void* cmpc_ws(size_t bytes, hipStream_t st);
 // out[o*ld_out + seg*out_seg + c] (+)= sum_{i<ninner} part[(o*ninner+i)*part_stride + seg*seg_ld + c], c < seg_C
 int cmpc_reduce_parts_f32(const float* part, long part_stride, int nouter, int ninner, int nseg, int seg_ld, int seg_C,
                           float* out, long ld_out, long out_seg, int accumulate, hipStream_t st);
-// cmpc_gemm_tn_grouped with a caller-owned persistent descriptor table (device) and a host copy of its contents: uploaded only when
-// the descriptors change
-int cmpc_gemm_tn_grouped_cached(const void* args /* cmpc_gemm_tn_args[n] */, int n, void* table_dev, size_t table_bytes, std::vector<char>* shadow, hipStream_t st);
+// cmpc_gemm_tn_grouped with `nslots` caller-owned persistent descriptor tables (device) and host copies of their contents: a step
+// whose descriptors equal a cached table reuses it; otherwise slot *victim (round robin) is rewritten (asynchronously)
+int cmpc_gemm_tn_grouped_cached(const void* args /* cmpc_gemm_tn_args[n] */, int n, void* const* tables_dev, int nslots, int* victim, size_t table_bytes,
+                                std::vector<char>* shadows, hipStream_t st);
 // Deferred folds.  Column sums whose target lies in [lo, hi) (the flat gradient buffer: bias, LayerNorm and peephole gradients, read by
 // nothing before the optimizer) need not be folded right behind their producer: between cmpc_fold_begin and cmpc_fold_flush (same host
 // thread) cmpc_ws hands out NON-recycled pieces of `arena`, cmpc_reduce_parts_f32 records such folds instead of launching them, and

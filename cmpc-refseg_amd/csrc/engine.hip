@@ -18,6 +18,7 @@
 #include <stdarg.h>
 #include <stdio.h>
 #include <array>
+#include <stdlib.h>
 #include <string.h>
 #include <algorithm>
 #include <string>
@@ -191,13 +192,17 @@ struct cmpc_engine_s {
     const int32_t* seq_len_feed = nullptr; const float* target_feed = nullptr;      // caller-owned feeds the backward pass re-reads
     hipStream_t last_main = nullptr; long l0 = 0;
     std::vector<cmpc_gemm_tn_args> deferred;
-    void* tn_table = nullptr; size_t tn_table_bytes = 0; std::vector<char> tn_shadow;      // descriptor table of the grouped dW launch
+    // descriptor tables of the two grouped dW launches of a step; 4 cached variants each (the backbone taps alternate between two
+    // buffer sets, so the lateral products' operand pointers alternate): a table that matches a cached one is not uploaded again
+    void* tn_table[2][4] = {}; size_t tn_table_bytes = 0; std::vector<char> tn_shadow[2][4]; int tn_victim[2] = {0, 0};
+    bool wgrad_overlap = true;          // issue the levels' / exchanges' dW beside the text encoder's backward chain
     cmpc_fold_ctx fold;                 // deferred bias / LayerNorm / peephole gradient folds (one launch per backward pass)
     std::vector<cmpc_fold_desc> fold_descs, fold_shadow;
     std::vector<Tap> taps;
     std::unordered_map<std::string, int> tapindex;
     long launches_step = 0;
     // optional per-launch timing of the dominant kernel family (bench.py's roofline): event pairs around every bf16 MFMA gemm_nt
+    bool marks_on = false; std::vector<std::pair<std::string, hipEvent_t>> marks;     // phase-boundary timestamps (cmpc_phase_marks)
     bool timing = false; std::vector<hipEvent_t> tev; std::vector<double> tflops, tbytes;
 };
 
@@ -527,7 +532,8 @@ void plan_workspace(E* e, Bump& zf, Bump& zb, Bump& g) {
     e->loss = (float*)zf.take((size_t)B * F); e->iu = (int*)zf.take((size_t)2 * B * 4);
     e->dscore = (float*)g.take((size_t)B * e->h * e->w * F); e->dfused = g.take((size_t)R * Mp * es);
     e->scalars = (float*)g.take(256);
-    e->tn_table_bytes = (size_t)256 << 10; e->tn_table = g.take(e->tn_table_bytes);
+    e->tn_table_bytes = (size_t)128 << 10;
+    for (int a = 0; a < 2; ++a) for (int b = 0; b < 4; ++b) e->tn_table[a][b] = g.take(e->tn_table_bytes);
     e->fold.cap = (size_t)512 << 20;                       // partial rows of the deferred folds (~2 MB each, ~110 per step)
     e->fold.arena = (char*)g.take(e->fold.cap);
     e->fold.table_cap = 1024;
@@ -541,6 +547,16 @@ void plan_workspace(E* e, Bump& zf, Bump& zb, Bump& g) {
 // launch helpers
 // ------------------------------------------------------------------------------------------
 hipEvent_t next_event(E* e) { hipEvent_t ev = e->evpool[e->evnext]; e->evnext = (e->evnext + 1) % e->evpool.size(); return ev; }
+
+// phase-boundary timestamp on a stream (only while cmpc_phase_marks is enabled; no profiler, so the overlap is the real one)
+int mark(E* e, const char* name, hipStream_t st) {
+    if (!e->marks_on) return CMPC_OK;
+    hipEvent_t ev = nullptr;
+    HCK(hipEventCreate(&ev));
+    HCK(hipEventRecord(ev, st));
+    e->marks.emplace_back(name, ev);
+    return CMPC_OK;
+}
 
 // lane streams wait for everything queued so far on `from`
 int fork_lanes(E* e, hipStream_t from, hipStream_t (&st)[3]) {
@@ -1022,9 +1038,10 @@ int clstm_bwd(E* e, hipStream_t st, hipEvent_t* dx_ready) {
     return CMPC_OK;
 }
 
-int flush_wgrad(E* e, hipStream_t st) {
+int flush_wgrad(E* e, hipStream_t st, int slot = 0) {
     if (e->deferred.empty()) return CMPC_OK;
-    const int rc = cmpc_gemm_tn_grouped_cached(e->deferred.data(), (int)e->deferred.size(), e->tn_table, e->tn_table_bytes, &e->tn_shadow, st);
+    const int rc = cmpc_gemm_tn_grouped_cached(e->deferred.data(), (int)e->deferred.size(), e->tn_table[slot], 4, &e->tn_victim[slot], e->tn_table_bytes,
+                                               e->tn_shadow[slot], st);
     e->deferred.clear();
     return rc;
 }
@@ -1166,6 +1183,7 @@ extern "C" int cmpc_create(const cmpc_cfg* c, cmpc_handle* out) {
     ECK(hipEventCreateWithFlags(&e->ev_opt1, hipEventDisableTiming));
 #undef ECK
     e->deferred.reserve(256);
+    if (const char* v = getenv("CMPC_WGRAD_OVERLAP")) e->wgrad_overlap = atoi(v) != 0;       // read once, at create
     e->fold_descs.resize(e->fold.table_cap); e->fold_shadow.resize(e->fold.table_cap);
     e->fold.descs = e->fold_descs.data(); e->fold.shadow = e->fold_shadow.data();
     e->fold.lo = e->grads; e->fold.hi = e->grads + e->total;
@@ -1266,6 +1284,23 @@ extern "C" int cmpc_get_cfg(cmpc_handle e, cmpc_cfg* out) {
     *out = e->cfg;
     return CMPC_OK;
 }
+extern "C" int cmpc_phase_marks(cmpc_handle e, int enable) {
+    if (!e) { cmpc_set_error("phase_marks: null handle"); return CMPC_EINVAL; }
+    for (auto& m : e->marks) (void)hipEventDestroy(m.second);
+    e->marks.clear();
+    e->marks_on = enable != 0;
+    return CMPC_OK;
+}
+extern "C" int cmpc_phase_marks_read(cmpc_handle e, int index, const char** name, float* ms_since_first) {
+    if (!e || index < 0 || index >= (int)e->marks.size()) return CMPC_EINVAL;       // also the end-of-list signal
+    CK(set_device(e));
+    HCK(hipEventSynchronize(e->marks[index].second));
+    float ms = 0.f;
+    HCK(hipEventElapsedTime(&ms, e->marks[0].second, e->marks[index].second));
+    if (name) *name = e->marks[index].first.c_str();
+    if (ms_since_first) *ms_since_first = ms;
+    return CMPC_OK;
+}
 extern "C" int cmpc_set_lanes(cmpc_handle e, int n_lanes) {
     if (!e || (n_lanes != 1 && n_lanes != 3)) { cmpc_set_error("set_lanes: n_lanes must be 1 or 3"); return CMPC_EINVAL; }
     e->cfg.n_lanes = n_lanes;
@@ -1309,15 +1344,19 @@ extern "C" int cmpc_forward(cmpc_handle e, const cmpc_feeds* f, const cmpc_fetch
     e->deferred.clear();
     e->lv[0].feat = f->c5; e->lv[1].feat = f->c4; e->lv[2].feat = f->c3;
     CK(params_ready(e, main, 0));
+    CK(mark(e, "fwd:start", main));
     HCK(hipMemsetAsync(e->ws, 0, e->zf_bytes, main));                         // every accumulate-into buffer of the forward pass
     CK(text_fwd(e, main, f->words, f->seq_len));
     CK(parser_fwd(e, main));
     CK(cmpc_lang_pool_fwd(e->parse, e->wf, e->vl, e->vl_rstd, B, e->T, Cp, e->RNN, 2, main));      // valid_lang: entity + attribute
     CK(params_ready(e, main, 1));
+    CK(mark(e, "fwd:text_done", main));
     if (f->feats_ready) HCK(hipStreamWaitEvent(main, (hipEvent_t)f->feats_ready, 0));
+    CK(mark(e, "fwd:feats_ready", main));
     hipStream_t st[3];
     CK(fork_lanes(e, main, st));
-    for (int i = 0; i < 3; ++i) CK(level_fwd(e, st[i], i, f->target_fine));
+    const char* lvm[3] = {"fwd:level_c5_done", "fwd:level_c4_done", "fwd:level_c3_done"};
+    for (int i = 0; i < 3; ++i) { CK(level_fwd(e, st[i], i, f->target_fine)); CK(mark(e, lvm[i], st[i])); }
     CK(join_lanes(e, main));
     CK(cmpc_lang_pool_fwd(e->parse, e->wf, e->nec, e->nec_rstd, B, e->T, Cp, e->RNN, 3, main));    // nec_lang: + relation
     // gated_exchange_fusion_lstm_2times (:261-293): fusion maps in EXG order c3, c4, c5 = lv[2], lv[1], lv[0]
@@ -1326,6 +1365,7 @@ extern "C" int cmpc_forward(cmpc_handle e, const cmpc_feeds* f, const cmpc_fetch
     CK(fork_lanes(e, main, st));
     for (int i = 0; i < 3; ++i) CK(exchange_fwd(e, st[i], i, fz[i], fz[o1[i]], fz[o2[i]]));
     CK(join_lanes(e, main));
+    CK(mark(e, "fwd:exch1_done", main));
     const void* ez[3] = {e->ex[0].out, e->ex[1].out, e->ex[2].out};
     CK(fork_lanes(e, main, st));
     hipEvent_t ex2_done[3] = {nullptr, nullptr, nullptr};
@@ -1334,6 +1374,7 @@ extern "C" int cmpc_forward(cmpc_handle e, const cmpc_feeds* f, const cmpc_fetch
         if (e->cfg.n_lanes > 1) { ex2_done[i] = next_event(e); HCK(hipEventRecord(ex2_done[i], st[i])); }
     }
     CK(clstm_fwd(e, main, ex2_done));            // ConvLSTM step s only waits for the round-2 module s that feeds it
+    CK(mark(e, "fwd:clstm_done", main));
     CK(cmpc_score_conv_fwd(e->dt, e->cl[2].h_new, pptr(e, "score/DW"), pptr(e, "score/biases"), e->score, B, e->h, e->w, e->Mp, e->M, main));
     CK(cmpc_upsample_fwd(e->score, e->up, e->sigm, f->target_fine, e->loss, e->iu, e->iu + B, B, e->h, e->w, e->H, e->W, main));
     if (e->have_target) {
@@ -1346,6 +1387,7 @@ extern "C" int cmpc_forward(cmpc_handle e, const cmpc_feeds* f, const cmpc_fetch
         if (fetch->up) HCK(hipMemcpyAsync(fetch->up, e->up, (size_t)B * e->H * e->W * 4, hipMemcpyDeviceToDevice, main));
         if (fetch->sigm) HCK(hipMemcpyAsync(fetch->sigm, e->sigm, (size_t)B * e->H * e->W * 4, hipMemcpyDeviceToDevice, main));
     }
+    CK(mark(e, "fwd:end", main));
     e->launches_step = g_cmpc_launches - e->l0;
     return CMPC_OK;
 }
@@ -1354,8 +1396,13 @@ extern "C" int cmpc_forward(cmpc_handle e, const cmpc_feeds* f, const cmpc_fetch
 // backward: reverse stage order; a stage output consumed by several stages gets the SUM of their input gradients
 // (add_n), exactly what tf.gradients' AddN nodes do for CMPC_model.py:447.
 // ------------------------------------------------------------------------------------------
+#include <chrono>
+static double host_now() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+#define HOSTPROF(tag) do { if (hp) { const double t_ = host_now(); fprintf(stderr, "[host] %-14s %7.3f ms\n", tag, t_ - hp_t); hp_t = t_; } } while (0)
 extern "C" int cmpc_backward(cmpc_handle e, void* stream) {
     if (!e) { cmpc_set_error("backward: null handle"); return CMPC_EINVAL; }
+    static const bool hp = getenv("CMPC_HOST_PROFILE") != nullptr;
+    double hp_t = host_now();
     if (!e->have_target || !e->seq_len_feed) { cmpc_set_error("backward: the last cmpc_forward had no target_fine"); return CMPC_EINVAL; }
     CK(set_device(e));
     hipStream_t main = (hipStream_t)stream;
@@ -1363,8 +1410,10 @@ extern "C" int cmpc_backward(cmpc_handle e, void* stream) {
     const int B = e->B, T = e->T, Cp = e->Cp, Mp = e->Mp, dt = e->dt;
     const long nmap = (long)e->R * Mp;
     const float* target = e->target_feed;
+    CK(mark(e, "bwd:start", main));
     HCK(hipMemsetAsync(e->ws + e->zf_bytes, 0, e->zb_bytes, main));
     HCK(hipMemsetAsync(e->grads, 0, (size_t)e->total * sizeof(float), main));
+    HOSTPROF("memsets");
     cmpc_fold_begin(&e->fold);
     struct FoldGuard { ~FoldGuard() { cmpc_fold_begin(nullptr); } } fold_guard;      // an early error return must not leave the collector on
     // final score head + ConvLSTM
@@ -1380,12 +1429,16 @@ extern "C" int cmpc_backward(cmpc_handle e, void* stream) {
     hipEvent_t dx_ready[3] = {nullptr, nullptr, nullptr};
     if (e->cfg.n_lanes > 1) for (int i = 0; i < 3; ++i) dx_ready[i] = next_event(e);
     CK(clstm_bwd(e, main, dx_ready));
+    CK(mark(e, "bwd:clstm_done", main));
+    HOSTPROF("clstm");
     for (int i = 0; i < 3; ++i) {
         st[i] = e->cfg.n_lanes > 1 ? e->lane[i] : main;
         if (dx_ready[i]) HCK(hipStreamWaitEvent(st[i], dx_ready[i], 0));
         CK(exchange_bwd(e, st[i], 3 + i, e->cl[i].dx, ez[i], ez[o1[i]], ez[o2[i]]));
     }
     CK(join_lanes(e, main));
+    CK(mark(e, "bwd:exch2_done", main));
+    HOSTPROF("exch2");
     // gradient of input j of a round = dfeat of module j + the f1 / f2 gradients of the two modules that read it
     auto fan_in = [&](int base, int j, const void* (&src)[3]) {
         int n = 0;
@@ -1406,6 +1459,8 @@ extern "C" int cmpc_backward(cmpc_handle e, void* stream) {
         CK(exchange_bwd(e, st[j], j, e->de1[j], fz[j], fz[o1[j]], fz[o2[j]]));
     }
     CK(join_lanes(e, main));
+    CK(mark(e, "bwd:exch1_done", main));
+    HOSTPROF("exch1");
     // pyramid levels (lane i = level i = c5, c4, c3 = exchange input 2 - i); the language-side sums run on main meanwhile
     CK(fork_lanes(e, main, st));
     CK(add_n(main, DT_F32, e->dnec, {e->ex[0].dnec, e->ex[1].dnec, e->ex[2].dnec, e->ex[3].dnec, e->ex[4].dnec, e->ex[5].dnec}, false, (long)B * Cp));
@@ -1415,8 +1470,25 @@ extern "C" int cmpc_backward(cmpc_handle e, void* stream) {
         fan_in(0, 2 - i, src);
         CK(add_n(st[i], dt, e->lv[i].dfus, {src[0], src[1], src[2]}, false, nmap));
         CK(level_bwd(e, st[i], i, target));
+        const char* lvb[3] = {"bwd:level_c5_done", "bwd:level_c4_done", "bwd:level_c3_done"};
+        CK(mark(e, lvb[i], st[i]));
     }
     CK(join_lanes(e, main));
+    HOSTPROF("levels");
+    // Every weight-gradient product queued so far (levels, exchanges, ConvLSTM: ~1.7 ms of MFMA work) has its operands complete:
+    // issue it on lane 0 now, beside the text encoder's backward (a serial chain of ~60 small launches on `main` that leaves
+    // the chip nearly idle); the text encoder's own few products follow in a second, small launch.
+    hipEvent_t wg_done = nullptr;
+    if (e->cfg.n_lanes > 1 && e->wgrad_overlap) {
+        hipEvent_t ev = next_event(e);
+        HCK(hipEventRecord(ev, main));
+        HCK(hipStreamWaitEvent(e->lane[0], ev, 0));
+        CK(flush_wgrad(e, e->lane[0], 1));
+        CK(mark(e, "bwd:dW_main_done", e->lane[0]));
+        wg_done = next_event(e);
+        HCK(hipEventRecord(wg_done, e->lane[0]));
+    }
+    HOSTPROF("dW main");
     CK(add_n(main, DT_F32, e->dvl, {e->lv[0].dvl, e->lv[1].dvl, e->lv[2].dvl}, false, (long)B * Cp));
     CK(cmpc_lang_pool_bwd(e->dvl, e->vl, e->vl_rstd, e->parse, e->wf, e->dparse, e->dwf, B, T, Cp, e->RNN, 2, main));
     hipLaunchKernelGGL(col_add3_kernel, dim3((B * T + 255) / 256), dim3(256), 0, main, e->dparse, 4, 2, e->lv[0].dpr, e->lv[1].dpr, e->lv[2].dpr, B * T);
@@ -1424,8 +1496,13 @@ extern "C" int cmpc_backward(cmpc_handle e, void* stream) {
     CK(add_n(main, DT_F32, e->dwf, {e->lv[0].dwf, e->lv[1].dwf, e->lv[2].dwf}, true, (long)B * T * Cp));
     CK(parser_bwd(e, main));
     CK(text_bwd(e, main, e->seq_len_feed));
-    CK(flush_wgrad(e, main));
+    CK(mark(e, "bwd:text_done", main));
+    HOSTPROF("text");
+    if (wg_done) HCK(hipStreamWaitEvent(main, wg_done, 0));
+    CK(flush_wgrad(e, main, 0));
     CK(cmpc_fold_flush(&e->fold, main));
+    CK(mark(e, "bwd:end", main));
+    HOSTPROF("flush+fold");
     e->last_main = main;
     e->launches_step = g_cmpc_launches - e->l0;
     return CMPC_OK;
@@ -1452,6 +1529,7 @@ extern "C" int cmpc_optimizer_step(cmpc_handle e, float gscale, void* stream, do
     HCK(hipEventRecord(e->ev_opt0, st));           // the text encoder's and parser's operands are final
     CK(cmpc_pack_weights_range(e->params, e->arena, e->descs_dev, e->tile_prefix_dev, e->tile_desc_dev, e->ndesc, e->stage0_tiles, e->total_tiles, st));
     HCK(hipEventRecord(e->ev_opt1, st));
+    CK(mark(e, "opt:end", st));
     e->opt_pending = true;
     if (lr_used) *lr_used = lr;
     e->launches_step = g_cmpc_launches - e->l0;

@@ -1305,7 +1305,8 @@ static int tn_validate(const cmpc_gemm_tn_args* a) {
 
 // table_dev / shadow: optional persistent device table + host copy of what it holds.  With static shapes and a static workspace the
 // descriptor table of a step is byte-identical to the previous step's: it is uploaded once and reused (no upload launches).
-int cmpc_gemm_tn_grouped_cached(const void* args_, int n, void* table_dev, size_t table_bytes, std::vector<char>* shadow, hipStream_t st) {
+int cmpc_gemm_tn_grouped_cached(const void* args_, int n, void* const* tables_dev, int nslots, int* victim, size_t table_bytes,
+                                std::vector<char>* shadows, hipStream_t st) {
     const cmpc_gemm_tn_args* args = (const cmpc_gemm_tn_args*)args_;
     if (n < 0 || (n > 0 && !args)) { cmpc_set_error("gemm_tn_grouped: bad args"); return CMPC_EINVAL; }
     std::vector<int> order;
@@ -1319,9 +1320,7 @@ int cmpc_gemm_tn_grouped_cached(const void* args_, int n, void* table_dev, size_
     }
     const int m = (int)order.size();
     if (m == 0) return CMPC_OK;
-    const bool cached = table_dev && shadow && (size_t)m * sizeof(TnGroupDesc) <= table_bytes;
-    TnGroupDesc* table = cached ? (TnGroupDesc*)table_dev : (TnGroupDesc*)cmpc_ws((size_t)m * sizeof(TnGroupDesc), st);
-    if (!table) return CMPC_EHIP;
+    const bool cached = tables_dev && shadows && victim && nslots > 0 && (size_t)m * sizeof(TnGroupDesc) <= table_bytes;
     // split reductions only as far as needed to fill the persistent grid twice
     const int slots = 512;
     const int want = (int)((2 * slots + tiles_tot - 1) / tiles_tot);
@@ -1347,13 +1346,18 @@ int cmpc_gemm_tn_grouped_cached(const void* args_, int n, void* table_dev, size_
         items += sorted[j].tiles * sorted[j].a.rsplit * sorted[j].a.nb * sorted[j].a.nb2;
     }
     const size_t bytes = (size_t)m * sizeof(TnGroupDesc);
+    TnGroupDesc* table = nullptr;
+    std::vector<char>* shadow = nullptr;
+    bool hit = false;
     if (cached) {
-        if (shadow->size() != bytes || memcmp(shadow->data(), sorted.data(), bytes) != 0) {
-            if (hipMemcpyAsync(table, sorted.data(), bytes, hipMemcpyHostToDevice, st) != hipSuccess) { cmpc_set_error("gemm_tn_grouped: table upload failed"); return CMPC_EHIP; }
-            if (hipStreamSynchronize(st) != hipSuccess) { cmpc_set_error("gemm_tn_grouped: table upload failed"); return CMPC_EHIP; }   // `sorted` dies with this call
-            shadow->assign((const char*)sorted.data(), (const char*)sorted.data() + bytes);
-        }
+        for (int k = 0; k < nslots && !hit; ++k)
+            if (shadows[k].size() == bytes && memcmp(shadows[k].data(), sorted.data(), bytes) == 0) { hit = true; table = (TnGroupDesc*)tables_dev[k]; }
+        if (!hit) { const int k = *victim; *victim = (k + 1) % nslots; table = (TnGroupDesc*)tables_dev[k]; shadow = &shadows[k]; }
     } else {
+        table = (TnGroupDesc*)cmpc_ws(bytes, st);
+    }
+    if (!table) return CMPC_EHIP;
+    if (!hit) {
         for (int c0 = 0; c0 < m; c0 += TN_UPLOAD) {     // through the kernel-argument segment: no host synchronisation
             TnUploadArgs ua;
             ua.n = std::min(TN_UPLOAD, m - c0);
@@ -1361,13 +1365,14 @@ int cmpc_gemm_tn_grouped_cached(const void* args_, int n, void* table_dev, size_
             for (int i = 0; i < ua.n; ++i) ua.d[i] = sorted[c0 + i];
             hipLaunchKernelGGL(tn_desc_upload_kernel, dim3(1), dim3(256), 0, st, ua, table);
         }
+        if (shadow) shadow->assign((const char*)sorted.data(), (const char*)sorted.data() + bytes);
     }
     hipLaunchKernelGGL(gemm_tn_grouped_kernel, dim3(std::min(items, slots)), dim3(256), 2 * 2 * TnCfg<bf16_t>::BR * 128 * 2, st, table, m, items);
     return cmpc_check_launch("gemm_tn_grouped");
 }
 
 extern "C" int cmpc_gemm_tn_grouped(const cmpc_gemm_tn_args* args, int n, void* stream) {
-    return cmpc_gemm_tn_grouped_cached(args, n, nullptr, 0, nullptr, (hipStream_t)stream);
+    return cmpc_gemm_tn_grouped_cached(args, n, nullptr, 0, nullptr, 0, nullptr, (hipStream_t)stream);
 }
 
 extern "C" int cmpc_gemm_tn(const cmpc_gemm_tn_args* a, void* stream) {

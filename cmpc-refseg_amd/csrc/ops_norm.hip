@@ -127,6 +127,14 @@ __global__ __launch_bounds__(256) void reduce_parts_grouped_kernel(const cmpc_fo
         if (s != 0.f) atomicAdd(d.out + (long)o * d.ld_out + (long)seg * d.out_seg + c, s);
     }
 }
+#define FOLD_UPLOAD 48
+struct FoldUploadArgs { int n, base; cmpc_fold_desc d[FOLD_UPLOAD]; };
+__global__ void fold_desc_upload_kernel(const FoldUploadArgs ua, cmpc_fold_desc* table) {
+    constexpr int W = (int)(sizeof(cmpc_fold_desc) / sizeof(int));
+    const int* src = reinterpret_cast<const int*>(&ua.d[0]);
+    int* dst = reinterpret_cast<int*>(table + ua.base);
+    for (int i = threadIdx.x; i < ua.n * W; i += blockDim.x) dst[i] = src[i];
+}
 int cmpc_fold_flush(cmpc_fold_ctx* ctx, hipStream_t st) {
     t_fold = nullptr;
     if (!ctx || ctx->n == 0) return CMPC_OK;
@@ -137,8 +145,12 @@ int cmpc_fold_flush(cmpc_fold_ctx* ctx, hipStream_t st) {
         blocks += ((d.nseg * d.seg_ld + 63) / 64) * d.nouter;
     }
     if (ctx->shadow_n != ctx->n || memcmp(ctx->shadow, ctx->descs, sizeof(cmpc_fold_desc) * ctx->n) != 0) {
-        if (hipMemcpyAsync(ctx->table_dev, ctx->descs, sizeof(cmpc_fold_desc) * ctx->n, hipMemcpyHostToDevice, st) != hipSuccess) {
-            cmpc_set_error("fold_flush: descriptor upload failed"); return CMPC_EHIP;
+        for (int c0 = 0; c0 < ctx->n; c0 += FOLD_UPLOAD) {     // through the kernel-argument segment: asynchronous, no host buffer lifetime issue
+            FoldUploadArgs ua;
+            ua.n = ctx->n - c0 < FOLD_UPLOAD ? ctx->n - c0 : FOLD_UPLOAD;
+            ua.base = c0;
+            for (int i = 0; i < ua.n; ++i) ua.d[i] = ctx->descs[c0 + i];
+            hipLaunchKernelGGL(fold_desc_upload_kernel, dim3(1), dim3(256), 0, st, ua, ctx->table_dev);
         }
         memcpy(ctx->shadow, ctx->descs, sizeof(cmpc_fold_desc) * ctx->n);
         ctx->shadow_n = ctx->n;

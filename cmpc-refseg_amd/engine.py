@@ -182,3 +182,14 @@ class Engine:
         ms, fl, by, n = C.c_double(), C.c_double(), C.c_double(), C.c_int64()
         _lib.call("cmpc_kernel_timing_read", self.h, C.byref(ms), C.byref(fl), C.byref(by), C.byref(n))
         return ms.value * 1e-3, fl.value, by.value, n.value
+
+    def phase_marks(self, enable: bool):
+        _lib.call("cmpc_phase_marks", self.h, int(enable))
+
+    def phase_marks_read(self):
+        """[(name, ms since the first mark)] of the marks recorded since phase_marks(True)."""
+        out, name, ms, i = [], C.c_char_p(), C.c_float(), 0
+        while self.lib.cmpc_phase_marks_read(self.h, i, C.byref(name), C.byref(ms)) == 0:
+            out.append((name.value.decode(), ms.value))
+            i += 1
+        return out

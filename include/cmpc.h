@@ -353,6 +353,11 @@ int cmpc_operand_info(cmpc_handle h, const char* key, int64_t* byte_off, int* dt
  * launched on.  cmpc_kernel_timing_read synchronises the device and returns the summed durations (ms), algorithmic FLOPs
  * (2 * rows * valid columns * valid K: padding not counted) and algorithmic bytes (A and C once per row, the weight once)
  * since it was enabled.  Use with n_lanes = 1: with lanes, an interval also contains other streams' kernels. */
+/* Phase-boundary timestamps without a profiler (so the overlap between lanes is the real one): while enabled, every entry point
+ * records a hipEvent at its stage boundaries on the stream that reaches them ("fwd:text_done", "bwd:level_c4_done", ...).
+ * cmpc_phase_marks_read(index) -> name and milliseconds since the first mark; returns CMPC_EINVAL past the last mark. */
+int cmpc_phase_marks(cmpc_handle h, int enable);
+int cmpc_phase_marks_read(cmpc_handle h, int index, const char** name, float* ms_since_first);
 int cmpc_set_lanes(cmpc_handle h, int n_lanes);      /* 1 or 3; takes effect from the next cmpc_forward */
 int cmpc_kernel_timing(cmpc_handle h, int enable);
 int cmpc_kernel_timing_read(cmpc_handle h, double* ms, double* flops, double* bytes, int64_t* launches);
