@@ -186,6 +186,8 @@ SIGNATURES = {
     "cmpc_tap": [_P, C.c_char_p, _PP, C.POINTER(_I), C.POINTER(_I), C.POINTER(_L * 4)],
     "cmpc_tap_name": [_P, _I, C.POINTER(C.c_char_p)],
     "cmpc_launch_count": [_P, C.POINTER(_L)],
+    "cmpc_grad_bucket": [_P, _I, C.POINTER(_I), C.POINTER(_L * 4), C.POINTER(_L * 4)],
+    "cmpc_grad_bucket_wait": [_P, _I, _P],
     "cmpc_phase_marks": [_P, _I],
     "cmpc_phase_marks_read": [_P, _I, C.POINTER(C.c_char_p), C.POINTER(C.c_float)],
     "cmpc_set_lanes": [_P, _I],
@@ -195,7 +197,7 @@ SIGNATURES = {
     "cmpc_operand_info": [_P, C.c_char_p, C.POINTER(_L), C.POINTER(_I), C.POINTER(_I), C.POINTER(_I)],
 }
 # entry points that return a count, not a status
-COUNTS = {"cmpc_param_count": [_P], "cmpc_tap_count": [_P]}
+COUNTS = {"cmpc_param_count": [_P], "cmpc_tap_count": [_P], "cmpc_grad_bucket_count": [_P]}
 
 _lib = None
 

@@ -46,6 +46,10 @@ struct cmpc_fold_ctx {
 };
 void cmpc_fold_begin(cmpc_fold_ctx* ctx);
 int cmpc_fold_flush(cmpc_fold_ctx* ctx, hipStream_t st);
+// Partial flush: fold (and forget) only the recorded folds whose target lies in one of the nr ranges [lo[i], hi[i]); the collector stays
+// on.  table_dev / shadow / shadow_n: the persistent descriptor table of THIS flush point (its own cache, see cmpc_fold_flush).
+int cmpc_fold_flush_ranges(cmpc_fold_ctx* ctx, const float* const* lo, const float* const* hi, int nr, cmpc_fold_desc* table_dev,
+                           cmpc_fold_desc* shadow, int* shadow_n, hipStream_t st);
 // out[o*nval + v] = sum_{i<ninner} part[(o*ninner+i)*nval + v]
 int cmpc_reduce_parts_f64(const double* part, int nouter, int ninner, int nval, double* out, hipStream_t st);
 

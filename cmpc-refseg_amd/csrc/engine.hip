@@ -191,13 +191,23 @@ struct cmpc_engine_s {
     bool have_target = false;
     const int32_t* seq_len_feed = nullptr; const float* target_feed = nullptr;      // caller-owned feeds the backward pass re-reads
     hipStream_t last_main = nullptr; long l0 = 0;
-    std::vector<cmpc_gemm_tn_args> deferred;
+    // Gradient buckets: contiguous ranges of the flat gradient buffer in the order they become final during cmpc_backward
+    //   0: exchange modules x6 + ConvLSTM + final score   (after the round-1 exchange backward)
+    //   1, 2, 3: pyramid level c5 / c4 / c3 (3 also: the three score_cX heads and the three laterals)   (after the levels' backward)
+    //   4: text encoder + parser   (end of the backward pass)
+    // The deferred dW products and bias / LayerNorm folds are issued per bucket, and an event per bucket tells a data-parallel
+    // caller when it may start that bucket's all-reduce (cmpc_grad_bucket_wait).
+    static constexpr int NBK = 5;
+    struct Range { int64_t off, count; };
+    std::vector<Range> bucket[NBK];
+    hipEvent_t bucket_ev[NBK] = {};
+    std::vector<cmpc_gemm_tn_args> deferred[NBK];
     // descriptor tables of the two grouped dW launches of a step; 4 cached variants each (the backbone taps alternate between two
     // buffer sets, so the lateral products' operand pointers alternate): a table that matches a cached one is not uploaded again
-    void* tn_table[2][4] = {}; size_t tn_table_bytes = 0; std::vector<char> tn_shadow[2][4]; int tn_victim[2] = {0, 0};
+    void* tn_table[NBK][4] = {}; size_t tn_table_bytes = 0; std::vector<char> tn_shadow[NBK][4]; int tn_victim[NBK] = {};
     bool wgrad_overlap = true;          // issue the levels' / exchanges' dW beside the text encoder's backward chain
     cmpc_fold_ctx fold;                 // deferred bias / LayerNorm / peephole gradient folds (one launch per backward pass)
-    std::vector<cmpc_fold_desc> fold_descs, fold_shadow;
+    std::vector<cmpc_fold_desc> fold_descs, fold_shadow[NBK]; cmpc_fold_desc* fold_table[NBK] = {}; int fold_shadow_n[NBK];
     std::vector<Tap> taps;
     std::unordered_map<std::string, int> tapindex;
     long launches_step = 0;
@@ -533,11 +543,12 @@ void plan_workspace(E* e, Bump& zf, Bump& zb, Bump& g) {
     e->dscore = (float*)g.take((size_t)B * e->h * e->w * F); e->dfused = g.take((size_t)R * Mp * es);
     e->scalars = (float*)g.take(256);
     e->tn_table_bytes = (size_t)128 << 10;
-    for (int a = 0; a < 2; ++a) for (int b = 0; b < 4; ++b) e->tn_table[a][b] = g.take(e->tn_table_bytes);
+    for (int a = 0; a < E::NBK; ++a) for (int b = 0; b < 4; ++b) e->tn_table[a][b] = g.take(e->tn_table_bytes);
     e->fold.cap = (size_t)512 << 20;                       // partial rows of the deferred folds (~2 MB each, ~110 per step)
     e->fold.arena = (char*)g.take(e->fold.cap);
     e->fold.table_cap = 1024;
-    e->fold.table_dev = (cmpc_fold_desc*)g.take(sizeof(cmpc_fold_desc) * e->fold.table_cap);
+    for (int a = 0; a < E::NBK; ++a) e->fold_table[a] = (cmpc_fold_desc*)g.take(sizeof(cmpc_fold_desc) * e->fold.table_cap);
+    e->fold.table_dev = e->fold_table[E::NBK - 1];
     tap(e, "fused", e->cl[2].h_new, vd, {R, Mp});
     tap(e, "pred", e->score, 0, {B, e->h, e->w, 1}); tap(e, "up", e->up, 0, {B, H, W, 1}); tap(e, "sigm", e->sigm, 0, {B, H, W, 1});
     tap(e, "iu", e->iu, 3, {2, B}); tap(e, "loss_vec", e->loss, 0, {B}); tap(e, "scalars", e->scalars, 0, {6});
@@ -619,7 +630,15 @@ int gemm_nt(hipStream_t st, int dt, std::initializer_list<Seg> segs, void* C, in
 struct TnOpt { int nb2 = 1; int64_t a_bs = 0, d_bs = 0, o_bs = 0; float alpha = 1.f; bool defer = false; };
 typedef std::vector<std::array<int64_t, 3>> Offs;
 
-// out[k, n] += alpha * sum_r A[r, k] D[r, n]; defer: weight gradient, issued by flush_wgrad() in one grouped launch
+// the gradient bucket a gradient-buffer address belongs to
+int bucket_of(const E* e, const float* p) {
+    const int64_t o = p - e->grads;
+    for (int b = 0; b < E::NBK; ++b)
+        for (const E::Range& r : e->bucket[b]) if (o >= r.off && o < r.off + r.count) return b;
+    return E::NBK - 1;
+}
+
+// out[k, n] += alpha * sum_r A[r, k] D[r, n]; defer: weight gradient, issued by flush_bucket() in one grouped launch per bucket
 int gemm_tn(E* e, hipStream_t st, int dt, const void* A, int lda, int Ka, const void* D, int ldd, int Nd, float* out, int ldo,
             int R, int Kv, int Nv, const Offs& offs, const TnOpt& o = TnOpt()) {
     cmpc_gemm_tn_args a; memset(&a, 0, sizeof(a));
@@ -632,7 +651,7 @@ int gemm_tn(E* e, hipStream_t st, int dt, const void* A, int lda, int Ka, const 
     const int br = dt != DT_F32 ? 64 : 32;
     a.rsplit = std::max(1, std::min((R + 4 * br - 1) / (4 * br), (512 + tiles - 1) / tiles));
     a.alpha = o.alpha; a.zeros = e->zero_page;
-    if (o.defer) { e->deferred.push_back(a); return CMPC_OK; }
+    if (o.defer) { e->deferred[bucket_of(e, out)].push_back(a); return CMPC_OK; }
     return cmpc_gemm_tn(&a, st);
 }
 const Offs OFF0 = {{0, 0, 0}};
@@ -1038,12 +1057,21 @@ int clstm_bwd(E* e, hipStream_t st, hipEvent_t* dx_ready) {
     return CMPC_OK;
 }
 
-int flush_wgrad(E* e, hipStream_t st, int slot = 0) {
-    if (e->deferred.empty()) return CMPC_OK;
-    const int rc = cmpc_gemm_tn_grouped_cached(e->deferred.data(), (int)e->deferred.size(), e->tn_table[slot], 4, &e->tn_victim[slot], e->tn_table_bytes,
-                                               e->tn_shadow[slot], st);
-    e->deferred.clear();
-    return rc;
+// bucket b is complete: its deferred weight-gradient products in one grouped launch, its deferred bias / LayerNorm / peephole folds in
+// another, then the event a data-parallel caller waits on before all-reducing the bucket
+int flush_bucket(E* e, hipStream_t st, int b) {
+    std::vector<cmpc_gemm_tn_args>& d = e->deferred[b];
+    if (!d.empty()) {
+        const int rc = cmpc_gemm_tn_grouped_cached(d.data(), (int)d.size(), e->tn_table[b], 4, &e->tn_victim[b], e->tn_table_bytes, e->tn_shadow[b], st);
+        d.clear();
+        CK(rc);
+    }
+    const float* lo[4]; const float* hi[4];
+    int nr = 0;
+    for (const E::Range& r : e->bucket[b]) { lo[nr] = e->grads + r.off; hi[nr] = e->grads + r.off + r.count; ++nr; }
+    CK(cmpc_fold_flush_ranges(&e->fold, lo, hi, nr, e->fold_table[b], e->fold_shadow[b].data(), &e->fold_shadow_n[b], st));
+    HCK(hipEventRecord(e->bucket_ev[b], st));
+    return CMPC_OK;
 }
 
 int params_ready(E* e, hipStream_t st, int stage) {
@@ -1090,6 +1118,7 @@ extern "C" int cmpc_destroy(cmpc_handle e) {
     for (hipEvent_t ev : e->evpool) (void)hipEventDestroy(ev);
     if (e->ev_opt0) (void)hipEventDestroy(e->ev_opt0);
     if (e->ev_opt1) (void)hipEventDestroy(e->ev_opt1);
+    for (hipEvent_t ev : e->bucket_ev) if (ev) (void)hipEventDestroy(ev);
     delete e;
     return CMPC_OK;
 }
@@ -1181,12 +1210,24 @@ extern "C" int cmpc_create(const cmpc_cfg* c, cmpc_handle* out) {
     for (auto& ev : e->evpool) { ev = nullptr; ECK(hipEventCreateWithFlags(&ev, hipEventDisableTiming)); }
     ECK(hipEventCreateWithFlags(&e->ev_opt0, hipEventDisableTiming));
     ECK(hipEventCreateWithFlags(&e->ev_opt1, hipEventDisableTiming));
-#undef ECK
-    e->deferred.reserve(256);
+    for (auto& d : e->deferred) d.reserve(128);
     if (const char* v = getenv("CMPC_WGRAD_OVERLAP")) e->wgrad_overlap = atoi(v) != 0;       // read once, at create
-    e->fold_descs.resize(e->fold.table_cap); e->fold_shadow.resize(e->fold.table_cap);
-    e->fold.descs = e->fold_descs.data(); e->fold.shadow = e->fold_shadow.data();
+    e->fold_descs.resize(e->fold.table_cap);
+    for (int a = 0; a < E::NBK; ++a) { e->fold_shadow[a].resize(e->fold.table_cap); e->fold_shadow_n[a] = -1; }
+    e->fold.descs = e->fold_descs.data(); e->fold.shadow = e->fold_shadow[E::NBK - 1].data();
+    {   // bucket ranges from the manifest order (build_manifest)
+        auto off = [&](const char* n) { return poff(e, n); };
+        const int64_t lat0 = off("c5_lateral/DW"), par0 = off("words_parse_1/DW"), l5 = off("vis_trans_c5_head1/DW"), l4 = off("vis_trans_c4_head1/DW"),
+                      l3 = off("vis_trans_c3_head1/DW"), ex0 = off("spa_graph_key_c3gv_f1/DW");
+        e->bucket[0] = {{ex0, e->total - ex0}};
+        e->bucket[1] = {{l5, l4 - l5}};
+        e->bucket[2] = {{l4, l3 - l4}};
+        e->bucket[3] = {{l3, ex0 - l3}, {lat0, par0 - lat0}};
+        e->bucket[4] = {{0, lat0}, {par0, l5 - par0}};
+        for (int b = 0; b < E::NBK; ++b) ECK(hipEventCreateWithFlags(&e->bucket_ev[b], hipEventDisableTiming));
+    }
     e->fold.lo = e->grads; e->fold.hi = e->grads + e->total;
+#undef ECK
     *out = e;
     return CMPC_OK;
 }
@@ -1284,6 +1325,19 @@ extern "C" int cmpc_get_cfg(cmpc_handle e, cmpc_cfg* out) {
     *out = e->cfg;
     return CMPC_OK;
 }
+extern "C" int cmpc_grad_bucket_count(cmpc_handle e) { return e ? E::NBK : 0; }
+extern "C" int cmpc_grad_bucket(cmpc_handle e, int b, int* nranges, int64_t offsets[4], int64_t counts[4]) {
+    if (!e || b < 0 || b >= E::NBK || !nranges) { cmpc_set_error("grad_bucket: bad argument"); return CMPC_EINVAL; }
+    *nranges = (int)e->bucket[b].size();
+    for (int i = 0; i < *nranges; ++i) { if (offsets) offsets[i] = e->bucket[b][i].off; if (counts) counts[i] = e->bucket[b][i].count; }
+    return CMPC_OK;
+}
+extern "C" int cmpc_grad_bucket_wait(cmpc_handle e, int b, void* stream) {
+    if (!e || b < 0 || b >= E::NBK) { cmpc_set_error("grad_bucket_wait: bad argument"); return CMPC_EINVAL; }
+    CK(set_device(e));
+    HCK(hipStreamWaitEvent((hipStream_t)stream, e->bucket_ev[b], 0));
+    return CMPC_OK;
+}
 extern "C" int cmpc_phase_marks(cmpc_handle e, int enable) {
     if (!e) { cmpc_set_error("phase_marks: null handle"); return CMPC_EINVAL; }
     for (auto& m : e->marks) (void)hipEventDestroy(m.second);
@@ -1341,7 +1395,7 @@ extern "C" int cmpc_forward(cmpc_handle e, const cmpc_feeds* f, const cmpc_fetch
     e->seq_len_feed = f->seq_len; e->target_feed = f->target_fine; e->last_main = main;
     const int B = e->B, Cp = e->Cp;
     e->have_target = f->target_fine != nullptr;
-    e->deferred.clear();
+    for (auto& d : e->deferred) d.clear();
     e->lv[0].feat = f->c5; e->lv[1].feat = f->c4; e->lv[2].feat = f->c3;
     CK(params_ready(e, main, 0));
     CK(mark(e, "fwd:start", main));
@@ -1461,6 +1515,7 @@ extern "C" int cmpc_backward(cmpc_handle e, void* stream) {
     CK(join_lanes(e, main));
     CK(mark(e, "bwd:exch1_done", main));
     HOSTPROF("exch1");
+    CK(flush_bucket(e, main, 0));              // exchange modules, ConvLSTM, final score: gradients final
     // pyramid levels (lane i = level i = c5, c4, c3 = exchange input 2 - i); the language-side sums run on main meanwhile
     CK(fork_lanes(e, main, st));
     CK(add_n(main, DT_F32, e->dnec, {e->ex[0].dnec, e->ex[1].dnec, e->ex[2].dnec, e->ex[3].dnec, e->ex[4].dnec, e->ex[5].dnec}, false, (long)B * Cp));
@@ -1479,15 +1534,16 @@ extern "C" int cmpc_backward(cmpc_handle e, void* stream) {
     // issue it on lane 0 now, beside the text encoder's backward (a serial chain of ~60 small launches on `main` that leaves
     // the chip nearly idle); the text encoder's own few products follow in a second, small launch.
     hipEvent_t wg_done = nullptr;
+    hipStream_t wst = main;
     if (e->cfg.n_lanes > 1 && e->wgrad_overlap) {
         hipEvent_t ev = next_event(e);
         HCK(hipEventRecord(ev, main));
         HCK(hipStreamWaitEvent(e->lane[0], ev, 0));
-        CK(flush_wgrad(e, e->lane[0], 1));
-        CK(mark(e, "bwd:dW_main_done", e->lane[0]));
-        wg_done = next_event(e);
-        HCK(hipEventRecord(wg_done, e->lane[0]));
+        wst = e->lane[0];
     }
+    for (int b = 1; b <= 3; ++b) CK(flush_bucket(e, wst, b));         // levels c5, c4, c3 (+ score_cX, laterals)
+    CK(mark(e, "bwd:dW_main_done", wst));
+    if (wst != main) { wg_done = next_event(e); HCK(hipEventRecord(wg_done, wst)); }
     HOSTPROF("dW main");
     CK(add_n(main, DT_F32, e->dvl, {e->lv[0].dvl, e->lv[1].dvl, e->lv[2].dvl}, false, (long)B * Cp));
     CK(cmpc_lang_pool_bwd(e->dvl, e->vl, e->vl_rstd, e->parse, e->wf, e->dparse, e->dwf, B, T, Cp, e->RNN, 2, main));
@@ -1499,8 +1555,8 @@ extern "C" int cmpc_backward(cmpc_handle e, void* stream) {
     CK(mark(e, "bwd:text_done", main));
     HOSTPROF("text");
     if (wg_done) HCK(hipStreamWaitEvent(main, wg_done, 0));
-    CK(flush_wgrad(e, main, 0));
-    CK(cmpc_fold_flush(&e->fold, main));
+    CK(flush_bucket(e, main, E::NBK - 1));     // text encoder + parser
+    CK(cmpc_fold_flush(&e->fold, main));       // (nothing is left; ends the collection)
     CK(mark(e, "bwd:end", main));
     HOSTPROF("flush+fold");
     e->last_main = main;

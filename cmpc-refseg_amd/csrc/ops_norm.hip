@@ -135,28 +135,47 @@ __global__ void fold_desc_upload_kernel(const FoldUploadArgs ua, cmpc_fold_desc*
     int* dst = reinterpret_cast<int*>(table + ua.base);
     for (int i = threadIdx.x; i < ua.n * W; i += blockDim.x) dst[i] = src[i];
 }
+static int fold_launch(cmpc_fold_desc* descs, int n, cmpc_fold_desc* table_dev, cmpc_fold_desc* shadow, int* shadow_n, hipStream_t st) {
+    if (n == 0) return CMPC_OK;
+    int blocks = 0;
+    for (int i = 0; i < n; ++i) {
+        descs[i].blk_begin = blocks;
+        blocks += ((descs[i].nseg * descs[i].seg_ld + 63) / 64) * descs[i].nouter;
+    }
+    if (*shadow_n != n || memcmp(shadow, descs, sizeof(cmpc_fold_desc) * n) != 0) {
+        for (int c0 = 0; c0 < n; c0 += FOLD_UPLOAD) {     // through the kernel-argument segment: asynchronous, no host buffer lifetime issue
+            FoldUploadArgs ua;
+            ua.n = n - c0 < FOLD_UPLOAD ? n - c0 : FOLD_UPLOAD;
+            ua.base = c0;
+            for (int i = 0; i < ua.n; ++i) ua.d[i] = descs[c0 + i];
+            hipLaunchKernelGGL(fold_desc_upload_kernel, dim3(1), dim3(256), 0, st, ua, table_dev);
+        }
+        memcpy(shadow, descs, sizeof(cmpc_fold_desc) * n);
+        *shadow_n = n;
+    }
+    hipLaunchKernelGGL(reduce_parts_grouped_kernel, dim3(blocks), dim3(256), 0, st, table_dev, n);
+    return cmpc_check_launch("reduce_parts_grouped");
+}
 int cmpc_fold_flush(cmpc_fold_ctx* ctx, hipStream_t st) {
     t_fold = nullptr;
     if (!ctx || ctx->n == 0) return CMPC_OK;
-    int blocks = 0;
+    const int n = ctx->n;
+    ctx->n = 0;
+    return fold_launch(ctx->descs, n, ctx->table_dev, ctx->shadow, &ctx->shadow_n, st);
+}
+int cmpc_fold_flush_ranges(cmpc_fold_ctx* ctx, const float* const* lo, const float* const* hi, int nr, cmpc_fold_desc* table_dev,
+                           cmpc_fold_desc* shadow, int* shadow_n, hipStream_t st) {
+    if (!ctx || ctx->n == 0) return CMPC_OK;
+    // stable partition: selected descriptors to the back (they are launched from there), the rest keep their order in front
+    std::vector<cmpc_fold_desc> sel, rest;
     for (int i = 0; i < ctx->n; ++i) {
-        cmpc_fold_desc& d = ctx->descs[i];
-        d.blk_begin = blocks;
-        blocks += ((d.nseg * d.seg_ld + 63) / 64) * d.nouter;
+        bool in = false;
+        for (int r = 0; r < nr && !in; ++r) in = ctx->descs[i].out >= lo[r] && ctx->descs[i].out < hi[r];
+        (in ? sel : rest).push_back(ctx->descs[i]);
     }
-    if (ctx->shadow_n != ctx->n || memcmp(ctx->shadow, ctx->descs, sizeof(cmpc_fold_desc) * ctx->n) != 0) {
-        for (int c0 = 0; c0 < ctx->n; c0 += FOLD_UPLOAD) {     // through the kernel-argument segment: asynchronous, no host buffer lifetime issue
-            FoldUploadArgs ua;
-            ua.n = ctx->n - c0 < FOLD_UPLOAD ? ctx->n - c0 : FOLD_UPLOAD;
-            ua.base = c0;
-            for (int i = 0; i < ua.n; ++i) ua.d[i] = ctx->descs[c0 + i];
-            hipLaunchKernelGGL(fold_desc_upload_kernel, dim3(1), dim3(256), 0, st, ua, ctx->table_dev);
-        }
-        memcpy(ctx->shadow, ctx->descs, sizeof(cmpc_fold_desc) * ctx->n);
-        ctx->shadow_n = ctx->n;
-    }
-    hipLaunchKernelGGL(reduce_parts_grouped_kernel, dim3(blocks), dim3(256), 0, st, ctx->table_dev, ctx->n);
-    return cmpc_check_launch("reduce_parts_grouped");
+    for (size_t i = 0; i < rest.size(); ++i) ctx->descs[i] = rest[i];
+    ctx->n = (int)rest.size();
+    return fold_launch(sel.data(), (int)sel.size(), table_dev, shadow, shadow_n, st);
 }
 int cmpc_reduce_parts_f32(const float* part, long part_stride, int nouter, int ninner, int nseg, int seg_ld, int seg_C,
                           float* out, long ld_out, long out_seg, int accumulate, hipStream_t st) {

@@ -174,6 +174,18 @@ class Engine:
     def set_lanes(self, n: int):
         _lib.call("cmpc_set_lanes", self.h, int(n))
 
+    def grad_buckets(self):
+        """[[(offset, count), ...], ...]: the ranges of the flat gradient buffer in the order they become final during backward."""
+        out, n, offs, cnts = [], C.c_int(), (C.c_int64 * 4)(), (C.c_int64 * 4)()
+        for b in range(self.lib.cmpc_grad_bucket_count(self.h)):
+            _lib.call("cmpc_grad_bucket", self.h, b, C.byref(n), C.byref(offs), C.byref(cnts))
+            out.append([(int(offs[i]), int(cnts[i])) for i in range(n.value)])
+        return out
+
+    def bucket_wait(self, b: int, stream: torch.cuda.Stream):
+        """`stream` waits (on the device) until gradient bucket b of the last backward() is final."""
+        _lib.call("cmpc_grad_bucket_wait", self.h, b, C.c_void_p(stream.cuda_stream))
+
     def kernel_timing(self, enable: bool):
         _lib.call("cmpc_kernel_timing", self.h, int(enable))
 

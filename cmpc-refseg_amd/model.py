@@ -85,6 +85,7 @@ class LSTM_model(object):
             # backbone on side stream 0 (beside the text encoder); the optimizer on a stream of its own (beside the next
             # step's backbone)
             self._side = (torch.cuda.Stream(device=self.device), torch.cuda.Stream(device=self.device))
+            self.comm_stream = torch.cuda.Stream(device=self.device)       # gradient all-reduce (data-parallel runs)
             self.bb_stream, self.opt_stream = self._side if n_lanes > 1 else (None, None)
             self.backbone = bb.DeepLabResNet(backbone_width, backbone_blocks)
             self.backbone.load_tf(backbone_params if backbone_params is not None else bb.init_params(backbone_width, backbone_blocks))
@@ -249,7 +250,11 @@ class LSTM_model(object):
             feats, ev = self.features_async(im, ready)
             self.loss_and_grads(feats, words, target_fine, seq_len, after=ev)
             sv = self.eng.tap("scalars").clone()
-            gscale = dist.allreduce_grads_(self.eng.grads)            # RCCL over xGMI: one flat buffer
+            gscale = 1.0
+            if self.world > 1:
+                # RCCL over xGMI, bucket by bucket as the backward pass finalises them; the optimizer waits for the last one
+                gscale = dist.allreduce_buckets_(self.eng, self.comm_stream)
+                torch.cuda.current_stream(self.device).wait_stream(self.comm_stream)
             if self.opt_stream is not None:
                 # Adam + repack on the optimizer stream: the next step's backbone does not depend on them; the next
                 # cmpc_forward waits (on the device) for the events cmpc_optimizer_step records
@@ -277,8 +282,8 @@ class LSTM_model(object):
             self.eng.load_state(named)
 
     def enable_data_parallel(self):
-        """One process per GPU; rank 0's weights are broadcast; gradients are summed with one all-reduce of the flat
-        buffer and divided by the world size in the Adam kernel."""
+        """One process per GPU; rank 0's weights are broadcast; gradients are summed bucket by bucket while the backward pass
+        runs (dist.allreduce_buckets_) and divided by the world size in the Adam kernel."""
         self.world = dist.world_size()
         if self.world > 1:
             with torch.cuda.device(self.device):

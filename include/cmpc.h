@@ -331,6 +331,15 @@ int cmpc_forward(cmpc_handle h, const cmpc_feeds* feeds, const cmpc_fetches* fet
 /* tf.gradients(cost) of the last cmpc_forward (which must have had target_fine) into the flat gradient buffer:
  * d cls_loss_all / d theta; the L2 term (:433,446) and the x2 on biases (:462-475) are applied by the optimizer. */
 int cmpc_backward(cmpc_handle h, void* stream);
+/* Gradient buckets for a data-parallel caller (one process per GPU; the reference has no distributed code).  The flat
+ * gradient buffer becomes final in cmpc_grad_bucket_count() pieces, in this order, while cmpc_backward is still running:
+ * the exchange modules + ConvLSTM + final score, the pyramid levels c5, c4, c3, the text encoder + parser.  Bucket b covers
+ * `nranges` (<= 4) contiguous element ranges of cmpc_buffers().grads.  cmpc_grad_bucket_wait makes `stream` wait (on the device) until
+ * bucket b of the most recent cmpc_backward is final: the caller then enqueues that bucket's all-reduce on `stream`, overlapping the
+ * rest of the backward pass, and orders cmpc_optimizer_step after the last all-reduce. */
+int cmpc_grad_bucket_count(cmpc_handle h);
+int cmpc_grad_bucket(cmpc_handle h, int bucket, int* nranges, int64_t offsets[4], int64_t counts[4]);
+int cmpc_grad_bucket_wait(cmpc_handle h, int bucket, void* stream);
 /* TF-Adam with polynomial LR decay, L2 on 'DW', x2 on 'biases' (CMPC_model.py:450-478), then repack of the operands.
  * gscale multiplies the gradients first (1/world after a summing all-reduce).  May be enqueued on a stream of its
  * own: the next cmpc_forward waits (on the device) for the events this call records.  *lr_used = the step's LR. */

@@ -50,7 +50,8 @@ def _worker(rank, world, port, q):
         g[n] = (gflat[off: off + hp[n].numel()] * scale).view(hp[n].shape); off += hp[n].numel()
     with torch.no_grad():
         opt.step(hp, g, O.poly_lr(0, cfg))
-    q.put((rank, local, torch.cat([hp[n].reshape(-1) for n in names])))
+    # numpy arrays travel by value: a torch tensor would travel as a shared-memory handle that dies with this process
+    q.put((rank, local.numpy(), torch.cat([hp[n].reshape(-1) for n in names]).numpy()))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -65,7 +66,7 @@ def test_two_rank_gradient_exchange():
     res = {}
     for _ in range(2):
         r, local, params = q.get(timeout=300)
-        res[r] = (local, params)
+        res[r] = (torch.from_numpy(local), torch.from_numpy(params))
     for p in procs:
         p.join(60)
         assert p.exitcode == 0
@@ -86,3 +87,52 @@ def test_two_rank_gradient_exchange():
         opt.step(hp, g, O.poly_lr(0, cfg))
     ref = torch.cat([hp[n].reshape(-1) for n in names])
     assert torch.allclose(res[0][1], ref, rtol=0, atol=1e-7)
+
+
+@pytest.mark.gpu
+def test_product_data_parallel_two_ranks_one_gpu(tmp_path):
+    """The PRODUCT's data-parallel path under world_size 2: LSTM_model.enable_data_parallel (broadcast of rank 0's weights + repack)
+    and train_step's bucketed gradient exchange (cmpc_grad_bucket_wait + all-reduce per bucket on the communication stream, 1/world in
+    the Adam kernel), three steps on different shards.  Two fresh child processes (started before this process touches the GPU) share
+    the test box's one GPU and exchange over gloo; RCCL over xGMI needs one GPU per rank and is what bench.py uses.  Checks: both
+    replicas end with bit-identical parameters, and they equal the oracle's emulation (average of the two shards' gradients, TF-Adam)."""
+    import subprocess
+    import numpy as np
+    port = _free_port()
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(r), WORLD_SIZE="2", LOCAL_RANK="0",
+                   HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "dp_worker.py"), str(tmp_path / f"rank{r}.npz")], env=env, cwd=ROOT))
+    for p in procs:
+        assert p.wait(timeout=600) == 0
+    a, b = (np.load(tmp_path / f"rank{r}.npz") for r in range(2))
+    for k in a.files:
+        if k != "losses":
+            assert np.array_equal(a[k], b[k]), k                     # replicas stay identical
+    sys.path.insert(0, ROOT)
+    from tests import util as U
+    from tests.util import O
+    torch.set_num_threads(8)
+    cfg = U.tiny_cfg()
+    hp, bp = O.init_head_params(cfg, seed=100), O.init_backbone_params(cfg)
+    opt = O.TFAdam(hp)
+    shards = []
+    for r in range(2):
+        words, im, sl, tgt = O.synth_batch(cfg, seed=r)
+        shards.append((O.backbone_forward(bp, im, cfg), words, sl, tgt))
+    for step in range(3):
+        gs = []
+        for r, (feats, words, sl, tgt) in enumerate(shards):
+            scal, grads, _ = O.grads_of(hp, feats, words, sl, tgt, cfg)
+            gs.append(grads)
+            assert abs(scal["loss_all"] - float((a, b)[r]["losses"][step])) <= 2e-4 * abs(scal["loss_all"]), (step, r)
+        avg = {n: (gs[0][n] + gs[1][n]) / 2 for n in hp}
+        with torch.no_grad():
+            opt.step(hp, avg, O.poly_lr(step, cfg))
+    lr = cfg.start_lr
+    for n, ref in hp.items():
+        if "spa_graph_key" in n and n.endswith("biases"):
+            continue          # exact-zero gradient here vs Adam-amplified rounding noise in the oracle (DESIGN.md)
+        d = float(np.abs(a[n.replace("/", "|")] - ref.numpy()).max())
+        assert d <= 0.35 * lr, (n, d)
