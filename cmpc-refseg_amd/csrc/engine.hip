@@ -201,6 +201,9 @@ struct cmpc_engine_s {
     struct Range { int64_t off, count; };
     std::vector<Range> bucket[NBK];
     hipEvent_t bucket_ev[NBK] = {};
+    std::vector<std::pair<int, int>> bucket_segs[NBK];       // Adam segment index ranges [lo, hi) of each bucket
+    std::vector<std::pair<int, int>> bucket_tiles[NBK];      // pack tile ranges [lo, hi) of the operands packed from each bucket's parameters
+    std::vector<cmpc_adam_seg> segs_host; std::vector<int> tile_prefix_host;
     std::vector<cmpc_gemm_tn_args> deferred[NBK];
     // descriptor tables of the two grouped dW launches of a step; 4 cached variants each (the backbone taps alternate between two
     // buffer sets, so the lateral products' operand pointers alternate): a table that matches a cached one is not uploaded again
@@ -407,6 +410,7 @@ int upload_tables(E* e) {
     for (const ParamSpec& s : e->specs)
         for (int64_t o = 0; o < s.count; o += 8192) segs.push_back(cmpc_adam_seg{s.off + o, (int)std::min<int64_t>(8192, s.count - o), s.wd, s.gmult});
     e->nseg = (int)segs.size();
+    e->segs_host = segs; e->tile_prefix_host = pref;
     HCK(hipMalloc(&e->segs_dev, sizeof(cmpc_adam_seg) * segs.size()));
     HCK(hipMemcpy(e->segs_dev, segs.data(), sizeof(cmpc_adam_seg) * segs.size(), hipMemcpyHostToDevice));
     return CMPC_OK;
@@ -1225,6 +1229,17 @@ extern "C" int cmpc_create(const cmpc_cfg* c, cmpc_handle* out) {
         e->bucket[3] = {{l3, ex0 - l3}, {lat0, par0 - lat0}};
         e->bucket[4] = {{0, lat0}, {par0, l5 - par0}};
         for (int b = 0; b < E::NBK; ++b) ECK(hipEventCreateWithFlags(&e->bucket_ev[b], hipEventDisableTiming));
+        // the optimizer's work per bucket: runs of Adam segments and of pack tiles (both tables are in parameter / plan order)
+        auto bucket_at = [&](int64_t o) { return bucket_of(e, e->grads + o); };
+        for (int i = 0; i < e->nseg; ++i) {
+            auto& v = e->bucket_segs[bucket_at(e->segs_host[i].off)];
+            if (!v.empty() && v.back().second == i) v.back().second = i + 1; else v.push_back({i, i + 1});
+        }
+        for (int i = 0; i < e->ndesc; ++i) {
+            auto& v = e->bucket_tiles[bucket_at(e->descs[i].src_off)];
+            const int t0 = e->tile_prefix_host[i], t1 = e->tile_prefix_host[i + 1];
+            if (!v.empty() && v.back().second == t0) v.back().second = t1; else v.push_back({t0, t1});
+        }
     }
     e->fold.lo = e->grads; e->fold.hi = e->grads + e->total;
 #undef ECK
@@ -1564,30 +1579,40 @@ extern "C" int cmpc_backward(cmpc_handle e, void* stream) {
     return CMPC_OK;
 }
 
-// tf.train.polynomial_decay + AdamOptimizer.apply_gradients (CMPC_model.py:450-478), then repack of the operands
-extern "C" int cmpc_optimizer_step(cmpc_handle e, float gscale, void* stream, double* lr_used) {
-    if (!e) { cmpc_set_error("optimizer_step: null handle"); return CMPC_EINVAL; }
+// tf.train.polynomial_decay + AdamOptimizer.apply_gradients (CMPC_model.py:450-478) + repack of the operands, for ONE gradient bucket.
+// `st` first waits (on the device) for the event cmpc_backward recorded when the bucket became final, so the update of the exchange
+// modules' and the levels' parameters runs beside the rest of the backward pass: none of those parameters (fp32 masters, packed
+// operands) is read again after its bucket is final.  A data-parallel caller orders `st` after the bucket's all-reduce itself.
+extern "C" int cmpc_optimizer_bucket(cmpc_handle e, int b, float gscale, void* stream, double* lr_used) {
+    if (!e || b < 0 || b >= E::NBK) { cmpc_set_error("optimizer_bucket: bad argument"); return CMPC_EINVAL; }
     CK(set_device(e));
     hipStream_t st = (hipStream_t)stream;
-    if (e->last_main != st) {                      // optimizer on a stream of its own: order it after the backward pass
-        hipEvent_t ev = next_event(e);
-        HCK(hipEventRecord(ev, e->last_main));
-        HCK(hipStreamWaitEvent(st, ev, 0));
-    }
+    HCK(hipStreamWaitEvent(st, e->bucket_ev[b], 0));
     const cmpc_cfg& c = e->cfg;
     const double gs = (double)std::min<int64_t>(e->step, c.lr_decay_step);
     const double lr = ((double)c.start_lr - (double)c.end_lr) * pow(1.0 - gs / (double)c.lr_decay_step, (double)c.lr_power) + (double)c.end_lr;
     const double t = (double)(e->step + 1), b1 = 0.9, b2 = 0.999;
     const double lr_t = lr * sqrt(1.0 - pow(b2, t)) / (1.0 - pow(b1, t));
-    CK(cmpc_adam_step(e->params, e->grads, e->adam_m, e->adam_v, e->segs_dev, e->nseg, (float)lr_t, (float)b1, (float)b2, 1e-8f, gscale / e->cfg.loss_scale, st));
-    e->step += 1;
-    CK(cmpc_pack_weights_range(e->params, e->arena, e->descs_dev, e->tile_prefix_dev, e->tile_desc_dev, e->ndesc, 0, e->stage0_tiles, st));
-    HCK(hipEventRecord(e->ev_opt0, st));           // the text encoder's and parser's operands are final
-    CK(cmpc_pack_weights_range(e->params, e->arena, e->descs_dev, e->tile_prefix_dev, e->tile_desc_dev, e->ndesc, e->stage0_tiles, e->total_tiles, st));
-    HCK(hipEventRecord(e->ev_opt1, st));
-    CK(mark(e, "opt:end", st));
-    e->opt_pending = true;
+    for (const auto& r : e->bucket_segs[b])
+        CK(cmpc_adam_step(e->params, e->grads, e->adam_m, e->adam_v, e->segs_dev + r.first, r.second - r.first, (float)lr_t, (float)b1, (float)b2, 1e-8f,
+                          gscale / e->cfg.loss_scale, st));
+    for (const auto& r : e->bucket_tiles[b])
+        CK(cmpc_pack_weights_range(e->params, e->arena, e->descs_dev, e->tile_prefix_dev, e->tile_desc_dev, e->ndesc, r.first, r.second, st));
+    if (b == E::NBK - 1) {                         // the text encoder's bucket is the last to become final: the step is complete
+        e->step += 1;
+        HCK(hipEventRecord(e->ev_opt0, st));
+        HCK(hipEventRecord(e->ev_opt1, st));
+        CK(mark(e, "opt:end", st));
+        e->opt_pending = true;
+    }
     if (lr_used) *lr_used = lr;
     e->launches_step = g_cmpc_launches - e->l0;
+    return CMPC_OK;
+}
+
+// the whole update on one stream: every bucket in order
+extern "C" int cmpc_optimizer_step(cmpc_handle e, float gscale, void* stream, double* lr_used) {
+    if (!e) { cmpc_set_error("optimizer_step: null handle"); return CMPC_EINVAL; }
+    for (int b = 0; b < E::NBK; ++b) CK(cmpc_optimizer_bucket(e, b, gscale, stream, lr_used));
     return CMPC_OK;
 }

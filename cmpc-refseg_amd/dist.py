@@ -2,7 +2,7 @@
 xGMI on ROCm; "gloo" in the tests).  The reference has no distributed code at all (SURVEY.md 5);
 images are independent except the per-replica l2_normalize(gv_lang) (CMPC_model.py:241), so the only
 exchange is the sum of the flat fp32 gradient buffer, issued as ~60 MB buckets as soon as each is final
-(allreduce_buckets_: exchange modules + ConvLSTM first, then the three pyramid levels, the text encoder last), so
+(allreduce_bucket_: exchange modules + ConvLSTM first, then the three pyramid levels, the text encoder last), so
 that all but the last bucket travel while the backward pass is still running; the 1/world factor is folded into
 the Adam kernel (gscale)."""
 from __future__ import annotations
@@ -42,17 +42,15 @@ def broadcast_params_(flat: torch.Tensor, src: int = 0):
         dist.broadcast(flat, src)
 
 
-def allreduce_buckets_(eng, comm_stream: torch.cuda.Stream, max_elems: int = 16 << 20) -> float:
-    """Sum the gradient buffer of `eng` (engine.Engine) over all ranks, bucket by bucket: for every bucket the communication
-    stream first waits (on the device) for the event cmpc_backward recorded when that bucket became final, then its ranges are
-    all-reduced in chunks of <= max_elems (64 MB) on that stream -- while the rest of the backward pass is still running on
-    the compute streams.  The caller orders the optimizer after `comm_stream`.  Returns the scale (1/world) for the optimizer."""
-    w = world_size()
-    if w > 1:
-        for b, ranges in enumerate(eng.grad_buckets()):
-            eng.bucket_wait(b, comm_stream)
-            with torch.cuda.stream(comm_stream):
-                for off, cnt in ranges:
-                    for o in range(off, off + cnt, max_elems):
-                        dist.all_reduce(eng.grads[o: min(o + max_elems, off + cnt)], op=dist.ReduceOp.SUM)
-    return 1.0 / w
+def allreduce_bucket_(eng, b: int, ranges, comm_stream: torch.cuda.Stream, max_elems: int = 16 << 20):
+    """Sum gradient bucket b of `eng` (engine.Engine) over all ranks: the communication stream first waits (on the device) for the
+    event cmpc_backward recorded when the bucket became final, then its ranges are all-reduced in chunks of <= max_elems (64 MB) on
+    that stream -- while the rest of the backward pass is still running on the compute streams.  The caller orders the bucket's
+    optimizer update after `comm_stream`."""
+    if world_size() <= 1:
+        return
+    eng.bucket_wait(b, comm_stream)
+    with torch.cuda.stream(comm_stream):
+        for off, cnt in ranges:
+            for o in range(off, off + cnt, max_elems):
+                dist.all_reduce(eng.grads[o: min(o + max_elems, off + cnt)], op=dist.ReduceOp.SUM)

@@ -148,6 +148,16 @@ class Engine:
         _lib.call("cmpc_optimizer_step", self.h, float(gscale), self._stream(), C.byref(lr))
         return lr.value
 
+    def optimizer_bucket(self, b: int, gscale: float = 1.0) -> float:
+        """Adam + repack for gradient bucket b on the current stream (which first waits, on the device, for the bucket)."""
+        lr = C.c_double()
+        _lib.call("cmpc_optimizer_bucket", self.h, int(b), float(gscale), self._stream(), C.byref(lr))
+        return lr.value
+
+    @property
+    def n_buckets(self) -> int:
+        return self.lib.cmpc_grad_bucket_count(self.h)
+
     # ---- intermediates ------------------------------------------------------------------------
     def tap_names(self) -> List[str]:
         out, name = [], C.c_char_p()

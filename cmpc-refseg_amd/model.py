@@ -250,19 +250,20 @@ class LSTM_model(object):
             feats, ev = self.features_async(im, ready)
             self.loss_and_grads(feats, words, target_fine, seq_len, after=ev)
             sv = self.eng.tap("scalars").clone()
-            gscale = 1.0
-            if self.world > 1:
-                # RCCL over xGMI, bucket by bucket as the backward pass finalises them; the optimizer waits for the last one
-                gscale = dist.allreduce_buckets_(self.eng, self.comm_stream)
-                torch.cuda.current_stream(self.device).wait_stream(self.comm_stream)
-            if self.opt_stream is not None:
-                # Adam + repack on the optimizer stream: the next step's backbone does not depend on them; the next
-                # cmpc_forward waits (on the device) for the events cmpc_optimizer_step records
-                self.opt_stream.wait_stream(torch.cuda.current_stream(self.device))
-                with torch.cuda.stream(self.opt_stream):
-                    lr = self.eng.optimizer_step(gscale)
-            else:
-                lr = self.eng.optimizer_step(gscale)
+            # Optimizer, bucket by bucket in the order the backward pass finalises them (exchange modules + ConvLSTM, levels c5 / c4 /
+            # c3, text encoder): every bucket's Adam + repack waits on the device for that bucket only, so all but the last run
+            # beside the rest of the backward pass; on the optimizer stream, so the next step's backbone does not wait for them.
+            # Data-parallel: the bucket's all-reduce (RCCL over xGMI, communication stream) goes in between; 1/world in the Adam kernel.
+            cur = torch.cuda.current_stream(self.device)
+            ost = self.opt_stream if self.opt_stream is not None else cur
+            gscale = 1.0 / self.world
+            buckets = self.eng.grad_buckets() if self.world > 1 else None
+            for b in range(self.eng.n_buckets):
+                if self.world > 1:
+                    dist.allreduce_bucket_(self.eng, b, buckets[b], self.comm_stream)
+                    ost.wait_stream(self.comm_stream)
+                with torch.cuda.stream(ost):
+                    lr = self.eng.optimizer_bucket(b, gscale)
             done = torch.cuda.Event()
             done.record(self.opt_stream if self.opt_stream is not None else torch.cuda.current_stream(self.device))
             self._inflight.append(done)

@@ -344,6 +344,10 @@ int cmpc_grad_bucket_wait(cmpc_handle h, int bucket, void* stream);
  * gscale multiplies the gradients first (1/world after a summing all-reduce).  May be enqueued on a stream of its
  * own: the next cmpc_forward waits (on the device) for the events this call records.  *lr_used = the step's LR. */
 int cmpc_optimizer_step(cmpc_handle h, float gscale, void* stream, double* lr_used);
+/* The same update for ONE gradient bucket (every bucket exactly once per step, the last bucket last): `stream` waits on the device until
+ * the bucket is final, then runs Adam on the bucket's parameters and repacks the operands packed from them -- beside the rest of the
+ * backward pass.  cmpc_optimizer_step = every bucket in order on one stream. */
+int cmpc_optimizer_bucket(cmpc_handle h, int bucket, float gscale, void* stream, double* lr_used);
 
 /* Named intermediate of the last forward / backward ("words_parse", "gw_w_c3", "up_c4", "scalars", ...: the fetches
  * of the reference's visualisers, test_visualize_graph.py:243-253, plus every stage output the parity tests compare).
