@@ -50,10 +50,6 @@ int cmpc_fold_flush(cmpc_fold_ctx* ctx, hipStream_t st);
 // on.  table_dev / shadow / shadow_n: the persistent descriptor table of THIS flush point (its own cache, see cmpc_fold_flush).
 int cmpc_fold_flush_ranges(cmpc_fold_ctx* ctx, const float* const* lo, const float* const* hi, int nr, cmpc_fold_desc* table_dev,
                            cmpc_fold_desc* shadow, int* shadow_n, hipStream_t st);
-// per-sample fp64 LayerNorm statistics accumulate (atomics) into their final location, which must be zero on entry: the wrappers clear it
-// unless the calling thread has declared its statistics buffers cleared (the engine clears them all with one memset per pass)
-void cmpc_stats_prezeroed(bool on);
-int cmpc_stats_clear(double* p, size_t n, hipStream_t st);
 // out[o*nval + v] = sum_{i<ninner} part[(o*ninner+i)*nval + v]
 int cmpc_reduce_parts_f64(const double* part, int nouter, int ninner, int nval, double* out, hipStream_t st);
 

@@ -140,7 +140,7 @@ struct LevelBuf {          // one pyramid level (c5 / c4 / c3), forward then bac
     // backward
     void *dfus, *dpre, *dX1, *dX2, *dU, *dG, *dY, *Z, *dZ, *dZt, *dA0_t, *dX0, *dV;
     float *dscore, *dsb, *dvl, *Zf, *dgw_w, *dZf, *dZtf, *dgw_v, *dA0, *dpr, *gsc2, *dPT, *dk0s, *dWd, *dwf, *dg;
-    double *bs, *bs2;
+    double* bs;
 };
 struct ExgBuf {            // one gated_exchange_module
     float *q, *kq, *logits, *attn, *pooled, *gvpre, *gv, *rs1, *g[2], *rstd;
@@ -148,7 +148,7 @@ struct ExgBuf {            // one gated_exchange_module
     void *dfeat, *dp[2], *dfs[2];
     float *dg[2], *dgv, *dgvpre, *dpooled, *dnec, *dattn, *dlog, *dkq, *dq;
 };
-struct ClstmStep { void *Yg, *c_pre, *c_new, *h_new, *dYg, *dc_prev, *dx, *dh; double *sums, *bs; };
+struct ClstmStep { void *Yg, *c_pre, *c_new, *h_new, *dYg, *dc_prev, *dx, *dh; double* sums; };
 
 }  // namespace
 
@@ -185,7 +185,7 @@ struct cmpc_engine_s {
     LevelBuf lv[3];                 // c5, c4, c3
     ExgBuf ex[6];                   // c3, c4, c5, c3_2, c4_2, c5_2
     void* de1[3];                   // gradients of the round-1 outputs (c3, c4, c5)
-    ClstmStep cl[3]; void* cl_scr;
+    ClstmStep cl[3]; void* cl_scr; double* cl_bs;
     float *score, *up, *sigm, *loss; int* iu; float *dscore; void* dfused;
     float* scalars;
     bool have_target = false;
@@ -482,8 +482,8 @@ void plan_workspace(E* e, Bump& zf, Bump& zb, Bump& g) {
         L.gw_w_t = g.take((size_t)B * N * Tp * es); L.gw_v_t = g.take((size_t)B * N * Tp * es);
         L.gsc = (float*)g.take((size_t)B * nch * 128 * F);
         L.Ztf = (float*)zf.take((size_t)B * Cp * Tp * F); L.Zt = g.take((size_t)B * Cp * Tp * es);
-        L.Y = g.take((size_t)R * Cp * es); L.sums1 = (double*)zf.take((size_t)B * 2 * D);
-        L.G = g.take((size_t)R * Cp * es); L.U = g.take((size_t)R * Cp * es); L.sums2 = (double*)zf.take((size_t)B * 2 * D);
+        L.Y = g.take((size_t)R * Cp * es); L.sums1 = (double*)g.take((size_t)B * 2 * D);
+        L.G = g.take((size_t)R * Cp * es); L.U = g.take((size_t)R * Cp * es); L.sums2 = (double*)g.take((size_t)B * 2 * D);
         L.X2 = g.take((size_t)R * Cp * es); L.rrow = (float*)g.take((size_t)R * F);
         L.sb = (float*)g.take((size_t)B * Mp * F); L.F = g.take((size_t)R * Mp * es);
         L.score = (float*)g.take((size_t)B * e->h * e->w * F); L.up = (float*)g.take((size_t)B * H * W * F);
@@ -492,7 +492,7 @@ void plan_workspace(E* e, Bump& zf, Bump& zb, Bump& g) {
         L.dfus = g.take((size_t)R * Mp * es); L.dscore = (float*)g.take((size_t)B * e->h * e->w * F);
         L.dpre = g.take((size_t)R * Mp * es); L.dsb = (float*)zb.take((size_t)B * Mp * F);
         L.dX1 = g.take((size_t)R * Cp * es); L.dX2 = g.take((size_t)R * Cp * es); L.dvl = (float*)g.take((size_t)B * Cp * F);
-        L.bs = (double*)zb.take((size_t)B * 2 * D); L.bs2 = (double*)zb.take((size_t)B * 2 * D);
+        L.bs = (double*)g.take((size_t)B * 2 * D);
         L.dU = g.take((size_t)R * Cp * es); L.dG = g.take((size_t)R * Cp * es); L.dY = g.take((size_t)R * Cp * es);
         L.Zf = (float*)zb.take((size_t)B * Tp * Cp * F); L.Z = g.take((size_t)B * Tp * Cp * es);
         L.dgw_w = (float*)g.take((size_t)B * N * Tp * F);
@@ -535,12 +535,12 @@ void plan_workspace(E* e, Bump& zf, Bump& zb, Bump& g) {
     // ---- ConvLSTM + final score
     for (int s = 0; s < 3; ++s) {
         ClstmStep& S = e->cl[s];
-        S.Yg = g.take((size_t)R * 4 * Mp * es); S.sums = (double*)zf.take((size_t)5 * B * 2 * D); S.bs = (double*)zb.take((size_t)5 * B * 2 * D);
+        S.Yg = g.take((size_t)R * 4 * Mp * es); S.sums = (double*)g.take((size_t)5 * B * 2 * D);
         S.c_pre = g.take((size_t)R * Mp * es); S.c_new = g.take((size_t)R * Mp * es); S.h_new = g.take((size_t)R * Mp * es);
         S.dYg = g.take((size_t)R * 4 * Mp * es); S.dc_prev = g.take((size_t)R * Mp * es);
         S.dx = g.take((size_t)R * Mp * es); S.dh = g.take((size_t)R * Mp * es);
     }
-    e->cl_scr = g.take((size_t)R * Mp * es);
+    e->cl_scr = g.take((size_t)R * Mp * es); e->cl_bs = (double*)g.take((size_t)5 * B * 2 * D);
     e->score = (float*)g.take((size_t)B * e->h * e->w * F); e->up = (float*)g.take((size_t)B * H * W * F);
     e->sigm = (float*)g.take((size_t)B * H * W * F);
     e->loss = (float*)zf.take((size_t)B * F); e->iu = (int*)zf.take((size_t)2 * B * 4);
@@ -869,7 +869,7 @@ int level_bwd(E* e, hipStream_t st, int li, const float* target) {
       CK(gemm_nt(st, dt, {{L.dU, Cp, opp(e, fmt("gupd_%s.n", lv)), Cp, Cp}}, L.dG, Cp, R, Cp, o));
       // dX1 (already holding fusion's share) += dG*[G>0]; dY = LN backward
       CK(cmpc_gconv_pre_bwd(dt, L.dG, L.G, L.Y, L.sums1, pptr(e, ln1 + "/gamma"), L.dX1, 1, L.dY, gptr(e, ln1 + "/gamma"), gptr(e, ln1 + "/beta"),
-                            L.bs2, B, N, Cp, C, st));
+                            L.bs, B, N, Cp, C, st));
       // Y = gw_w . Z,  Z = gw_v^T . X1
       TnOpt zt; zt.nb2 = B; zt.a_bs = (int64_t)N * Tp; zt.d_bs = (int64_t)N * Cp; zt.o_bs = (int64_t)Tp * Cp;
       CK(gemm_tn(e, st, dt, L.gw_v_t, Tp, Tp, L.X1, Cp, Cp, L.Zf, Cp, N, T, C, OFF0, zt));
@@ -1045,7 +1045,7 @@ int clstm_bwd(E* e, hipStream_t st, hipEvent_t* dx_ready) {
         const void* c_prev = s > 0 ? e->cl[s - 1].c_new : nullptr;
         CK(cmpc_convlstm_bwd(dt, dh, dc, S.Yg, c_prev, S.c_pre, pptr(e, pre + "W_ci"), pptr(e, pre + "W_cf"), pptr(e, pre + "W_co"), &ln, S.sums,
                              S.dYg, s > 0 ? S.dc_prev : nullptr, gptr(e, pre + "W_ci"), gptr(e, pre + "W_cf"), gptr(e, pre + "W_co"), &dln,
-                             e->cl_scr, S.bs, B, N, Mp, M, st));
+                             e->cl_scr, e->cl_bs, B, N, Mp, M, st));
         Offs ox, oh;
         for (int g = 0; g < 4; ++g) { ox.push_back({0, (int64_t)g * Mp, (int64_t)g * M}); oh.push_back({0, (int64_t)g * Mp, (int64_t)M * 4 * M + (int64_t)g * M}); }
         CK(gemm_tn(e, st, dt, xs[s], Mp, Mp, S.dYg, 4 * Mp, Mp, gk, 4 * M, R, M, M, ox, d));
@@ -1414,8 +1414,6 @@ extern "C" int cmpc_forward(cmpc_handle e, const cmpc_feeds* f, const cmpc_fetch
     e->lv[0].feat = f->c5; e->lv[1].feat = f->c4; e->lv[2].feat = f->c3;
     CK(params_ready(e, main, 0));
     CK(mark(e, "fwd:start", main));
-    cmpc_stats_prezeroed(true);                  // every LayerNorm statistics buffer of the pass lies in the region cleared next
-    struct StatsGuard { ~StatsGuard() { cmpc_stats_prezeroed(false); } } stats_guard;
     HCK(hipMemsetAsync(e->ws, 0, e->zf_bytes, main));                         // every accumulate-into buffer of the forward pass
     CK(text_fwd(e, main, f->words, f->seq_len));
     CK(parser_fwd(e, main));
@@ -1482,8 +1480,6 @@ extern "C" int cmpc_backward(cmpc_handle e, void* stream) {
     const long nmap = (long)e->R * Mp;
     const float* target = e->target_feed;
     CK(mark(e, "bwd:start", main));
-    cmpc_stats_prezeroed(true);
-    struct StatsGuard { ~StatsGuard() { cmpc_stats_prezeroed(false); } } stats_guard;
     HCK(hipMemsetAsync(e->ws + e->zf_bytes, 0, e->zb_bytes, main));
     HCK(hipMemsetAsync(e->grads, 0, (size_t)e->total * sizeof(float), main));
     HOSTPROF("memsets");

@@ -17,9 +17,9 @@ __device__ __forceinline__ void flush_sums(double s1, double s2, double* dst, do
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     if (lane == 0) { red[2 * slot][w] = s1; red[2 * slot + 1][w] = s2; }
     __syncthreads();
-    if (threadIdx.x == 0) {        // dst = the sample's (zeroed) pair: 2 fp64 atomics per workgroup, no fold launch
-        atomicAdd(dst, red[2 * slot][0] + red[2 * slot][1] + red[2 * slot][2] + red[2 * slot][3]);
-        atomicAdd(dst + 1, red[2 * slot + 1][0] + red[2 * slot + 1][1] + red[2 * slot + 1][2] + red[2 * slot + 1][3]);
+    if (threadIdx.x == 0) {        // dst = this workgroup's partial pair (folded by reduce_parts_f64)
+        dst[0] = red[2 * slot][0] + red[2 * slot][1] + red[2 * slot][2] + red[2 * slot][3];
+        dst[1] = red[2 * slot + 1][0] + red[2 * slot + 1][1] + red[2 * slot + 1][2] + red[2 * slot + 1][3];
     }
     __syncthreads();
 }
@@ -81,9 +81,9 @@ __global__ __launch_bounds__(256) void clstm_a_kernel(T* __restrict__ Yg, const 
         sj1 += aj1; sj2 += aj2; si1 += ai1; si2 += ai2; sf1 += af1; sf2 += af2;
     }
     const long wg = (long)b * gridDim.x + blockIdx.x, nwg = (long)B * gridDim.x;
-    flush_sums(sj1, sj2, sums + (0 * (long)B + b) * 2, red, 0);
-    flush_sums(si1, si2, sums + (1 * (long)B + b) * 2, red, 1);
-    flush_sums(sf1, sf2, sums + (2 * (long)B + b) * 2, red, 2);
+    flush_sums(sj1, sj2, sums + (0 * nwg + wg) * 2, red, 0);
+    flush_sums(si1, si2, sums + (1 * nwg + wg) * 2, red, 1);
+    flush_sums(sf1, sf2, sums + (2 * nwg + wg) * 2, red, 2);
 }
 
 
@@ -158,8 +158,8 @@ __global__ __launch_bounds__(256) void clstm_b_kernel(T* __restrict__ Yg, const 
         so1 += ao1; so2 += ao2; sc1 += ac1; sc2 += ac2;
     }
     const long wg = (long)b * gridDim.x + blockIdx.x, nwg = (long)B * gridDim.x;
-    flush_sums(so1, so2, dpart + (0 * (long)B + b) * 2, red, 0);
-    flush_sums(sc1, sc2, dpart + (1 * (long)B + b) * 2, red, 1);
+    flush_sums(so1, so2, dpart + (0 * nwg + wg) * 2, red, 0);
+    flush_sums(sc1, sc2, dpart + (1 * nwg + wg) * 2, red, 1);
 }
 
 // ---- forward C ---------------------------------------------------------------------------------
@@ -246,8 +246,8 @@ __global__ __launch_bounds__(256) void clstm_bwd1_kernel(const T* __restrict__ d
         so1 += ao1; so2 += ao2; sc1 += ac1; sc2 += ac2;
     }
     const long wg = (long)b * gridDim.x + blockIdx.x, nwg = (long)B * gridDim.x;
-    flush_sums(so1, so2, dpart + (0 * (long)B + b) * 2, red, 0);
-    flush_sums(sc1, sc2, dpart + (1 * (long)B + b) * 2, red, 1);
+    flush_sums(so1, so2, dpart + (0 * nwg + wg) * 2, red, 0);
+    flush_sums(sc1, sc2, dpart + (1 * nwg + wg) * 2, red, 1);
     float* pr = part + wg * 4 * ld;                 // [dgamma_o, dbeta_o, dgamma_c, dbeta_c]
     colflush(ago, pr, ld, M, lds); colflush(abo, pr + ld, ld, M, lds);
     colflush(agc, pr + 2 * ld, ld, M, lds); colflush(abc, pr + 3 * ld, ld, M, lds);
@@ -333,9 +333,9 @@ __global__ __launch_bounds__(256) void clstm_bwd2_kernel(const T* __restrict__ Y
         for (int q = 0; q < 6; ++q) s[q] += a[q];
     }
     const long wg = (long)b * gridDim.x + blockIdx.x, nwg = (long)B * gridDim.x;
-    flush_sums(s[0], s[1], dpart + (0 * (long)B + b) * 2, red, 0);
-    flush_sums(s[2], s[3], dpart + (1 * (long)B + b) * 2, red, 1);
-    flush_sums(s[4], s[5], dpart + (2 * (long)B + b) * 2, red, 2);
+    flush_sums(s[0], s[1], dpart + (0 * nwg + wg) * 2, red, 0);
+    flush_sums(s[2], s[3], dpart + (1 * nwg + wg) * 2, red, 1);
+    flush_sums(s[4], s[5], dpart + (2 * nwg + wg) * 2, red, 2);
     float* pr = part + wg * 6 * ld;                 // [dgamma_q, dbeta_q] for q = j, i, f
 #pragma unroll
     for (int q = 0; q < 3; ++q) { colflush(ag[q], pr + (2 * q) * ld, ld, M, lds); colflush(ab[q], pr + (2 * q + 1) * ld, ld, M, lds); }
@@ -451,9 +451,11 @@ extern "C" int cmpc_convlstm_a(int dt, void* Yg, const void* c_prev, const float
     if (!ok("convlstm_a", dt, ld, M)) return CMPC_EINVAL;
     const int gx = rows_grid(N, 100);
     float* part; double* dpart;
-    if (cmpc_stats_clear(sums, (size_t)5 * B * 2, ST)) return CMPC_EHIP;        // all five pairs of the step (convlstm_b adds o and c)
+    if (clstm_ws((long)B * gx, 0, 3, ld, &part, &dpart, ST)) return CMPC_EHIP;
     CLSTM_NB(ld, CMPC_DISPATCH_DT(dt, hipLaunchKernelGGL((clstm_a_kernel<T, NBX>), dim3(gx, B), dim3(256), 0, ST,
-                                             (T*)Yg, (const T*)c_prev, W_ci, W_cf, sums, B, N, ld, M)));
+                                             (T*)Yg, (const T*)c_prev, W_ci, W_cf, dpart, B, N, ld, M)));
+    for (int q = 0; q < 3; ++q)
+        if (cmpc_reduce_parts_f64(dpart + (long)q * B * gx * 2, B, gx, 2, sums + (long)q * B * 2, ST)) return CMPC_EHIP;
     return cmpc_check_launch("convlstm_a");
 }
 
@@ -462,8 +464,11 @@ extern "C" int cmpc_convlstm_b(int dt, void* Yg, const void* c_prev, const float
     if (!ok("convlstm_b", dt, ld, M)) return CMPC_EINVAL;
     const int gx = rows_grid(N, 100);
     float* part; double* dpart;
+    if (clstm_ws((long)B * gx, 0, 2, ld, &part, &dpart, ST)) return CMPC_EHIP;
     CLSTM_NB(ld, CMPC_DISPATCH_DT(dt, hipLaunchKernelGGL((clstm_b_kernel<T, NBX>), dim3(gx, B), dim3(256), 0, ST,
-                                             (T*)Yg, (const T*)c_prev, W_co, to_lnp(ln), sums, sums + (long)3 * B * 2, (T*)c_pre, B, N, ld, M)));
+                                             (T*)Yg, (const T*)c_prev, W_co, to_lnp(ln), sums, dpart, (T*)c_pre, B, N, ld, M)));
+    for (int q = 0; q < 2; ++q)
+        if (cmpc_reduce_parts_f64(dpart + (long)q * B * gx * 2, B, gx, 2, sums + (long)(3 + q) * B * 2, ST)) return CMPC_EHIP;
     return cmpc_check_launch("convlstm_b");
 }
 
@@ -486,11 +491,11 @@ extern "C" int cmpc_convlstm_bwd(int dt, const void* dh, const void* dc_new, con
     const long nwg = (long)B * gx;
     float* part; double* dpart;
     if (clstm_ws(nwg, 6, 3, ld, &part, &dpart, ST)) return CMPC_EHIP;
-    if (cmpc_stats_clear(bsums, (size_t)5 * B * 2, ST)) return CMPC_EHIP;
     // pass 1: LN(o), LN(c) dxhat + their statistics / parameter gradients
     CLSTM_NB(ld, CMPC_DISPATCH_DT(dt, hipLaunchKernelGGL((clstm_bwd1_kernel<T, NBX>), dim3(gx, B), dim3(256), lds, ST,
-                           (const T*)dh, (const T*)dc_new, (const T*)Yg, (const T*)c_pre, to_lnp(ln), sums, (T*)dYg, (T*)scr, part, bsums + (long)3 * B * 2, B, N, ld, M)));
+                           (const T*)dh, (const T*)dc_new, (const T*)Yg, (const T*)c_pre, to_lnp(ln), sums, (T*)dYg, (T*)scr, part, dpart, B, N, ld, M)));
     for (int q = 0; q < 2; ++q) {
+        if (cmpc_reduce_parts_f64(dpart + (long)q * nwg * 2, B, gx, 2, bsums + (long)(3 + q) * B * 2, ST)) return CMPC_EHIP;
         if (cmpc_reduce_parts_f32(part + (2 * q) * ld, 4 * ld, 1, (int)nwg, 1, ld, M, dln->dgamma[3 + q], 0, 0, 1, ST)) return CMPC_EHIP;
         if (cmpc_reduce_parts_f32(part + (2 * q + 1) * ld, 4 * ld, 1, (int)nwg, 1, ld, M, dln->dbeta[3 + q], 0, 0, 1, ST)) return CMPC_EHIP;
     }
@@ -499,8 +504,9 @@ extern "C" int cmpc_convlstm_bwd(int dt, const void* dh, const void* dc_new, con
     if (clstm_ws(nwg, 6, 3, ld, &part, &dpart, ST)) return CMPC_EHIP;
     CLSTM_NB(ld, CMPC_DISPATCH_DT(dt, hipLaunchKernelGGL((clstm_bwd2_kernel<T, NBX>), dim3(gx, B), dim3(256), lds, ST,
                            (const T*)Yg, (const T*)c_prev, (const T*)c_pre, W_co, to_lnp(ln), sums, bsums, (T*)dYg, (const T*)scr, (T*)dc_prev,
-                           part, bsums, B, N, ld, M)));
+                           part, dpart, B, N, ld, M)));
     for (int q = 0; q < 3; ++q) {
+        if (cmpc_reduce_parts_f64(dpart + (long)q * nwg * 2, B, gx, 2, bsums + (long)q * B * 2, ST)) return CMPC_EHIP;
         if (cmpc_reduce_parts_f32(part + (2 * q) * ld, 6 * ld, 1, (int)nwg, 1, ld, M, dln->dgamma[q], 0, 0, 1, ST)) return CMPC_EHIP;
         if (cmpc_reduce_parts_f32(part + (2 * q + 1) * ld, 6 * ld, 1, (int)nwg, 1, ld, M, dln->dbeta[q], 0, 0, 1, ST)) return CMPC_EHIP;
     }

@@ -27,15 +27,6 @@ extern "C" const char* cmpc_last_error(void) { return g_err; }
 struct WsSlot { hipStream_t st; void* p; size_t bytes; bool used; };
 static WsSlot g_ws[64];
 static thread_local cmpc_fold_ctx* t_fold = nullptr;
-static thread_local bool t_stats_zeroed = false;
-void cmpc_stats_prezeroed(bool on) { t_stats_zeroed = on; }
-// fp64 sample statistics are accumulated with atomics into their final location, which must start at zero: cleared here unless the
-// caller (the engine: one memset for all of a pass's statistics) has declared them cleared
-int cmpc_stats_clear(double* p, size_t n, hipStream_t st) {
-    if (t_stats_zeroed) return CMPC_OK;
-    if (hipMemsetAsync(p, 0, n * sizeof(double), st) != hipSuccess) { cmpc_set_error("statistics memset failed"); return CMPC_EHIP; }
-    return CMPC_OK;
-}
 void cmpc_fold_begin(cmpc_fold_ctx* ctx) { t_fold = ctx; if (ctx) { ctx->off = 0; ctx->n = 0; } }
 void* cmpc_ws(size_t bytes, hipStream_t st) {
     if (t_fold) {                       // collecting deferred folds: partial rows must survive until cmpc_fold_flush
@@ -477,9 +468,10 @@ __global__ __launch_bounds__(256) void sample_stats_kernel(const T* __restrict__
     s1 = wave_sum_d(s1); s2 = wave_sum_d(s2);
     if (lane == 0) { red[0][w] = s1; red[1][w] = s2; }
     __syncthreads();
-    if (threadIdx.x == 0) {        // straight into the sample's (zeroed) pair: 2 fp64 atomics per workgroup, no fold launch
-        atomicAdd(dpart + (long)b * 2, red[0][0] + red[0][1] + red[0][2] + red[0][3]);
-        atomicAdd(dpart + (long)b * 2 + 1, red[1][0] + red[1][1] + red[1][2] + red[1][3]);
+    if (threadIdx.x == 0) {
+        double* d = dpart + ((long)b * gridDim.x + blockIdx.x) * 2;
+        d[0] = red[0][0] + red[0][1] + red[0][2] + red[0][3];
+        d[1] = red[1][0] + red[1][1] + red[1][2] + red[1][3];
     }
 }
 
@@ -570,9 +562,9 @@ __global__ __launch_bounds__(256) void gconv_pre_bwd1_kernel(const T* __restrict
     if (lane == 0) { red[0][w] = s1; red[1][w] = s2; }
     __syncthreads();
     const long wg = (long)b * gridDim.x + blockIdx.x;
-    if (threadIdx.x == 0) {        // straight into the sample's (zeroed) pair: 2 fp64 atomics per workgroup, no fold launch
-        atomicAdd(dpart + (long)b * 2, red[0][0] + red[0][1] + red[0][2] + red[0][3]);
-        atomicAdd(dpart + (long)b * 2 + 1, red[1][0] + red[1][1] + red[1][2] + red[1][3]);
+    if (threadIdx.x == 0) {
+        dpart[wg * 2] = red[0][0] + red[0][1] + red[0][2] + red[0][3];
+        dpart[wg * 2 + 1] = red[1][0] + red[1][1] + red[1][2] + red[1][3];
     }
     colsum_flush(ag, part + wg * 2 * ld, ld, C, lds);
     colsum_flush(ab, part + wg * 2 * ld + ld, ld, C, lds);
@@ -714,9 +706,9 @@ __global__ __launch_bounds__(256) void gconv_post_bwd1_kernel(const T* __restric
     if (lane == 0) { red[0][w] = s1; red[1][w] = s2; }
     __syncthreads();
     const long wg = (long)b * gridDim.x + blockIdx.x;
-    if (threadIdx.x == 0) {        // straight into the sample's (zeroed) pair: 2 fp64 atomics per workgroup, no fold launch
-        atomicAdd(dpart + (long)b * 2, red[0][0] + red[0][1] + red[0][2] + red[0][3]);
-        atomicAdd(dpart + (long)b * 2 + 1, red[1][0] + red[1][1] + red[1][2] + red[1][3]);
+    if (threadIdx.x == 0) {
+        dpart[wg * 2] = red[0][0] + red[0][1] + red[0][2] + red[0][3];
+        dpart[wg * 2 + 1] = red[1][0] + red[1][1] + red[1][2] + red[1][3];
     }
     colsum_flush(ag, part + wg * 2 * ld, ld, C, lds);
     colsum_flush(ab, part + wg * 2 * ld + ld, ld, C, lds);
@@ -825,8 +817,10 @@ extern "C" int cmpc_l2norm_rows_bwd(int dt, const void* dy, const void* y, const
 extern "C" int cmpc_sample_stats(int dt, const void* x, double* sums, int B, int N, int ld, int C, void* stream) {
     if (ld <= 0 || C > ld || ld % 8) { cmpc_set_error("sample_stats: bad ld/C"); return CMPC_EINVAL; }
     const int gx = rows_grid(N) > 128 ? 128 : rows_grid(N);
-    if (cmpc_stats_clear(sums, (size_t)B * 2, ST)) return CMPC_EHIP;
-    CMPC_DISPATCH_DT(dt, hipLaunchKernelGGL((sample_stats_kernel<T>), dim3(gx, B), dim3(256), 0, ST, (const T*)x, sums, N, ld, C));
+    double* dpart = (double*)cmpc_ws((size_t)B * gx * 2 * sizeof(double), ST);
+    if (!dpart) return CMPC_EHIP;
+    CMPC_DISPATCH_DT(dt, hipLaunchKernelGGL((sample_stats_kernel<T>), dim3(gx, B), dim3(256), 0, ST, (const T*)x, dpart, N, ld, C));
+    if (cmpc_reduce_parts_f64(dpart, B, gx, 2, sums, ST)) return CMPC_EHIP;
     return cmpc_check_launch("sample_stats");
 }
 
@@ -854,9 +848,9 @@ extern "C" int cmpc_gconv_pre_bwd(int dt, const void* dG, const void* G, const v
     const int gx = rows_grid(N) > 64 ? 64 : rows_grid(N);
     float* part; double* dpart;
     if (ln_bwd_ws(B, gx, ld, &part, &dpart, ST)) return CMPC_EHIP;
-    if (cmpc_stats_clear(bsums, (size_t)B * 2, ST)) return CMPC_EHIP;
     CMPC_DISPATCH_DT(dt, hipLaunchKernelGGL((gconv_pre_bwd1_kernel<T>), dim3(gx, B), dim3(256), WPB * ld * sizeof(float), ST,
-                           (const T*)dG, (const T*)G, (const T*)Y, sums, gamma, (T*)dX, accumulate_dX, (T*)dY, part, bsums, N, ld, C));
+                           (const T*)dG, (const T*)G, (const T*)Y, sums, gamma, (T*)dX, accumulate_dX, (T*)dY, part, dpart, N, ld, C));
+    if (cmpc_reduce_parts_f64(dpart, B, gx, 2, bsums, ST)) return CMPC_EHIP;
     if (cmpc_reduce_parts_f32(part, 2 * ld, 1, B * gx, 1, ld, C, dgamma, 0, 0, 1, ST)) return CMPC_EHIP;
     if (cmpc_reduce_parts_f32(part + ld, 2 * ld, 1, B * gx, 1, ld, C, dbeta, 0, 0, 1, ST)) return CMPC_EHIP;
     CMPC_DISPATCH_DT(dt, hipLaunchKernelGGL((ln_bwd2_kernel<T>), dim3(rows_grid(N), B), dim3(256), 0, ST, (T*)dY, (const T*)Y, sums, bsums, N, ld, C));
@@ -878,9 +872,9 @@ extern "C" int cmpc_gconv_post_bwd(int dt, const void* dout, const void* out, co
     const int gx = rows_grid(N) > 64 ? 64 : rows_grid(N);
     float* part; double* dpart;
     if (ln_bwd_ws(B, gx, ld, &part, &dpart, ST)) return CMPC_EHIP;
-    if (cmpc_stats_clear(bsums, (size_t)B * 2, ST)) return CMPC_EHIP;
     CMPC_DISPATCH_DT(dt, hipLaunchKernelGGL((gconv_post_bwd1_kernel<T>), dim3(gx, B), dim3(256), WPB * ld * sizeof(float), ST,
-                           (const T*)dout, (const T*)out, rstd_row, (const T*)U, sums, gamma, (T*)dU, part, bsums, N, ld, C));
+                           (const T*)dout, (const T*)out, rstd_row, (const T*)U, sums, gamma, (T*)dU, part, dpart, N, ld, C));
+    if (cmpc_reduce_parts_f64(dpart, B, gx, 2, bsums, ST)) return CMPC_EHIP;
     if (cmpc_reduce_parts_f32(part, 2 * ld, 1, B * gx, 1, ld, C, dgamma, 0, 0, 1, ST)) return CMPC_EHIP;
     if (cmpc_reduce_parts_f32(part + ld, 2 * ld, 1, B * gx, 1, ld, C, dbeta, 0, 0, 1, ST)) return CMPC_EHIP;
     CMPC_DISPATCH_DT(dt, hipLaunchKernelGGL((ln_bwd2_kernel<T>), dim3(rows_grid(N), B), dim3(256), 0, ST, (T*)dU, (const T*)U, sums, bsums, N, ld, C));
