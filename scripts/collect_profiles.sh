@@ -1,0 +1,18 @@
+#!/bin/bash
+# Collect the round's committed profiles on the GPU box (outputs under gpurun_out/prof_r02; summaries copied to profiles/ afterwards).
+#   kernel stats: every launch of 30 train steps on ONE stream (rocprofv3 --kernel-trace --stats)
+#   PMC passes (separate runs, counters only): FETCH_SIZE, WRITE_SIZE, MFMA busy
+set -o pipefail
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/prof_r02; mkdir -p $O
+cd /tmp && export TMPDIR=/tmp
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python3 $R/scripts/prof_step.py 30 1 > $O/stats.log 2>&1 || exit 1
+timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/fetch -- python3 $R/scripts/prof_step.py 10 1 > $O/fetch.log 2>&1 || exit 1
+timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/write -- python3 $R/scripts/prof_step.py 10 1 > $O/write.log 2>&1 || exit 1
+timeout -k 10 300 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_BUSY_CYCLES --output-format csv -d $O/mfma -- python3 $R/scripts/prof_step.py 10 1 > $O/mfma.log 2>&1 || exit 1
+cd $R
+python scripts/summarize_profile.py $O/stats $O/r02_bench_b8_f16_kernel_stats.csv 30
+python scripts/pmc_traffic.py $O/fetch $O/write gemm_nt_v $O/r02_gemm_nt_traffic.json
+python scripts/pmc_mfma.py $O/mfma $O/r02_mfma_busy.txt
+timeout -k 10 300 python scripts/phase_timeline.py > $O/r02_phase_timeline.txt 2>/dev/null
+rm -rf $O/stats $O/fetch $O/write $O/mfma
+ls -la $O

@@ -11,7 +11,7 @@ lanes = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 B = int(sys.argv[3]) if len(sys.argv) > 3 else 8
 pkg = importlib.import_module("cmpc-refseg_amd")
 dev = torch.device("cuda:0")
-m = pkg.LSTM_model(batch_size=B, mode="train", dtype=os.environ.get("CMPC_DTYPE", "bf16"), n_lanes=3)
+m = pkg.LSTM_model(batch_size=B, mode="train", dtype=os.environ.get("CMPC_DTYPE", "f16"), n_lanes=3)
 m.set_lanes(lanes)
 w, im, sl, tg = (torch.from_numpy(x).to(dev) for x in synth_batch(B, 20, 320, 320, m.cfg.vocab_size, 0))
 for i in range(steps):
