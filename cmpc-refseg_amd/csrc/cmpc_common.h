@@ -25,7 +25,7 @@ int cmpc_check_launch(const char* what);
 // Library-owned scratch for per-workgroup partial sums: one growing buffer PER STREAM (up to 64
 // streams), so stage operators running on different streams never share partial rows.
 void* cmpc_ws(size_t bytes, hipStream_t st);
-// out[o*ld_out + seg*out_seg + c] (+)= sum_{i<ninner} part[(o*ninner+i)*part_stride + seg*seg_ld + c], c < seg_C
+// out[o*ld_out + seg*out_seg + c] (+)= sum_{i<ninner} part[(o*ninner+i)*part_stride + seg*seg_ld + c], c < seg_C   (one writer per element)
 int cmpc_reduce_parts_f32(const float* part, long part_stride, int nouter, int ninner, int nseg, int seg_ld, int seg_C,
                           float* out, long ld_out, long out_seg, int accumulate, hipStream_t st);
 // cmpc_gemm_tn_grouped with `nslots` caller-owned persistent descriptor tables (device) and host copies of their contents: a step
@@ -37,7 +37,7 @@ int cmpc_gemm_tn_grouped_cached(const void* args /* cmpc_gemm_tn_args[n] */, int
 // thread) cmpc_ws hands out NON-recycled pieces of `arena`, cmpc_reduce_parts_f32 records such folds instead of launching them, and
 // cmpc_fold_flush folds them all in ONE launch.  table_dev: device buffer for the descriptors (>= 64 B each); it is re-uploaded only
 // when the recorded list differs from the previous flush (shapes are static, so after the first step it never does).
-struct cmpc_fold_desc { const float* part; long part_stride; int nouter, ninner, nseg, seg_ld, seg_C, blk_begin; float* out; long ld_out, out_seg; };
+struct cmpc_fold_desc { const float* part; long part_stride; int nouter, ninner, nseg, seg_ld, seg_C, blk_begin; float* out; long ld_out, out_seg; int chain, pad_; };
 struct cmpc_fold_ctx {
     char* arena = nullptr; size_t cap = 0, off = 0; const float* lo = nullptr; const float* hi = nullptr;
     cmpc_fold_desc* table_dev = nullptr; int table_cap = 0;

@@ -548,7 +548,7 @@ void plan_workspace(E* e, Bump& zf, Bump& zb, Bump& g) {
     e->scalars = (float*)g.take(256);
     e->tn_table_bytes = (size_t)128 << 10;
     for (int a = 0; a < E::NBK; ++a) for (int b = 0; b < 4; ++b) e->tn_table[a][b] = g.take(e->tn_table_bytes);
-    e->fold.cap = (size_t)512 << 20;                       // partial rows of the deferred folds (~2 MB each, ~110 per step)
+    e->fold.cap = (size_t)2048 << 20;                       // partial rows of the deferred folds (~2 MB each, ~110 per step) and the per-part slabs of the split dW reductions
     e->fold.arena = (char*)g.take(e->fold.cap);
     e->fold.table_cap = 1024;
     for (int a = 0; a < E::NBK; ++a) e->fold_table[a] = (cmpc_fold_desc*)g.take(sizeof(cmpc_fold_desc) * e->fold.table_cap);
@@ -653,7 +653,7 @@ int gemm_tn(E* e, hipStream_t st, int dt, const void* A, int lda, int Ka, const 
     a.nb2 = o.nb2; a.a_bs = o.a_bs; a.d_bs = o.d_bs; a.o_bs = o.o_bs;
     const int tiles = ((Kv + 127) / 128) * ((Nv + 127) / 128) * a.nb * a.nb2;
     const int br = dt != DT_F32 ? 64 : 32;
-    a.rsplit = std::max(1, std::min((R + 4 * br - 1) / (4 * br), (512 + tiles - 1) / tiles));
+    a.rsplit = std::max(1, std::min((R + 4 * br - 1) / (4 * br), (512 + tiles - 1) / tiles));      // split parts go through slabs + a fixed-order fold
     a.alpha = o.alpha; a.zeros = e->zero_page;
     if (o.defer) { e->deferred[bucket_of(e, out)].push_back(a); return CMPC_OK; }
     return cmpc_gemm_tn(&a, st);

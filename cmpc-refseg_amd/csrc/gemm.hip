@@ -916,8 +916,16 @@ __device__ __forceinline__ int tn_swz(int r, int byte, int rowb) {
     return r * rowb + ((((byte >> 5) ^ f) << 5) | (byte & 31));
 }
 
+// How a workgroup delivers its tile -- always exactly ONE writer per destination element, so no atomics and a sum that does not
+// depend on the order workgroups finish in:
+//   TN_ACC   : accumulate into acc and return (the caller chains further products that add into the same output tile)
+//   TN_RMW   : out[k, n] += alpha * acc        (the reduction is not split: this workgroup is the only writer of the tile)
+//   TN_SLAB  : slab[k, n]  = alpha * acc       (split reduction: every part has its own [Kv][lds] fp32 slab, and a fold launch
+//              sums the slabs of a tile in a fixed order into the output)
+enum { TN_ACC = 0, TN_RMW = 1, TN_SLAB = 2 };
 template <typename T>
-__device__ __forceinline__ void gemm_tn_body(const cmpc_gemm_tn_args& p, const int bx, const int by, const int bz) {
+__device__ __forceinline__ void gemm_tn_body(const cmpc_gemm_tn_args& p, const int bx, const int by, const int bz, f4 (&acc)[4][4],
+                                             const int MODE, float* slab = nullptr, int lds = 0) {
     constexpr int BR = TnCfg<T>::BR;
     constexpr int ROWB = 128 * (int)sizeof(T);     // bytes per LDS row
     constexpr int EPC = 16 / (int)sizeof(T);
@@ -940,12 +948,6 @@ __device__ __forceinline__ void gemm_tn_body(const cmpc_gemm_tn_args& p, const i
     const int rbeg = by * per;
     const int rend = min(p.R, rbeg + per);
     const int nt = (rend > rbeg) ? (rend - rbeg + BR - 1) / BR : 0;
-
-    f4 acc[4][4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = f4{0.f, 0.f, 0.f, 0.f};
 
     uint4 ra[NCH], rd[NCH];
     auto gload = [&](int t) {
@@ -1034,7 +1036,7 @@ __device__ __forceinline__ void gemm_tn_body(const cmpc_gemm_tn_args& p, const i
         if (t + 1 < nt) lstore(cur ^ 1);
         __syncthreads();
     }
-    if (nt == 0) return;
+    if (MODE == TN_ACC) return;
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -1043,14 +1045,26 @@ __device__ __forceinline__ void gemm_tn_body(const cmpc_gemm_tn_args& p, const i
             for (int r = 0; r < 4; ++r) {
                 const int k = k0 + wm * 64 + i * 16 + fq * 4 + r;
                 const int n = n0 + wn * 64 + j * 16 + fr;
-                if (k < p.Kv && n < p.Nv) atomicAdd(out + (long)k * p.ldo + n, acc[i][j][r] * p.alpha);
+                if (k < p.Kv && n < p.Nv) {
+                    if (MODE == TN_SLAB) slab[(long)k * lds + n] = acc[i][j][r] * p.alpha;
+                    else out[(long)k * p.ldo + n] += acc[i][j][r] * p.alpha;
+                }
             }
+}
+__device__ __forceinline__ void tn_zero(f4 (&acc)[4][4]) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f4{0.f, 0.f, 0.f, 0.f};
 }
 
 
 template <typename T>
-__global__ __launch_bounds__(256) void gemm_tn_kernel(const cmpc_gemm_tn_args p) {
-    gemm_tn_body<T>(p, blockIdx.x, blockIdx.y, blockIdx.z);
+__global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const cmpc_gemm_tn_args p, float* slabs, long slab_size, int lds) {
+    f4 acc[4][4];
+    tn_zero(acc);
+    if (slabs) gemm_tn_body<T>(p, blockIdx.x, blockIdx.y, blockIdx.z, acc, TN_SLAB, slabs + ((long)blockIdx.z * p.rsplit + blockIdx.y) * slab_size, lds);
+    else gemm_tn_body<T>(p, blockIdx.x, blockIdx.y, blockIdx.z, acc, TN_RMW);
 }
 
 // Grouped form: ALL deferred weight-gradient products of a backward pass in ONE persistent launch.  The
@@ -1064,6 +1078,10 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const cmpc_gemm_tn_args p)
 struct TnGroupDesc {
     cmpc_gemm_tn_args a;
     int item_begin, tiles;
+    int chain;          // > 0: the next `chain` descriptors add into the SAME output tiles (same shape, alpha): one workgroup accumulates them all
+    int lds;            // slab row stride (slab mode)
+    float* slabs;       // != NULL: split reduction, part (bz, by) writes slabs + (bz * rsplit + by) * slab_size; a fold launch follows
+    long slab_size;
 };
 #define TN_UPLOAD 10
 struct TnUploadArgs {
@@ -1077,18 +1095,27 @@ __global__ void tn_desc_upload_kernel(const TnUploadArgs ua, TnGroupDesc* table)
     for (int i = threadIdx.x; i < ua.n * W; i += blockDim.x) dst[i] = src[i];
 }
 
-__global__ __launch_bounds__(256) void gemm_tn_grouped_kernel(const TnGroupDesc* __restrict__ table, int ndesc, int total) {
+__global__ __launch_bounds__(256, 2) void gemm_tn_grouped_kernel(const TnGroupDesc* __restrict__ table, int ndesc, int total) {
     for (int w = blockIdx.x; w < total; w += gridDim.x) {
         int lo = 0, hi = ndesc;                       // uniform binary search: scalar loads
         while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (table[mid].item_begin <= w) lo = mid; else hi = mid; }
         const TnGroupDesc& d = table[lo];
         const int local = w - d.item_begin;
         const int tiles = d.tiles, rs = d.a.rsplit;
-        const int bx = local % tiles, rest = local / tiles;
-        if (d.a.dtype == DT_F32) gemm_tn_body<float>(d.a, bx, rest % rs, rest / rs);
-        else if (d.a.dtype == DT_BF16) gemm_tn_body<bf16_t>(d.a, bx, rest % rs, rest / rs);
-        else gemm_tn_body<f16_t>(d.a, bx, rest % rs, rest / rs);
-        __syncthreads();                              // the next item reuses the LDS stages
+        const int bx = local % tiles, rest = local / tiles, by = rest % rs, bz = rest / rs;
+        f4 acc[4][4];
+        tn_zero(acc);
+        // a part of a split reduction writes its own slab; products chained behind d add into the same output tile: they are
+        // accumulated in a fixed order and stored once (by the head, last).  ONE call site per dtype keeps the register budget.
+        float* slab = d.slabs ? d.slabs + ((long)bz * rs + by) * d.slab_size : nullptr;
+        for (int q = d.chain; q >= 0; --q) {
+            const TnGroupDesc& c = table[lo + q];
+            const int mode = slab ? TN_SLAB : (q > 0 ? TN_ACC : TN_RMW);
+            if (c.a.dtype == DT_F32) gemm_tn_body<float>(c.a, bx, by, bz, acc, mode, slab, d.lds);
+            else if (c.a.dtype == DT_BF16) gemm_tn_body<bf16_t>(c.a, bx, by, bz, acc, mode, slab, d.lds);
+            else gemm_tn_body<f16_t>(c.a, bx, by, bz, acc, mode, slab, d.lds);
+            __syncthreads();                          // the next product / item reuses the LDS stages
+        }
     }
 }
 
@@ -1303,47 +1330,124 @@ static int tn_validate(const cmpc_gemm_tn_args* a) {
     return CMPC_OK;
 }
 
+// out region of batch entry (b1, b2) += sum over the rsplit slabs of that entry, rows k < Kv, columns n < Nv
+static int tn_fold(const cmpc_gemm_tn_args& a, int rsplit, float* slabs, long slab_size, int lds, hipStream_t st) {
+    // uniform outer stride (nb == 1): one fold over all nb2 entries; otherwise one per inner-batch offset
+    for (int b1 = 0; b1 < a.nb; ++b1) {
+        for (int b2 = 0; b2 < a.nb2; b2 += (a.nb == 1 ? a.nb2 : 1)) {
+            const int nouter = a.nb == 1 ? a.nb2 : 1;
+            const long bz = b1 + (long)a.nb * b2;
+            const int rc = cmpc_reduce_parts_f32(slabs + bz * rsplit * slab_size, slab_size, nouter, rsplit, a.Kv, lds, a.Nv,
+                                                 a.out + a.o_off[b1] + (long)b2 * a.o_bs, a.o_bs, a.ldo, 1, st);
+            if (rc != CMPC_OK) return rc;
+        }
+    }
+    return CMPC_OK;
+}
+#define CK_FOLD(x) do { const int rc_ = (x); if (rc_ != CMPC_OK) return rc_; } while (0)
+
 // table_dev / shadow: optional persistent device table + host copy of what it holds.  With static shapes and a static workspace the
 // descriptor table of a step is byte-identical to the previous step's: it is uploaded once and reused (no upload launches).
 int cmpc_gemm_tn_grouped_cached(const void* args_, int n, void* const* tables_dev, int nslots, int* victim, size_t table_bytes,
                                 std::vector<char>* shadows, hipStream_t st) {
     const cmpc_gemm_tn_args* args = (const cmpc_gemm_tn_args*)args_;
     if (n < 0 || (n > 0 && !args)) { cmpc_set_error("gemm_tn_grouped: bad args"); return CMPC_EINVAL; }
-    std::vector<int> order;
-    long tiles_tot = 0;
+    // 1. expand: an outer batch that accumulates into ONE output (o_bs == 0) becomes a chain of single products
+    std::vector<cmpc_gemm_tn_args> ex;
     for (int i = 0; i < n; ++i) {
         const int rc = tn_validate(&args[i]);
         if (rc != CMPC_OK) return rc;
         if (args[i].R == 0) continue;
-        order.push_back(i);
-        tiles_tot += (long)((args[i].Kv + 127) / 128) * ((args[i].Nv + 127) / 128) * args[i].nb * args[i].nb2;
+        if (args[i].nb2 > 1 && args[i].o_bs == 0) {
+            const int esz = args[i].dtype == DT_F32 ? 4 : 2;
+            for (int b = 0; b < args[i].nb2; ++b) {
+                cmpc_gemm_tn_args a = args[i];
+                a.A = (const char*)a.A + (size_t)b * a.a_bs * esz; a.D = (const char*)a.D + (size_t)b * a.d_bs * esz;
+                a.nb2 = 1; a.a_bs = a.d_bs = 0;
+                ex.push_back(a);
+            }
+        } else ex.push_back(args[i]);
     }
-    const int m = (int)order.size();
+    const int m = (int)ex.size();
     if (m == 0) return CMPC_OK;
-    const bool cached = tables_dev && shadows && victim && nslots > 0 && (size_t)m * sizeof(TnGroupDesc) <= table_bytes;
-    // split reductions only as far as needed to fill the persistent grid twice
-    const int slots = 512;
-    const int want = (int)((2 * slots + tiles_tot - 1) / tiles_tot);
-    std::vector<TnGroupDesc> descs(m);
-    std::vector<long> len(m);
-    for (int j = 0; j < m; ++j) {
-        TnGroupDesc& d = descs[j];
-        memset(&d, 0, sizeof(d));                      // padding bytes take part in the cache comparison
-        d.a = args[order[j]];
-        const int br = d.a.dtype == DT_F32 ? TnCfg<float>::BR : TnCfg<bf16_t>::BR;
-        d.a.rsplit = std::max(1, std::min(want, std::max(1, d.a.R / (16 * br))));
-        d.tiles = ((d.a.Kv + 127) / 128) * ((d.a.Nv + 127) / 128);
-        len[j] = ((d.a.R + d.a.rsplit - 1) / d.a.rsplit + br - 1) / br;     // steps of one item
+    // 2. chains: products that add into the same output region (same tiles, same scale) are accumulated by ONE workgroup per tile,
+    //    in list order, and stored once -- every output element has exactly one writer, so no atomics and a run-to-run identical sum
+    auto same_out = [](const cmpc_gemm_tn_args& x, const cmpc_gemm_tn_args& y) {
+        if (x.out != y.out || x.ldo != y.ldo || x.Kv != y.Kv || x.Nv != y.Nv || x.nb != y.nb || x.nb2 != y.nb2 || x.o_bs != y.o_bs || x.alpha != y.alpha) return false;
+        for (int b = 0; b < x.nb; ++b) if (x.o_off[b] != y.o_off[b]) return false;
+        return true;
+    };
+    std::vector<std::vector<int>> chains;
+    for (int i = 0; i < m; ++i) {
+        bool placed = false;
+        for (auto& c : chains) if (same_out(ex[c[0]], ex[i])) { c.push_back(i); placed = true; break; }
+        if (!placed) chains.push_back({i});
     }
-    std::vector<int> idx(m);
-    for (int j = 0; j < m; ++j) idx[j] = j;
-    std::stable_sort(idx.begin(), idx.end(), [&](int x, int y) { return len[x] > len[y]; });   // long items first
-    std::vector<TnGroupDesc> sorted(m);
-    int items = 0;
-    for (int j = 0; j < m; ++j) {
-        sorted[j] = descs[idx[j]];
-        sorted[j].item_begin = items;
-        items += sorted[j].tiles * sorted[j].a.rsplit * sorted[j].a.nb * sorted[j].a.nb2;
+    const bool cached = tables_dev && shadows && victim && nslots > 0 && (size_t)m * sizeof(TnGroupDesc) <= table_bytes;
+    // 3. split the long reductions only as far as needed to fill the persistent grid twice (as many parts per product as the
+    //    atomic version used); a chain whose parts number more than one writes per-part slabs that a fold launch sums in a fixed order
+    const int slots = 512;
+    long tiles_tot = 0;
+    for (int i = 0; i < m; ++i) tiles_tot += (long)((ex[i].Kv + 127) / 128) * ((ex[i].Nv + 127) / 128) * ex[i].nb * ex[i].nb2;
+    const int want = (int)((2 * slots + tiles_tot - 1) / tiles_tot);
+    std::vector<int> rsplit(m, 1);
+    std::vector<long> steps(m, 0);
+    for (int i = 0; i < m; ++i) {
+        const int br = ex[i].dtype == DT_F32 ? TnCfg<float>::BR : TnCfg<bf16_t>::BR;
+        rsplit[i] = std::max(1, std::min(want, std::max(1, ex[i].R / (16 * br))));
+        steps[i] = ((ex[i].R + rsplit[i] - 1) / rsplit[i] + br - 1) / br;
+    }
+    struct Unit { std::vector<int> prods; bool slab; long len; };      // one table entry group: a chain stored directly, or ONE product in slab mode
+    std::vector<Unit> units;
+    struct Fold { int prod; float* slabs; long slab_size; int lds; };
+    std::vector<Fold> folds;
+    size_t slab_total = 0;
+    for (const auto& c : chains) {
+        int parts = 0; long len = 0;
+        for (int i : c) { parts += rsplit[i]; len += steps[i]; }
+        // a short chain of unsplit products (e.g. the B per-sample products of a [T, .] word-side gradient): one workgroup walks it
+        const bool direct = (c.size() == 1 && rsplit[c[0]] == 1) || (parts == (int)c.size() && len <= 64);
+        if (direct) { for (int i : c) rsplit[i] = 1; units.push_back(Unit{c, false, len}); continue; }
+        for (int i : c) {
+            const cmpc_gemm_tn_args& a = ex[i];
+            const int lds = (a.Nv + 3) / 4 * 4;
+            const long slab_size = (long)a.Kv * lds;
+            folds.push_back(Fold{i, (float*)(uintptr_t)slab_total, slab_size, lds});        // offset for now: ONE block is carved below
+            slab_total += ((size_t)slab_size * rsplit[i] * a.nb * a.nb2 * sizeof(float) + 255) / 256 * 256;
+            units.push_back(Unit{{i}, true, steps[i]});
+        }
+    }
+    // one scratch block for every slab of this launch (+ the descriptor table when the caller keeps none): cmpc_ws hands out the same
+    // per-stream block on every call outside a fold collection, so separate calls would alias
+    const size_t table_room = cached ? 0 : ((size_t)m * sizeof(TnGroupDesc) + 255) / 256 * 256;
+    char* scratch = nullptr;
+    if (slab_total + table_room > 0) { scratch = (char*)cmpc_ws(slab_total + table_room, st); if (!scratch) return CMPC_EHIP; }
+    for (Fold& f : folds) f.slabs = (float*)(scratch + table_room + (size_t)(uintptr_t)f.slabs);
+    std::vector<int> idx(units.size());
+    for (size_t u = 0; u < units.size(); ++u) idx[u] = (int)u;
+    std::stable_sort(idx.begin(), idx.end(), [&](int x, int y) { return units[x].len > units[y].len; });   // long items first
+    std::vector<TnGroupDesc> sorted;
+    sorted.reserve(m);
+    int items = 0, fi = 0;
+    std::vector<int> fold_of_unit(units.size(), -1);
+    for (size_t u = 0; u < units.size(); ++u) if (units[u].slab) fold_of_unit[u] = fi++;
+    for (int ui : idx) {
+        const Unit& un = units[ui];
+        const cmpc_gemm_tn_args& h = ex[un.prods[0]];
+        const int tiles = ((h.Kv + 127) / 128) * ((h.Nv + 127) / 128);
+        const int n_items = tiles * rsplit[un.prods[0]] * h.nb * h.nb2;
+        for (size_t q = 0; q < un.prods.size(); ++q) {
+            TnGroupDesc d;
+            memset(&d, 0, sizeof(d));                  // padding bytes take part in the cache comparison
+            d.a = ex[un.prods[q]];
+            d.a.rsplit = rsplit[un.prods[q]];
+            d.tiles = tiles;
+            d.chain = q == 0 ? (int)un.prods.size() - 1 : 0;
+            d.item_begin = q == 0 ? items : items + n_items;     // followers are never the target of the item search
+            if (un.slab) { const Fold& f = folds[fold_of_unit[ui]]; d.slabs = f.slabs; d.slab_size = f.slab_size; d.lds = f.lds; }
+            sorted.push_back(d);
+        }
+        items += n_items;
     }
     const size_t bytes = (size_t)m * sizeof(TnGroupDesc);
     TnGroupDesc* table = nullptr;
@@ -1354,7 +1458,7 @@ int cmpc_gemm_tn_grouped_cached(const void* args_, int n, void* const* tables_de
             if (shadows[k].size() == bytes && memcmp(shadows[k].data(), sorted.data(), bytes) == 0) { hit = true; table = (TnGroupDesc*)tables_dev[k]; }
         if (!hit) { const int k = *victim; *victim = (k + 1) % nslots; table = (TnGroupDesc*)tables_dev[k]; shadow = &shadows[k]; }
     } else {
-        table = (TnGroupDesc*)cmpc_ws(bytes, st);
+        table = (TnGroupDesc*)scratch;
     }
     if (!table) return CMPC_EHIP;
     if (!hit) {
@@ -1368,7 +1472,11 @@ int cmpc_gemm_tn_grouped_cached(const void* args_, int n, void* const* tables_de
         if (shadow) shadow->assign((const char*)sorted.data(), (const char*)sorted.data() + bytes);
     }
     hipLaunchKernelGGL(gemm_tn_grouped_kernel, dim3(std::min(items, slots)), dim3(256), 2 * 2 * TnCfg<bf16_t>::BR * 128 * 2, st, table, m, items);
-    return cmpc_check_launch("gemm_tn_grouped");
+    if (cmpc_check_launch("gemm_tn_grouped") != CMPC_OK) return CMPC_EHIP;
+    // fixed-order sums of the slabs into the outputs (recorded into the caller's deferred-fold list when one is active and the
+    // output is a gradient: then they run with the bias / LayerNorm folds in ONE launch; otherwise launched here)
+    for (const Fold& f : folds) CK_FOLD(tn_fold(ex[f.prod], rsplit[f.prod], f.slabs, f.slab_size, f.lds, st));
+    return CMPC_OK;
 }
 
 extern "C" int cmpc_gemm_tn_grouped(const cmpc_gemm_tn_args* args, int n, void* stream) {
@@ -1382,8 +1490,30 @@ extern "C" int cmpc_gemm_tn(const cmpc_gemm_tn_args* a, void* stream) {
     if (a->R == 0) return CMPC_OK;              // empty reduction: out += 0
     dim3 grid(((a->Kv + 127) / 128) * ((a->Nv + 127) / 128), a->rsplit, a->nb * a->nb2);
     hipStream_t st = (hipStream_t)stream;
-    if (a->dtype == DT_F32) hipLaunchKernelGGL((gemm_tn_kernel<float>), grid, dim3(256), 2 * 2 * TnCfg<float>::BR * 128 * 4, st, *a);
-    else if (a->dtype == DT_BF16) hipLaunchKernelGGL((gemm_tn_kernel<bf16_t>), grid, dim3(256), 2 * 2 * TnCfg<bf16_t>::BR * 128 * 2, st, *a);
-    else hipLaunchKernelGGL((gemm_tn_kernel<f16_t>), grid, dim3(256), 2 * 2 * TnCfg<f16_t>::BR * 128 * 2, st, *a);
+    // one writer per element: an unsplit reduction adds straight into `out`; a split one (or an outer batch that shares one
+    // output, o_bs == 0) goes through per-part slabs and a fixed-order fold
+    const bool shared_out = a->nb2 > 1 && a->o_bs == 0;
+    float* slabs = nullptr; long slab_size = 0; int lds = 0;
+    if (a->rsplit > 1 || shared_out) {
+        lds = (a->Nv + 3) / 4 * 4; slab_size = (long)a->Kv * lds;
+        slabs = (float*)cmpc_ws((size_t)slab_size * a->rsplit * a->nb * a->nb2 * sizeof(float), st);
+        if (!slabs) return CMPC_EHIP;
+    }
+    if (a->dtype == DT_F32) hipLaunchKernelGGL((gemm_tn_kernel<float>), grid, dim3(256), 2 * 2 * TnCfg<float>::BR * 128 * 4, st, *a, slabs, slab_size, lds);
+    else if (a->dtype == DT_BF16) hipLaunchKernelGGL((gemm_tn_kernel<bf16_t>), grid, dim3(256), 2 * 2 * TnCfg<bf16_t>::BR * 128 * 2, st, *a, slabs, slab_size, lds);
+    else hipLaunchKernelGGL((gemm_tn_kernel<f16_t>), grid, dim3(256), 2 * 2 * TnCfg<f16_t>::BR * 128 * 2, st, *a, slabs, slab_size, lds);
+    if (slabs) {
+        if (cmpc_check_launch("gemm_tn") != CMPC_OK) return CMPC_EHIP;
+        if (shared_out) {      // every (b2, split) slab of inner entry b1 folds into the one shared region
+            for (int b1 = 0; b1 < a->nb; ++b1) {
+                // slabs are ordered [bz = b1 + nb * b2][by]: for nb == 1 the nb2 * rsplit slabs are contiguous
+                if (a->nb != 1) { cmpc_set_error("gemm_tn: o_bs == 0 needs nb == 1"); return CMPC_EINVAL; }
+                const int rc = cmpc_reduce_parts_f32(slabs, slab_size, 1, a->rsplit * a->nb2, a->Kv, lds, a->Nv, a->out + a->o_off[0], 0, a->ldo, 1, st);
+                if (rc != CMPC_OK) return rc;
+            }
+            return CMPC_OK;
+        }
+        return tn_fold(*a, a->rsplit, slabs, slab_size, lds, st);
+    }
     return cmpc_check_launch("gemm_tn");
 }

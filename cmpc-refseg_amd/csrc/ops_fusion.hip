@@ -288,7 +288,7 @@ __global__ __launch_bounds__(256) void graph_softmax_bwd2_kernel(const float* __
                                                                 const float* __restrict__ gw_w, const float* __restrict__ gw_v,
                                                                 const float* __restrict__ A0, const float* __restrict__ pr, const float* __restrict__ mask,
                                                                 const float* __restrict__ cdot, float* __restrict__ dA0, T* __restrict__ dA0_t,
-                                                                float* dpr, int N, int Tn, int Tp) {
+                                                                float* __restrict__ dpr_part, int N, int Tn, int Tp) {
     __shared__ float red[4][64];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, b = blockIdx.y, ch = blockIdx.x;
     const bool tv = lane < Tn;
@@ -317,9 +317,9 @@ __global__ __launch_bounds__(256) void graph_softmax_bwd2_kernel(const float* __
     }
     red[w][lane] = dp;
     __syncthreads();
-    if (w == 0 && tv) {
-        const float sdp = red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane];
-        if (sdp != 0.f) atomicAdd(dpr + b * Tn + lane, sdp);
+    if (w == 0) {                 // this chunk's partial row of d(parse_R) (folded over the chunks by reduce_parts: one writer per word)
+        const float sdp = tv ? red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane] : 0.f;
+        dpr_part[((long)b * gridDim.x + ch) * 64 + lane] = sdp;
     }
 }
 
@@ -541,10 +541,11 @@ extern "C" int cmpc_graph_softmax_bwd(int dt, const float* dgw_w, const float* d
     if (T_ <= 0 || T_ > 64 || Tp < T_ || Tp > 64) { cmpc_set_error("graph_softmax: need 0 < T <= Tp <= 64"); return CMPC_EINVAL; }
     if (!scratch) { cmpc_set_error("graph_softmax: scratch (B*ceil(N/64)*128 floats) required"); return CMPC_EINVAL; }
     const int ch = (N + GS_ROWS - 1) / GS_ROWS;
-    if (hipMemsetAsync(dpr, 0, sizeof(float) * B * T_, ST) != hipSuccess) { cmpc_set_error("graph_softmax_bwd: memset"); return CMPC_EHIP; }
+    float* dpr_part = scratch + (long)B * ch * 64;        // second half of the scratch: per-chunk partial rows of d(parse_R)
     hipLaunchKernelGGL(graph_softmax_bwd1_kernel, dim3(ch, B), dim3(256), 0, ST, dgw_v, gw_v, mask, scratch, N, T_, Tp);
     CMPC_DISPATCH_DT(dt, hipLaunchKernelGGL((graph_softmax_bwd2_kernel<T>), dim3(ch, B), dim3(256), 0, ST, dgw_w, dgw_v, gw_w, gw_v, A0, pr, mask,
-                                             scratch, dA0, (T*)dA0_t, dpr, N, T_, Tp));
+                                             scratch, dA0, (T*)dA0_t, dpr_part, N, T_, Tp));
+    if (cmpc_reduce_parts_f32(dpr_part, 64, B, ch, 1, 64, T_, dpr, T_, 0, 0, ST)) return CMPC_EHIP;      // dpr[b, t] = sum over the chunks
     return cmpc_check_launch("graph_softmax_bwd");
 }
 

@@ -14,13 +14,18 @@ __global__ void embed_gather_kernel(const float* __restrict__ table, const int* 
     for (int c = threadIdx.x; c < ld_out; c += blockDim.x) out[(long)r * ld_out + c] = (c < G) ? table[(long)wd * G + c] : 0.f;
 }
 
-__global__ void embed_scatter_kernel(const float* __restrict__ dout, int ld, const int* __restrict__ words, float* dtable, int G, int vocab) {
+// d(embedding table): row `wd` += sum of dout over every occurrence of word wd.  The block of the FIRST occurrence of a word adds all
+// its occurrences in index order (n_words <= a few hundred: the scan is free); the others return -- one writer per table row, no
+// atomics, a sum that does not depend on scheduling.
+__global__ void embed_scatter_kernel(const float* __restrict__ dout, int ld, const int* __restrict__ words, float* dtable, int n_words, int G, int vocab) {
     const int r = blockIdx.x;
-    int wd = words[r];
-    wd = wd < 0 ? 0 : (wd >= vocab ? vocab - 1 : wd);
+    auto clampw = [&](int w) { return w < 0 ? 0 : (w >= vocab ? vocab - 1 : w); };
+    const int wd = clampw(words[r]);
+    for (int q = 0; q < r; ++q) if (clampw(words[q]) == wd) return;          // not the first occurrence
     for (int c = threadIdx.x; c < G; c += blockDim.x) {
-        const float g = dout[(long)r * ld + c];
-        if (g != 0.f) atomicAdd(dtable + (long)wd * G + c, g);
+        float g = 0.f;
+        for (int q = r; q < n_words; ++q) if (clampw(words[q]) == wd) g += dout[(long)q * ld + c];
+        dtable[(long)wd * G + c] += g;
     }
 }
 
@@ -338,7 +343,7 @@ extern "C" int cmpc_embed_gather(const float* table, const int* words, float* ou
 }
 extern "C" int cmpc_embed_scatter(const float* dout, int ld, const int* words, float* dtable, int n_words, int G, int vocab, void* stream) {
     if (n_words <= 0) return CMPC_OK;
-    hipLaunchKernelGGL(embed_scatter_kernel, dim3(n_words), dim3(128), 0, ST, dout, ld, words, dtable, G, vocab);
+    hipLaunchKernelGGL(embed_scatter_kernel, dim3(n_words), dim3(128), 0, ST, dout, ld, words, dtable, n_words, G, vocab);
     return cmpc_check_launch("embed_scatter");
 }
 extern "C" int cmpc_lstm_cell_fwd(float* gates, const float* c_prev, const float* h_prev, const int* seq_len, int t,

@@ -55,11 +55,11 @@ void* cmpc_ws(size_t bytes, hipStream_t st) {
     return slot->p;
 }
 
-// Column-parallel fold of per-workgroup partial rows: a block owns 64 columns (lane = column, so every
-// part row is read as one 256-B line), its 4 waves and gridDim.z slices split the rows; the few
-// slices of one column meet in a low-contention atomic.
+// Column-parallel fold of per-workgroup partial rows: a block owns 64 columns (lane = column, so every part row is read as one 256-B
+// line) of one outer index and walks ALL its partial rows, its 4 waves taking rows w, w+4, ... and meeting in LDS in a fixed order:
+// exactly one writer per output element, no atomics, a sum that does not depend on scheduling.
 __global__ __launch_bounds__(256) void reduce_parts_f32_kernel(const float* __restrict__ part, long part_stride, int ninner, int nseg, int seg_ld, int seg_C,
-                                                              float* __restrict__ out, long ld_out, long out_seg) {
+                                                              float* __restrict__ out, long ld_out, long out_seg, int accumulate) {
     __shared__ float red[4][64];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int j = blockIdx.x * 64 + lane;
@@ -67,23 +67,22 @@ __global__ __launch_bounds__(256) void reduce_parts_f32_kernel(const float* __re
     const bool ok = j < nseg * seg_ld;
     const int seg = ok ? j / seg_ld : 0, c = ok ? j - seg * seg_ld : 0;
     const bool valid = ok && c < seg_C;
-    const int per = (ninner + gridDim.z - 1) / gridDim.z;
-    const int i0 = blockIdx.z * per, i1 = min(ninner, i0 + per);
     const float* p = part + (long)o * ninner * part_stride + j;
     float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
     if (valid) {
-        int i = i0 + w;
-        for (; i + 12 < i1; i += 16) {
+        int i = w;
+        for (; i + 12 < ninner; i += 16) {
             s0 += p[(long)i * part_stride]; s1 += p[(long)(i + 4) * part_stride];
             s2 += p[(long)(i + 8) * part_stride]; s3 += p[(long)(i + 12) * part_stride];
         }
-        for (; i < i1; i += 4) s0 += p[(long)i * part_stride];
+        for (; i < ninner; i += 4) s0 += p[(long)i * part_stride];
     }
     red[w][lane] = (s0 + s1) + (s2 + s3);
     __syncthreads();
     if (w == 0 && valid) {
         const float s = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
-        if (s != 0.f) atomicAdd(out + (long)o * ld_out + (long)seg * out_seg + c, s);
+        float* dst = out + (long)o * ld_out + (long)seg * out_seg + c;
+        *dst = accumulate ? *dst + s : s;
     }
 }
 __global__ __launch_bounds__(64) void reduce_parts_f64_kernel(const double* __restrict__ part, int ninner, int nval, double* __restrict__ out) {
@@ -110,22 +109,27 @@ __global__ __launch_bounds__(256) void reduce_parts_grouped_kernel(const cmpc_fo
     const bool ok = j < cols;
     const int seg = ok ? j / d.seg_ld : 0, c = ok ? j - seg * d.seg_ld : 0;
     const bool valid = ok && c < d.seg_C;
-    const float* p = d.part + (long)o * d.ninner * d.part_stride + j;
-    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-    if (valid) {
-        int i = w;
-        for (; i + 12 < d.ninner; i += 16) {
-            s0 += p[(long)i * d.part_stride]; s1 += p[(long)(i + 4) * d.part_stride];
-            s2 += p[(long)(i + 8) * d.part_stride]; s3 += p[(long)(i + 12) * d.part_stride];
+    float tot = 0.f;
+    // descriptors chained behind d fold into the same target (e.g. the three ConvLSTM steps' LayerNorm gradients): summed here in
+    // list order, one writer per element
+    for (int q = 0; q <= d.chain; ++q) {
+        const cmpc_fold_desc& e = table[lo + q];
+        const float* p = e.part + (long)o * e.ninner * e.part_stride + j;
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+        if (valid) {
+            int i = w;
+            for (; i + 12 < e.ninner; i += 16) {
+                s0 += p[(long)i * e.part_stride]; s1 += p[(long)(i + 4) * e.part_stride];
+                s2 += p[(long)(i + 8) * e.part_stride]; s3 += p[(long)(i + 12) * e.part_stride];
+            }
+            for (; i < e.ninner; i += 4) s0 += p[(long)i * e.part_stride];
         }
-        for (; i < d.ninner; i += 4) s0 += p[(long)i * d.part_stride];
+        __syncthreads();
+        red[w][lane] = (s0 + s1) + (s2 + s3);
+        __syncthreads();
+        tot += (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
     }
-    red[w][lane] = (s0 + s1) + (s2 + s3);
-    __syncthreads();
-    if (w == 0 && valid) {
-        const float s = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
-        if (s != 0.f) atomicAdd(d.out + (long)o * d.ld_out + (long)seg * d.out_seg + c, s);
-    }
+    if (w == 0 && valid) d.out[(long)o * d.ld_out + (long)seg * d.out_seg + c] += tot;
 }
 #define FOLD_UPLOAD 48
 struct FoldUploadArgs { int n, base; cmpc_fold_desc d[FOLD_UPLOAD]; };
@@ -137,11 +141,28 @@ __global__ void fold_desc_upload_kernel(const FoldUploadArgs ua, cmpc_fold_desc*
 }
 static int fold_launch(cmpc_fold_desc* descs, int n, cmpc_fold_desc* table_dev, cmpc_fold_desc* shadow, int* shadow_n, hipStream_t st) {
     if (n == 0) return CMPC_OK;
+    // folds with the same target and shape become one chain (head first, `chain` = number of followers): a single block sums them
+    std::vector<cmpc_fold_desc> sorted;
+    std::vector<char> used(n, 0);
+    sorted.reserve(n);
     int blocks = 0;
     for (int i = 0; i < n; ++i) {
-        descs[i].blk_begin = blocks;
-        blocks += ((descs[i].nseg * descs[i].seg_ld + 63) / 64) * descs[i].nouter;
+        if (used[i]) continue;
+        const size_t head = sorted.size();
+        for (int k = i; k < n; ++k) {
+            const cmpc_fold_desc &a = descs[i], &b = descs[k];
+            if (used[k] || a.out != b.out || a.nouter != b.nouter || a.nseg != b.nseg || a.seg_ld != b.seg_ld || a.seg_C != b.seg_C ||
+                a.ld_out != b.ld_out || a.out_seg != b.out_seg) continue;
+            used[k] = 1;
+            sorted.push_back(b);
+        }
+        const int nb = ((descs[i].nseg * descs[i].seg_ld + 63) / 64) * descs[i].nouter;
+        for (size_t k = head; k < sorted.size(); ++k) { sorted[k].chain = 0; sorted[k].blk_begin = blocks + nb; }   // followers are never searched for
+        sorted[head].chain = (int)(sorted.size() - head) - 1;
+        sorted[head].blk_begin = blocks;
+        blocks += nb;
     }
+    memcpy(descs, sorted.data(), sizeof(cmpc_fold_desc) * n);
     if (*shadow_n != n || memcmp(shadow, descs, sizeof(cmpc_fold_desc) * n) != 0) {
         for (int c0 = 0; c0 < n; c0 += FOLD_UPLOAD) {     // through the kernel-argument segment: asynchronous, no host buffer lifetime issue
             FoldUploadArgs ua;
@@ -180,16 +201,14 @@ int cmpc_fold_flush_ranges(cmpc_fold_ctx* ctx, const float* const* lo, const flo
 int cmpc_reduce_parts_f32(const float* part, long part_stride, int nouter, int ninner, int nseg, int seg_ld, int seg_C,
                           float* out, long ld_out, long out_seg, int accumulate, hipStream_t st) {
     const int cols = nseg * seg_ld;
-    if (!accumulate) { cmpc_set_error("reduce_parts_f32: only the accumulating form is implemented"); return CMPC_EINVAL; }
-    if (t_fold && out >= t_fold->lo && out < t_fold->hi && t_fold->n < t_fold->table_cap &&
+    if (accumulate && t_fold && out >= t_fold->lo && out < t_fold->hi && t_fold->n < t_fold->table_cap &&
         (const char*)part >= t_fold->arena && (const char*)part < t_fold->arena + t_fold->cap) {
         // the target is read by nothing before the optimizer and the partial rows are not recycled: fold later, with all the others
-        t_fold->descs[t_fold->n++] = cmpc_fold_desc{part, part_stride, nouter, ninner, nseg, seg_ld, seg_C, 0, out, ld_out, out_seg};
+        t_fold->descs[t_fold->n++] = cmpc_fold_desc{part, part_stride, nouter, ninner, nseg, seg_ld, seg_C, 0, out, ld_out, out_seg, 0, 0};
         return CMPC_OK;
     }
-    int nz = ninner / 32; nz = nz < 1 ? 1 : (nz > 16 ? 16 : nz);
-    hipLaunchKernelGGL(reduce_parts_f32_kernel, dim3((cols + 63) / 64, nouter, nz), dim3(256), 0, st, part, part_stride, ninner, nseg, seg_ld, seg_C,
-                       out, ld_out, out_seg);
+    hipLaunchKernelGGL(reduce_parts_f32_kernel, dim3((cols + 63) / 64, nouter), dim3(256), 0, st, part, part_stride, ninner, nseg, seg_ld, seg_C,
+                       out, ld_out, out_seg, accumulate);
     return cmpc_check_launch("reduce_parts_f32");
 }
 int cmpc_reduce_parts_f64(const double* part, int nouter, int ninner, int nval, double* out, hipStream_t st) {

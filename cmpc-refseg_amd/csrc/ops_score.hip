@@ -177,7 +177,7 @@ __global__ __launch_bounds__(256) void score_conv_bwd_data_row_kernel(const floa
 
 // dW[tap,m] += sum_pixels dscore[b, y-dy, x-dx] * feat[b,y,x,m];  dbias += sum dscore
 template <typename T>
-__global__ __launch_bounds__(256) void score_conv_bwd_w_kernel(const float* __restrict__ dscore, const T* __restrict__ feat, float* part, float* dbias,
+__global__ __launch_bounds__(256) void score_conv_bwd_w_kernel(const float* __restrict__ dscore, const T* __restrict__ feat, float* part, float* bias_part,
                                                               int B, int h, int w, int ld, int M) {
     extern __shared__ float lds[];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -229,7 +229,11 @@ __global__ __launch_bounds__(256) void score_conv_bwd_w_kernel(const float* __re
         for (int c = threadIdx.x; c < ld; c += 256)
             pr[c] = (c < M) ? lds[c] + lds[ld + c] + lds[2 * ld + c] + lds[3 * ld + c] : 0.f;
     }
-    if (lane == 0 && sb != 0.f) atomicAdd(dbias, sb);
+    // bias gradient: this workgroup's partial (its 4 waves in a fixed order), folded over the workgroups by reduce_parts
+    __syncthreads();
+    if (lane == 0) lds[wv] = sb;
+    __syncthreads();
+    if (threadIdx.x == 0) bias_part[blockIdx.x] = (lds[0] + lds[1]) + (lds[2] + lds[3]);
 }
 
 // tf.image.resize_bilinear (align_corners=False, legacy): in = out_idx * (in_size / out_size) in
@@ -242,7 +246,7 @@ __device__ __forceinline__ void interp_coef(int o, float scale, int n_in, int& l
 }
 
 __global__ __launch_bounds__(256) void upsample_fwd_kernel(const float* __restrict__ score, float* __restrict__ up, float* __restrict__ sigm,
-                                                          const float* __restrict__ target, float* loss, int* inter, int* uni,
+                                                          const float* __restrict__ target, float* loss_part, int* inter, int* uni,
                                                           int h, int w, int H, int W) {
     __shared__ float red[4];
     const int b = blockIdx.y;
@@ -272,7 +276,8 @@ __global__ __launch_bounds__(256) void upsample_fwd_kernel(const float* __restri
         ls = block_sum_256(ls, red);
         const float fi = block_sum_256((float)ci, red);
         const float fu = block_sum_256((float)cu, red);
-        if (threadIdx.x == 0) { atomicAdd(loss + b, ls); atomicAdd(inter + b, (int)(fi + 0.5f)); atomicAdd(uni + b, (int)(fu + 0.5f)); }
+        // loss: this workgroup's partial (folded in a fixed order by reduce_parts); the pixel counters are integers: atomics are exact
+        if (threadIdx.x == 0) { loss_part[(long)b * gridDim.x + blockIdx.x] = ls; atomicAdd(inter + b, (int)(fi + 0.5f)); atomicAdd(uni + b, (int)(fu + 0.5f)); }
     }
 }
 
@@ -331,11 +336,13 @@ extern "C" int cmpc_score_conv_bwd(int dt, const float* dscore, const void* feat
     });
     if (dWk) {
         const int gw = g > 256 ? 256 : g;
-        float* part = (float*)cmpc_ws((size_t)gw * 9 * ld * sizeof(float), ST);
+        float* part = (float*)cmpc_ws(((size_t)gw * 9 * ld + gw) * sizeof(float), ST);
         if (!part) return CMPC_EHIP;
+        float* bias_part = part + (size_t)gw * 9 * ld;
         CMPC_DISPATCH_DT(dt, hipLaunchKernelGGL((score_conv_bwd_w_kernel<T>), dim3(gw), dim3(256), WPB * ld * sizeof(float), ST,
-                                                 dscore, (const T*)feat, part, dbias, B, h, w, ld, M));
+                                                 dscore, (const T*)feat, part, bias_part, B, h, w, ld, M));
         if (cmpc_reduce_parts_f32(part, 9L * ld, 1, gw, 9, ld, M, dWk, 0, M, 1, ST)) return CMPC_EHIP;
+        if (dbias && cmpc_reduce_parts_f32(bias_part, 1, 1, gw, 1, 1, 1, dbias, 0, 0, 1, ST)) return CMPC_EHIP;
     }
     return cmpc_check_launch("score_conv_bwd");
 }
@@ -344,7 +351,10 @@ extern "C" int cmpc_upsample_fwd(const float* score, float* up, float* sigm, con
                                  int* inter, int* uni, int B, int h, int w, int H, int W, void* stream) {
     if (target && (!loss || !inter || !uni)) { cmpc_set_error("upsample_fwd: loss/inter/uni required with target"); return CMPC_EINVAL; }
     const int gx = (H * W + 255) / 256 > 64 ? 64 : (H * W + 255) / 256;
-    hipLaunchKernelGGL(upsample_fwd_kernel, dim3(gx, B), dim3(256), 0, ST, score, up, sigm, target, loss, inter, uni, h, w, H, W);
+    float* loss_part = nullptr;
+    if (target) { loss_part = (float*)cmpc_ws((size_t)B * gx * sizeof(float), ST); if (!loss_part) return CMPC_EHIP; }
+    hipLaunchKernelGGL(upsample_fwd_kernel, dim3(gx, B), dim3(256), 0, ST, score, up, sigm, target, loss_part, inter, uni, h, w, H, W);
+    if (target && cmpc_reduce_parts_f32(loss_part, 1, B, gx, 1, 1, 1, loss, 1, 0, 1, ST)) return CMPC_EHIP;       // loss[b] += sum over the workgroups
     return cmpc_check_launch("upsample_fwd");
 }
 
