@@ -7,8 +7,8 @@ gradient all-reduce + fused Adam) at 320x320, L=20, B=8 per GPU, synthetic data.
          bench.py --gpus N --steps K --warmup W
 
 Prints ONE JSON line on rank 0 (contract in the project brief): metric/value/unit, ms_per_step,
-`roofline` for the dominant kernel (the bf16 MFMA gemm_nt, timed live with events on the launch
-stream) and `cpu_baseline` (the oracle -- a torch-CPU fp32 restatement of the reference graph,
+`roofline` for the dominant kernel family (the 16-bit MFMA gemm_nt, timed live with hipEvents on the launch
+stream inside the library: cmpc_kernel_timing) and `cpu_baseline` (the oracle -- a torch-CPU fp32 restatement of the reference graph,
 since TensorFlow cannot run here -- timed on this box's host cores on a bounded sample).
 """
 from __future__ import annotations
@@ -48,8 +48,9 @@ def synth_batch(B, T, H, W, vocab, seed):
 
 
 def cpu_baseline(args):
-    """The oracle (test infrastructure) timed as the CPU baseline: one full train step
-    (backbone forward + head forward/backward + TF-Adam) on `cpu_images` synthetic images."""
+    """The oracle (test infrastructure) timed as the CPU baseline on this box's host cores: BASELINE.json config 2's train step
+    (backbone forward + head forward/backward + TF-Adam, batch of `cpu_images`) -- the `value` -- and config 1 (4 images, forward
+    only: the reference's own CPU-runnable case) next to it."""
     from oracle import cmpc_torch as O
     # the GPU box gives one GPU a 16-core CPU share; os.cpu_count() reports the whole host
     try:
@@ -74,7 +75,20 @@ def cpu_baseline(args):
         dt = time.time() - t0
         log(f"cpu baseline step {step}: {dt:.1f} s")
         best = dt if best is None else min(best, dt)
+    # config 1: 4 images, forward only
+    cfg4 = O.Cfg(batch_size=4)
+    hp4 = O.init_head_params(cfg4)
+    w4, im4, sl4, _ = map(torch.from_numpy, synth_batch(4, cfg4.num_steps, cfg4.H, cfg4.W, cfg4.vocab_size, 7))
+    best4 = None
+    for _ in range(2):
+        t0 = time.time()
+        with torch.no_grad():
+            O.head_forward(hp4, O.backbone_forward(bp, im4, cfg4), w4, sl4, cfg4)
+        d4 = time.time() - t0
+        best4 = d4 if best4 is None else min(best4, d4)
+    log(f"cpu baseline forward (4 images): {best4:.1f} s")
     return {"value": B / best, "unit": "images/sec", "cores": nthreads, "kind": "port",
+            "forward_only_config1": {"images_per_sec": 4 / best4, "s_per_batch": best4, "what": "BASELINE config 1: 4 images 320x320 L=20, forward only"},
             "sample": f"best of {args.cpu_steps} train steps (backbone fwd + head fwd/bwd + Adam) on a batch of {B} synthetic "
                       f"320x320 L=20 images, torch-CPU fp32 restatement of the TF graph (TensorFlow unavailable), {best:.1f} s/step"}
 
