@@ -18,6 +18,7 @@
 #include <stdarg.h>
 #include <stdio.h>
 #include <array>
+#include <map>
 #include <stdlib.h>
 #include <string.h>
 #include <algorithm>
@@ -216,7 +217,7 @@ struct cmpc_engine_s {
     long launches_step = 0;
     // optional per-launch timing of the dominant kernel family (bench.py's roofline): event pairs around every bf16 MFMA gemm_nt
     bool marks_on = false; std::vector<std::pair<std::string, hipEvent_t>> marks;     // phase-boundary timestamps (cmpc_phase_marks)
-    bool timing = false; std::vector<hipEvent_t> tev; std::vector<double> tflops, tbytes;
+    bool timing = false; std::vector<hipEvent_t> tev; std::vector<double> tflops, tbytes; std::vector<std::array<int, 4>> tshape;
 };
 
 namespace {
@@ -616,6 +617,7 @@ int gemm_nt(hipStream_t st, int dt, std::initializer_list<Seg> segs, void* C, in
         for (const Seg& s : segs) kalg += (s.A == te->spatial && s.K == 64) ? 8 : valid_extent(te, s.K);
         const double nv = valid_extent(te, o.n_valid < 0 ? N : o.n_valid), rows = (double)M * o.batch;
         te->tev.push_back(e0); te->tev.push_back(e1);
+        { int kp = 0; for (const Seg& s : segs) kp += s.K; te->tshape.push_back({M * o.batch, N, kp, (int)segs.size()}); }
         te->tflops.push_back(2.0 * rows * nv * kalg);
         te->tbytes.push_back(2.0 * (rows * (kalg + nv) + nv * kalg));        // A and C once per row, the weight once (bf16)
         return rc;
@@ -1378,7 +1380,7 @@ extern "C" int cmpc_set_lanes(cmpc_handle e, int n_lanes) {
 extern "C" int cmpc_kernel_timing(cmpc_handle e, int enable) {
     if (!e) { cmpc_set_error("kernel_timing: null handle"); return CMPC_EINVAL; }
     for (hipEvent_t ev : e->tev) (void)hipEventDestroy(ev);
-    e->tev.clear(); e->tflops.clear(); e->tbytes.clear();
+    e->tev.clear(); e->tflops.clear(); e->tbytes.clear(); e->tshape.clear();
     e->timing = enable != 0;
     return CMPC_OK;
 }
@@ -1391,6 +1393,16 @@ extern "C" int cmpc_kernel_timing_read(cmpc_handle e, double* ms, double* flops,
         float dt_ms = 0.f;
         HCK(hipEventElapsedTime(&dt_ms, e->tev[2 * i], e->tev[2 * i + 1]));
         t += dt_ms; f += e->tflops[i]; b += e->tbytes[i];
+    }
+    if (getenv("CMPC_TIMING_DUMP")) {            // per-shape breakdown on stderr (diagnostic)
+        std::map<std::array<int, 4>, std::array<double, 3>> agg;
+        for (size_t i = 0; i < e->tflops.size(); ++i) {
+            float d = 0.f; (void)hipEventElapsedTime(&d, e->tev[2 * i], e->tev[2 * i + 1]);
+            auto& a = agg[e->tshape[i]]; a[0] += d; a[1] += e->tflops[i]; a[2] += 1;
+        }
+        for (auto& kv : agg)
+            fprintf(stderr, "[gemm_nt] M=%6d N=%5d K=%5d segs=%d  launches %5.0f  total %8.3f ms  avg %7.1f us  %7.1f TFLOP/s\n", kv.first[0], kv.first[1], kv.first[2],
+                    kv.first[3], kv.second[2], kv.second[0], 1e3 * kv.second[0] / kv.second[2], kv.second[1] / kv.second[0] / 1e9);
     }
     if (ms) *ms = t;
     if (flops) *flops = f;

@@ -7,6 +7,7 @@
 #include <stdarg.h>
 #include <stdio.h>
 #include <string.h>
+#include <mutex>
 
 // ------------------------------------------------------------------------------------------
 // error plumbing shared by all translation units
@@ -33,6 +34,8 @@ void* cmpc_ws(size_t bytes, hipStream_t st) {
         const size_t need = (bytes + 255) / 256 * 256;
         if (t_fold->off + need <= t_fold->cap) { void* p = t_fold->arena + t_fold->off; t_fold->off += need; return p; }
     }
+    static std::mutex mu;                   // the slot table is shared by every handle / host thread of the process
+    std::lock_guard<std::mutex> lock(mu);
     WsSlot* slot = nullptr;
     for (auto& w : g_ws) if (w.used && w.st == st) { slot = &w; break; }
     if (!slot) {
