@@ -88,7 +88,9 @@ class LSTM_model(object):
             self.comm_stream = torch.cuda.Stream(device=self.device)       # gradient all-reduce (data-parallel runs)
             self.bb_stream, self.opt_stream = self._side if n_lanes > 1 else (None, None)
             self.backbone = bb.DeepLabResNet(backbone_width, backbone_blocks)
-            self.backbone.load_tf(backbone_params if backbone_params is not None else bb.init_params(backbone_width, backbone_blocks))
+            # the frozen backbone's variables under their TensorFlow names (deeplab_resnet/model.py): kept for checkpoints
+            self.backbone_vars = dict(backbone_params if backbone_params is not None else bb.init_params(backbone_width, backbone_blocks))
+            self.backbone.load_tf(self.backbone_vars)
             self.backbone = self.backbone.to(self.device).to(tdt(self.dt)).to(memory_format=torch.channels_last).eval()
         self.world = 1
         self.last = {}
@@ -281,6 +283,16 @@ class LSTM_model(object):
         with torch.cuda.device(self.device):
             torch.cuda.synchronize(self.device)
             self.eng.load_state(named)
+
+    def load_backbone(self, named: Dict[str, torch.Tensor]):
+        """Restore the frozen backbone from TensorFlow-named variables (`conv1/weights`, `bn2a_branch2a/gamma`, ...:
+        trainval_model.py:50-54 loads exactly this subset from deeplab_resnet_init.ckpt).  Frozen batch-norms are re-folded; the
+        captured backbone graphs stay valid (weights are updated in place)."""
+        with torch.cuda.device(self.device):
+            torch.cuda.synchronize(self.device)
+            self.backbone_vars = dict(named)
+            self.backbone.load_tf(self.backbone_vars)
+            torch.cuda.synchronize(self.device)
 
     def enable_data_parallel(self):
         """One process per GPU; rank 0's weights are broadcast; gradients are summed bucket by bucket while the backward pass

@@ -2,6 +2,8 @@
 (util/text_processing.py:17-67, trainval_model.py:90-91,267-296, util/im_processing.py:7-41, util/eval_tools.py:31-35)."""
 import importlib
 
+import os
+
 import numpy as np
 import pytest
 
@@ -62,3 +64,35 @@ def test_seg_eval_accumulators():
     assert r["precision@0.5"] == pytest.approx(2 / 3) and r["precision@0.6"] == pytest.approx(1 / 3) and r["precision@0.9"] == pytest.approx(1 / 3)
     with pytest.raises(ValueError):
         H.compute_mask_IU(np.zeros((3, 4), bool), gt)
+
+
+def test_saver_rotation_and_names(tmp_path):
+    """checkpoint.Saver without a GPU: file naming `<prefix>-<step>.npz`, max_to_keep rotation (trainval_model.py:56), TensorFlow
+    variable names incl. the Adam slots, backbone-only filter (trainval_model.py:50-54)."""
+    import types
+    import torch
+    CK = importlib.import_module("cmpc-refseg_amd.checkpoint")
+    idx = {"text_objseg/c5_lateral/DW": (0, (1, 1, 2, 3)), "text_objseg/c5_lateral/biases": (8, (3,))}
+    eng = types.SimpleNamespace(index=idx, params=torch.arange(12.0), m=torch.ones(12), v=torch.full((12,), 2.0), step=0)
+    model = types.SimpleNamespace(eng=eng, device=torch.device("cpu"), backbone_vars={"conv1/weights": torch.zeros(7, 7, 3, 4), "bn_conv1/gamma": torch.ones(4)})
+    orig = torch.cuda.synchronize
+    torch.cuda.synchronize = lambda *a, **k: None
+    try:
+        sv = CK.Saver(max_to_keep=2)
+        paths = []
+        for step in (5, 10, 15):
+            eng.step = step
+            paths.append(sv.save(model, str(tmp_path / "snap")))
+        assert [os.path.basename(p) for p in paths] == ["snap-5.npz", "snap-10.npz", "snap-15.npz"]
+        assert sorted(os.listdir(tmp_path)) == ["snap-10.npz", "snap-15.npz"] and CK.latest_checkpoint(str(tmp_path / "snap")).endswith("snap-15.npz")
+        z = np.load(paths[-1], allow_pickle=False)
+        keys = {k.replace("|", "/") for k in z.files}
+        assert {"text_objseg/c5_lateral/DW", "text_objseg/c5_lateral/DW/Adam", "text_objseg/c5_lateral/biases/Adam_1", "global_step", "beta1_power",
+                "beta2_power", "conv1/weights", "bn_conv1/gamma"} <= keys
+        assert int(z["global_step"]) == 15 and z["text_objseg|c5_lateral|DW"].shape == (1, 1, 2, 3)
+        assert float(z["beta1_power"]) == pytest.approx(0.9 ** 16, rel=1e-6)
+        assert np.array_equal(z["text_objseg|c5_lateral|biases"], np.arange(8.0, 11.0, dtype=np.float32))
+        only_bb = CK.Saver(var_filter=CK.is_backbone_var).save(model, str(tmp_path / "bb"), global_step=0)
+        assert {k.replace("|", "/") for k in np.load(only_bb).files} == {"conv1/weights", "bn_conv1/gamma"}
+    finally:
+        torch.cuda.synchronize = orig
