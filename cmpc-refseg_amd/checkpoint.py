@@ -1,16 +1,18 @@
 """Checkpoints in the reference's variable name space -- the counterpart of the tf.train.Saver calls of the reference's driver
 (trainval_model.py:46-63 restore, :56 `Saver(max_to_keep=4)`, :136-142 save, :82 resume via -lastiter).
 
-A checkpoint is ONE `.npz` file (plain NumPy arrays, loaded with allow_pickle=False) whose keys are the TensorFlow variable names the
-reference graph creates:
+Two on-disk forms, same variable name space:
+  * TensorFlow's own: `<prefix>-<step>.index` + `.data-00000-of-00001` (tf_bundle.py reads and writes the tensor-bundle format without
+    TensorFlow), so `deeplab_resnet_init.ckpt` and the reference's snapshots load directly and the snapshots written here load in the
+    reference: `Saver(fmt="tf")`;
+  * ONE `.npz` file (plain NumPy arrays, loaded with allow_pickle=False): `Saver(fmt="npz")`, the default.
+The keys / variable names are the ones the reference graph creates:
     text_objseg/<scope>/DW, .../biases, .../beta, .../gamma, text_objseg/Variable (GloVe table), text_objseg/rnn/...   head
     <var>/Adam, <var>/Adam_1                    AdamOptimizer slots m and v of every trainable head variable
     beta1_power, beta2_power, global_step       AdamOptimizer's non-slot variables and the step counter (CMPC_model.py:450)
     conv1/weights, bn_conv1/gamma, res2a_branch2a/weights, bn2a_branch2a/moving_mean, ...   frozen backbone (deeplab_resnet/model.py)
-A TensorFlow checkpoint is brought into this form on any machine that has TensorFlow with
-    r = tf.train.load_checkpoint(ckpt); np.savez(out, **{n: r.get_tensor(n) for n in r.get_variable_to_shape_map()})
-(the tensor-bundle format itself is not read here: TensorFlow is not available in this image and the reference ships no checkpoint
-to test a reader against).
+The tensor-bundle reader is pinned by round trips and format known-answers only: TensorFlow is not available in this image and the
+reference ships no checkpoint to test it against (tests/test_tf_bundle.py).
 """
 from __future__ import annotations
 
@@ -21,6 +23,8 @@ from typing import Callable, Dict, Iterable, Optional
 
 import numpy as np
 import torch
+
+from . import tf_bundle
 
 BACKBONE_PREFIXES = ("res", "bn", "conv1")          # the subset `trainval_model.py:50-54` restores from deeplab_resnet_init.ckpt
 
@@ -86,37 +90,61 @@ def restore_variables(model, variables: Dict[str, np.ndarray], var_filter: Optio
 
 
 class Saver:
-    """tf.train.Saver(var_list=None, max_to_keep=4) for LSTM_model.  save() writes `<prefix>-<global_step>.npz` and deletes all but the
-    newest `max_to_keep` files of that prefix; restore() reads one file (optionally only the variables `var_filter` selects:
+    """tf.train.Saver(var_list=None, max_to_keep=4) for LSTM_model.  save() writes `<prefix>-<global_step>` (fmt "npz": one `.npz`
+    file; fmt "tf": TensorFlow's `.index` + `.data-00000-of-00001` pair and the `checkpoint` state file) and deletes all but the
+    newest `max_to_keep` snapshots of that prefix; restore() reads either form (optionally only the variables `var_filter` selects:
     `Saver(var_filter=is_backbone_var)` is the backbone-only restore of trainval_model.py:50-54)."""
 
-    def __init__(self, var_filter: Optional[Callable[[str], bool]] = None, max_to_keep: int = 4):
-        self.var_filter, self.max_to_keep = var_filter, max_to_keep
+    def __init__(self, var_filter: Optional[Callable[[str], bool]] = None, max_to_keep: int = 4, fmt: str = "npz"):
+        if fmt not in ("npz", "tf"):
+            raise ValueError("fmt must be 'npz' or 'tf'")
+        self.var_filter, self.max_to_keep, self.fmt = var_filter, max_to_keep, fmt
 
     def save(self, model, prefix: str, global_step: Optional[int] = None) -> str:
         vs = model_variables(model)
         if self.var_filter is not None:
             vs = {k: v for k, v in vs.items() if self.var_filter(k)}
         step = int(vs.get("global_step", 0)) if global_step is None else int(global_step)
-        path = f"{prefix}-{step}.npz"
-        os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)
-        np.savez(path, **{k.replace("/", "|"): v for k, v in vs.items()})      # '/' is not portable inside zip member names
+        os.makedirs(os.path.dirname(os.path.abspath(prefix)), exist_ok=True)
+        if self.fmt == "tf":
+            path = f"{prefix}-{step}"
+            tf_bundle.write_bundle(path, vs)
+        else:
+            path = f"{prefix}-{step}.npz"
+            np.savez(path, **{k.replace("/", "|"): v for k, v in vs.items()})      # '/' is not portable inside zip member names
+        kept = _snapshots(prefix)
         if self.max_to_keep and self.max_to_keep > 0:
-            pat = re.compile(re.escape(os.path.basename(prefix)) + r"-(\d+)\.npz$")
-            files = [(int(pat.search(os.path.basename(f)).group(1)), f) for f in glob.glob(f"{prefix}-*.npz") if pat.search(os.path.basename(f))]
-            for _, f in sorted(files)[:-self.max_to_keep]:
-                os.remove(f)
+            for _, p in kept[:-self.max_to_keep]:
+                for f in ([p] if p.endswith(".npz") else [p + ".index"] + glob.glob(glob.escape(p) + ".data-*")):
+                    os.remove(f)
+            kept = kept[-self.max_to_keep:]
+        if self.fmt == "tf":
+            d = os.path.dirname(os.path.abspath(prefix))
+            tf_bundle.write_checkpoint_state(d, os.path.basename(path), [os.path.basename(p) for _, p in kept if not p.endswith(".npz")])
         return path
 
     def restore(self, model, path: str, strict: bool = True):
-        with np.load(path, allow_pickle=False) as z:
-            vs = {k.replace("|", "/"): z[k] for k in z.files}
+        if os.path.exists(path + ".index"):
+            vs = tf_bundle.read_bundle(path)
+        else:
+            with np.load(path, allow_pickle=False) as z:
+                vs = {k.replace("|", "/"): z[k] for k in z.files}
         restore_variables(model, vs, self.var_filter, strict=strict)
         return vs
 
 
+def _snapshots(prefix: str):
+    """[(step, path)] of the snapshots of `prefix`, oldest first; path = the .npz file or the TensorFlow checkpoint prefix."""
+    pat = re.compile(re.escape(os.path.basename(prefix)) + r"-(\d+)(\.npz|\.index)$")
+    out = []
+    for f in glob.glob(glob.escape(prefix) + "-*"):
+        m = pat.search(os.path.basename(f))
+        if m:
+            out.append((int(m.group(1)), f if m.group(2) == ".npz" else f[: -len(".index")]))
+    return sorted(out)
+
+
 def latest_checkpoint(prefix: str) -> Optional[str]:
-    """tf.train.latest_checkpoint for files written by Saver.save."""
-    pat = re.compile(r"-(\d+)\.npz$")
-    files = [(int(pat.search(f).group(1)), f) for f in glob.glob(f"{prefix}-*.npz") if pat.search(f)]
-    return max(files)[1] if files else None
+    """tf.train.latest_checkpoint for snapshots written by Saver.save (either form): the one with the largest step."""
+    snaps = _snapshots(prefix)
+    return snaps[-1][1] if snaps else None

@@ -210,6 +210,7 @@ struct cmpc_engine_s {
     // buffer sets, so the lateral products' operand pointers alternate): a table that matches a cached one is not uploaded again
     void* tn_table[NBK][4] = {}; size_t tn_table_bytes = 0; std::vector<char> tn_shadow[NBK][4]; int tn_victim[NBK] = {};
     bool wgrad_overlap = true;          // issue the levels' / exchanges' dW beside the text encoder's backward chain
+    bool mutan_epilogue = false;        // the Mutan heads' tanh as the epilogue of their GEMM (measured slower in the 3-lane step: DESIGN.md)
     cmpc_fold_ctx fold;                 // deferred bias / LayerNorm / peephole gradient folds (one launch per backward pass)
     std::vector<cmpc_fold_desc> fold_descs, fold_shadow[NBK]; cmpc_fold_desc* fold_table[NBK] = {}; int fold_shadow_n[NBK];
     std::vector<Tap> taps;
@@ -795,9 +796,9 @@ int level_fwd(E* e, hipStream_t st, int li, const float* target) {
     { GemmOpt o; o.bias = (const float*)opp(e, fmt("mlang_%s.b", lv)); o.act = ACT_TANH;
       CK(gemm_nt(st, DT_F32, {{e->vl, Cp, opp(e, fmt("mlang_%s.t", lv)), Cp, Cp}}, L.g, 5 * Cp, B, 5 * Cp, o));
       const int ldk = Cp + 64; const std::string k = fmt("mutan_%s.t", lv);
-      GemmOpt p; p.bias = (const float*)opp(e, fmt("mutan_%s.b", lv));
+      GemmOpt p; p.bias = (const float*)opp(e, fmt("mutan_%s.b", lv)); if (e->mutan_epilogue) p.act = ACT_TANH;
       CK(gemm_nt(st, dt, {{L.X0, Cp, opp(e, k), ldk, Cp}, {e->spatial, 64, opp(e, k, 0, Cp), ldk, 64}}, L.P, 5 * Cp, R, 5 * Cp, p));
-      CK(cmpc_mutan_fwd(dt, L.P, L.g, L.X1, L.mut_rstd, B, N, Cp, C, st)); }
+      CK(cmpc_mutan_fwd(dt, L.P, L.g, L.X1, L.mut_rstd, B, N, Cp, C, e->mutan_epilogue ? 1 : 0, st)); }
     // -- build_spa_graph + graph_conv (:359-410); adjacency never formed, trans2 folded into the word side
     { const float scale = 1.0f / sqrtf((float)C);
       const std::string t2n = fmt("t2_%s.n", lv);
@@ -1218,6 +1219,7 @@ extern "C" int cmpc_create(const cmpc_cfg* c, cmpc_handle* out) {
     ECK(hipEventCreateWithFlags(&e->ev_opt1, hipEventDisableTiming));
     for (auto& d : e->deferred) d.reserve(128);
     if (const char* v = getenv("CMPC_WGRAD_OVERLAP")) e->wgrad_overlap = atoi(v) != 0;       // read once, at create
+    if (const char* v = getenv("CMPC_MUTAN_EPILOGUE")) e->mutan_epilogue = atoi(v) != 0;
     e->fold_descs.resize(e->fold.table_cap);
     for (int a = 0; a < E::NBK; ++a) { e->fold_shadow[a].resize(e->fold.table_cap); e->fold_shadow_n[a] = -1; }
     e->fold.descs = e->fold_descs.data(); e->fold.shadow = e->fold_shadow[E::NBK - 1].data();
@@ -1410,6 +1412,33 @@ extern "C" int cmpc_kernel_timing_read(cmpc_handle e, double* ms, double* flops,
     if (launches) *launches = (int64_t)e->tflops.size();
     return CMPC_OK;
 }
+// CRC-32C (Castagnoli) of host bytes: the per-tensor and per-block checksum of TensorFlow checkpoints (tf_bundle.py); SSE4.2's crc32
+// instruction where the host has it, a byte table otherwise.  crc: the value returned for the preceding bytes (0 to start).
+namespace {
+__attribute__((target("sse4.2"))) uint32_t crc32c_hw(uint32_t c, const unsigned char* p, size_t n) {
+    uint64_t c64 = c;
+    while (n >= 8) { uint64_t v; memcpy(&v, p, 8); c64 = __builtin_ia32_crc32di(c64, v); p += 8; n -= 8; }
+    c = (uint32_t)c64;
+    while (n--) c = __builtin_ia32_crc32qi(c, *p++);
+    return c;
+}
+uint32_t crc32c_sw(uint32_t c, const unsigned char* p, size_t n) {
+    static uint32_t table[256];
+    static const bool init = [] {
+        for (uint32_t i = 0; i < 256; ++i) { uint32_t r = i; for (int k = 0; k < 8; ++k) r = (r >> 1) ^ (0x82F63B78u & (0u - (r & 1u))); table[i] = r; }
+        return true;
+    }();
+    (void)init;
+    while (n--) c = table[(c ^ *p++) & 0xff] ^ (c >> 8);
+    return c;
+}
+}  // namespace
+extern "C" uint32_t cmpc_crc32c(uint32_t crc, const void* data, size_t n) {
+    const unsigned char* p = (const unsigned char*)data;
+    const uint32_t c = ~crc;
+    return ~(__builtin_cpu_supports("sse4.2") ? crc32c_hw(c, p, n) : crc32c_sw(c, p, n));
+}
+
 extern "C" int cmpc_launch_count(cmpc_handle e, int64_t* n) { if (!e || !n) return CMPC_EINVAL; *n = e->launches_step; return CMPC_OK; }
 
 // ------------------------------------------------------------------------------------------

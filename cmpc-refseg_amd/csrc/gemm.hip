@@ -99,7 +99,7 @@ __device__ __forceinline__ void gemm_nt_epilogue_act(const cmpc_gemm_nt_args& p,
         for (int e = 0; e < 8; ++e) {
             float x = v[e] * alpha + bv[e];
             if (ACT == ACT_RELU) x = fmaxf(x, 0.0f);
-            else if (ACT == ACT_TANH) x = tanhf(x);
+            else if (ACT == ACT_TANH) x = cmpc_tanh(x);
             else if (ACT == ACT_SIGMOID) x = 1.0f / (1.0f + expf(-x));
             v[e] = ok[e] ? x : 0.0f;
         }
@@ -458,9 +458,17 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 __device__ __forceinline__ int v5_g(int row) { return (4 - ((row >> 2) & 3)) & 3; }
 __device__ __forceinline__ int v5_lds_off(int row, int c) { return row * 64 + ((c ^ v5_g(row)) << 4); }
 
+#ifdef CMPC_V5_TRACE      // diagnostic build only (scripts/v5_trace.py): 100 MHz timestamps of workgroup phases
+__device__ unsigned long long g_v5_trace[8 * 8192];
+#define V5_STAMP(i) do { if (threadIdx.x == 0 && blockIdx.x + gridDim.x * blockIdx.z < 8192) g_v5_trace[(blockIdx.x + gridDim.x * blockIdx.z) * 8 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define V5_STAMP(i) do { } while (0)
+#endif
+
 template <typename T>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void gemm_nt_v5_kernel(const cmpc_gemm_nt_args p) {
     constexpr int BM = 256, BN = 256, ROWB = 64;
+    V5_STAMP(0);
     constexpr int EPC = 16 / (int)sizeof(T);
     constexpr int BK = ROWB / (int)sizeof(T);              // 32 bf16
     constexpr int WAVES_N = 4;
@@ -475,7 +483,10 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const int gx = (p.N + BN - 1) / BN, nwg = gridDim.x;
     const int xq = nwg >> 3, xr = nwg & 7, xcd = blockIdx.x & 7, xi = blockIdx.x >> 3;
     const int tix = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + xi;
-    const int m0 = (tix / gx) * BM, n0 = (tix % gx) * BN;
+    // tile order: strips of 4 tile columns, row-major inside a strip.  The ~32 workgroups an XCD runs at a time then form an 8 x 4
+    // block of tiles (12 operand panels per k-step through its L2) instead of 1.6 rows of a wide product (22 panels).
+    const int gy = nwg / gx, strip = tix / (gy * 4), sw = min(4, gx - strip * 4), rem = tix - strip * gy * 4;
+    const int m0 = (rem / sw) * BM, n0 = (strip * 4 + rem % sw) * BN;
     const long bz = blockIdx.z;
 
     int ntile[3], ntot = 0;
@@ -553,8 +564,10 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     if (ntot > 0) issue_next(0);
     if (ntot > 1) issue_next(1);
     if (ntot > 2) issue_next(2);
+    V5_STAMP(1);
     if (ntot > 2) wait_vmcnt<2 * LPT>(); else if (ntot > 1) wait_vmcnt<LPT>(); else wait_vmcnt<0>();
     __builtin_amdgcn_s_barrier();
+    V5_STAMP(2);
     uint4 alo[4], ahi[4], bb[TN];
     if (ntot > 0) { read_b(0, bb); read_a(0, 0, alo); }
     int cur = 0;
@@ -580,6 +593,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         mma_half(0, alo, bb);
         mma_half(1, ahi, bb);
     }
+    V5_STAMP(3);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
 
@@ -602,6 +616,11 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // slab reads of this half are done before it is overwritten
         __builtin_amdgcn_wave_barrier();
     }
+    V5_STAMP(4);
+#ifdef CMPC_V5_TRACE
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    V5_STAMP(5);
+#endif
 }
 
 // gemm_nt v3 = v2 with producer / consumer wave specialisation.
@@ -1249,6 +1268,12 @@ static int launch_nt_small(const cmpc_gemm_nt_args* a, hipStream_t st) {
     else hipLaunchKernelGGL((gemm_nt_kernel<T, 128, 64>), grid, dim3(256), lds, st, *a);
     return cmpc_check_launch("gemm_nt");
 }
+
+#ifdef CMPC_V5_TRACE
+extern "C" int cmpc_debug_v5_trace(unsigned long long* out, int n_words) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_v5_trace), sizeof(unsigned long long) * n_words) == hipSuccess ? 0 : -1;
+}
+#endif
 
 extern "C" int cmpc_gemm_nt(const cmpc_gemm_nt_args* a, void* stream) {
     if (!a || a->nseg < 1 || a->nseg > 3 || a->M <= 0 || a->N <= 0 || a->batch <= 0) {

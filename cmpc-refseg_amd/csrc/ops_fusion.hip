@@ -14,7 +14,9 @@ __host__ inline int rows_grid(int N, int cap) { int g = (N + WPB - 1) / WPB; ret
 // FULL = (ld == MB * 512): every lane owns live columns in every block, so the `c0 < ld` guards vanish at compile time.
 // With the guards each (head, block) piece is its own exec-masked region and hipcc waits for its load before the next
 // region's load is issued: ten dependent round trips per row (mutan_bwd ran at 2.1 TB/s).
-template <typename T, bool FULL>
+// PRE: P already holds tanh(vis_trans_h) (the producing GEMM applied it as its epilogue) and is only read; otherwise P holds the
+// pre-activations and is overwritten by their tanh (what mutan_bwd expects to find).
+template <typename T, bool FULL, bool PRE>
 __global__ __launch_bounds__(256) void mutan_fwd_kernel(T* __restrict__ P, const float* __restrict__ g, T* __restrict__ X1,
                                                        float* __restrict__ rstd, int N, int ld, int C) {
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, b = blockIdx.y;
@@ -58,11 +60,11 @@ __global__ __launch_bounds__(256) void mutan_fwd_kernel(T* __restrict__ P, const
                 if (FULL || c0 < ld) {
 #pragma unroll
                     for (int e = 0; e < 8; ++e) {
-                        const float th = (c0 + e < C) ? tanhf(pv[h][k][e]) : 0.f;
+                        const float th = (c0 + e < C) ? (PRE ? pv[h][k][e] : cmpc_tanh(pv[h][k][e])) : 0.f;
                         pv[h][k][e] = th;
                         q[k][e] += th * gv[h][k][e];
                     }
-                    st8<T>(Pr + h * ld + c0, pv[h][k]);
+                    if (!PRE) st8<T>(Pr + h * ld + c0, pv[h][k]);
                 }
             }
         }
@@ -72,7 +74,7 @@ __global__ __launch_bounds__(256) void mutan_fwd_kernel(T* __restrict__ P, const
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 const int c = k * 512 + lane * 8 + e;
-                q[k][e] = (c < C) ? tanhf(q[k][e]) : 0.f;
+                q[k][e] = (c < C) ? cmpc_tanh(q[k][e]) : 0.f;
                 ss += q[k][e] * q[k][e];
             }
         ss = wave_sum(ss);
@@ -498,11 +500,17 @@ bool map_ok(const char* what, int ld, int C, int dt) {
 
 #define ST ((hipStream_t)stream)
 
-extern "C" int cmpc_mutan_fwd(int dt, void* P, const float* g, void* X1, float* rstd, int B, int N, int ld, int C, void* stream) {
+extern "C" int cmpc_mutan_fwd(int dt, void* P, const float* g, void* X1, float* rstd, int B, int N, int ld, int C, int pre_tanh, void* stream) {
     if (!map_ok("mutan_fwd", ld, C, dt)) return CMPC_EINVAL;
+    const dim3 grid(rows_grid(N, 400), B);
     CMPC_DISPATCH_DT(dt, {
-        if (ld == MB * 512) hipLaunchKernelGGL((mutan_fwd_kernel<T, true>), dim3(rows_grid(N, 400), B), dim3(256), 0, ST, (T*)P, g, (T*)X1, rstd, N, ld, C);
-        else hipLaunchKernelGGL((mutan_fwd_kernel<T, false>), dim3(rows_grid(N, 400), B), dim3(256), 0, ST, (T*)P, g, (T*)X1, rstd, N, ld, C);
+        if (ld == MB * 512) {
+            if (pre_tanh) hipLaunchKernelGGL((mutan_fwd_kernel<T, true, true>), grid, dim3(256), 0, ST, (T*)P, g, (T*)X1, rstd, N, ld, C);
+            else hipLaunchKernelGGL((mutan_fwd_kernel<T, true, false>), grid, dim3(256), 0, ST, (T*)P, g, (T*)X1, rstd, N, ld, C);
+        } else {
+            if (pre_tanh) hipLaunchKernelGGL((mutan_fwd_kernel<T, false, true>), grid, dim3(256), 0, ST, (T*)P, g, (T*)X1, rstd, N, ld, C);
+            else hipLaunchKernelGGL((mutan_fwd_kernel<T, false, false>), grid, dim3(256), 0, ST, (T*)P, g, (T*)X1, rstd, N, ld, C);
+        }
     });
     return cmpc_check_launch("mutan_fwd");
 }

@@ -117,8 +117,9 @@ int cmpc_sample_stats(int dt, const void* x, double* sums, int B, int N, int ld,
 
 /* ---- mutan_fusion (CMPC_model.py:295-328): P [R, 5*ld] holds the five vis_trans pre-activations
  *      (GEMM incl. spatial channels and bias); g [B, 5*ld] = tanh(lang_trans); on return P holds
- *      tanh(P_h), X1 = l2norm(tanh(sum_h tanh(P_h) * g_h)) ------------------------------------ */
-int cmpc_mutan_fwd(int dt, void* P, const float* g, void* X1, float* rstd, int B, int N, int ld, int C, void* stream);
+ *      tanh(P_h), X1 = l2norm(tanh(sum_h tanh(P_h) * g_h)).  pre_tanh != 0: P already holds the tanh
+ *      values (the GEMM ran with ACT_TANH) and is only read ----------------------------------- */
+int cmpc_mutan_fwd(int dt, void* P, const float* g, void* X1, float* rstd, int B, int N, int ld, int C, int pre_tanh, void* stream);
 /* in: Th (tanh values), dX1; out: Th overwritten by dP_h, dg[b][5*ld] += column sums */
 int cmpc_mutan_bwd(int dt, void* Th, const float* g, const void* X1, const float* rstd, const void* dX1,
                    float* dg, int B, int N, int ld, int C, void* stream);
@@ -376,6 +377,10 @@ int cmpc_kernel_timing(cmpc_handle h, int enable);
 int cmpc_kernel_timing_read(cmpc_handle h, double* ms, double* flops, double* bytes, int64_t* launches);
 /* number of kernel launches / memsets the last forward+backward+optimizer_step issued (host-side counter) */
 int cmpc_launch_count(cmpc_handle h, int64_t* n);
+
+/* Host utility (no GPU): CRC-32C of `n` bytes, continuing from `crc` (0 to start) -- the checksum of TensorFlow's tensor-bundle
+ * checkpoints (trainval_model.py:46-63 restores / saves them; cmpc-refseg_amd/tf_bundle.py reads and writes the format). */
+uint32_t cmpc_crc32c(uint32_t crc, const void* data, size_t n);
 
 #ifdef __cplusplus
 }

@@ -155,7 +155,8 @@ def test_gemm_nt_pipelines_agree_with_torch(dt, tdt):
     ops, dev = _ops(), torch.device("cuda:0")
     torch.manual_seed(5)
     for (M, N, Ks, nv) in ((3000, 640, (256,), 640), (1111, 1024, (64, 128, 64), 1000), (12800, 512, (512,), 500), (700, 264, (2048, 64), 264),
-                           (4096, 1024, (1024,), 1000), (2500, 2048, (512, 64), 2048), (12800, 512, (4096, 128), 512), (900, 384, (4160,), 380)):
+                           (4096, 1024, (1024,), 1000), (2500, 2048, (512, 64), 2048), (12800, 512, (4096, 128), 512), (900, 384, (4160,), 380),
+                           (2300, 1100, (128, 64), 1090)):
         K = sum(Ks)
         A = [torch.randn(M, k, device=dev).to(tdt) for k in Ks]
         Bt = (0.25 * torch.randn(N, K, device=dev)).to(tdt)
@@ -173,6 +174,17 @@ def test_gemm_nt_pipelines_agree_with_torch(dt, tdt):
         assert U.rel_err(C.float().cpu(), ref.cpu()) < (1e-2 if dt == 1 else 2e-3), (dt, M, N, Ks)
         if nv < N:      # pad columns: the product contributes exact zeros
             assert torch.equal(C[:, nv:], C0[:, nv:])
+        if N >= 1024:   # the 256 x 256 kernel's fp32-output path (c_f32), batched, with alpha
+            nb = 2; Mb = M // nb
+            Cf = torch.randn(nb * Mb, N, device=dev); Cf0 = Cf.clone()
+            segs, off = [], 0
+            for a, k in zip(A, Ks):
+                segs.append((a, k, Bt.data_ptr() + 2 * off, K, k, Mb * k, 0)); off += k
+            ops.gemm_nt(dt, segs, Cf, N, Mb, N, n_valid=nv, batch=nb, sC=Mb * N, c_f32=True, bias=bias, alpha=0.5, accumulate=True)
+            ref = 0.5 * (torch.cat(A, 1)[: nb * Mb].float() @ Bt.float().t()) + bias
+            ref[:, nv:] = 0
+            torch.cuda.synchronize()
+            assert U.rel_err(Cf.cpu(), (ref + Cf0).cpu()) < 1e-5, (dt, M, N, Ks, "c_f32")
 
 
 
@@ -232,10 +244,12 @@ def test_head_16bit_within_tolerance(case, dtype, tap_tol, loss_tol, grad_tol):
     assert abs(float(o["loss_all"].detach()) - case["scal"]["loss_all"]) <= loss_tol * abs(case["scal"]["loss_all"])
     g = m.store.grad_dict()
     assert all(torch.isfinite(v).all() for v in g.values())
-    for n in ("text_objseg/fusion_c5/DW", "text_objseg/rnn/conv_lstm_cell/kernel", "text_objseg/vis_trans_c4_head3/DW",
-              "text_objseg/trans_feat_c3_2_f1/DW", "text_objseg/score/DW", "text_objseg/rnn/lstm_cell/kernel",
-              "text_objseg/c3_lateral/DW", "text_objseg/gconv_update_spa_graph_c4/DW", "text_objseg/words_trans_c5/DW"):
-        assert U.rel_err(g[n], _ref_grad(case, n)) < grad_tol, n
+    errs = {n: round(float(U.rel_err(g[n], _ref_grad(case, n))), 5) for n in (
+        "text_objseg/fusion_c5/DW", "text_objseg/rnn/conv_lstm_cell/kernel", "text_objseg/vis_trans_c4_head3/DW",
+        "text_objseg/trans_feat_c3_2_f1/DW", "text_objseg/score/DW", "text_objseg/rnn/lstm_cell/kernel",
+        "text_objseg/c3_lateral/DW", "text_objseg/gconv_update_spa_graph_c4/DW", "text_objseg/words_trans_c5/DW")}
+    print(dtype, "gradient errors:", errs)
+    assert max(errs.values()) < grad_tol, errs
 
 
 def test_train_steps_match_tf_adam(case):
@@ -314,8 +328,10 @@ def test_two_runs_are_bit_identical(case, dtype, full):
         assert torch.equal(a[i], b[i]), i
 
 
-def test_checkpoint_save_restore_resume(case, tmp_path):
-    """tf.train.Saver round trip in the reference's variable name space (trainval_model.py:46-63,136-142): train 2 steps, save, restore
+@pytest.mark.parametrize("fmt", ["npz", "tf"])
+def test_checkpoint_save_restore_resume(case, tmp_path, fmt):
+    """tf.train.Saver round trip in the reference's variable name space (trainval_model.py:46-63,136-142), as one .npz file and as
+    TensorFlow's own .index / .data pair (tf_bundle.py): train 2 steps, save, restore
     into a fresh model built from DIFFERENT weights, continue both for one step -> bit-identical parameters, Adam state and step
     counter; the backbone-only restore (trainval_model.py:50-54) changes the backbone taps and nothing else."""
     import importlib
@@ -324,8 +340,8 @@ def test_checkpoint_save_restore_resume(case, tmp_path):
     a = _model(case, "f32")
     for _ in range(2):
         a.train_step(case["words"], case["im"], case["tgt"], case["sl"])
-    path = CK.Saver().save(a, str(tmp_path / "snap"))
-    assert path.endswith("snap-2.npz")
+    path = CK.Saver(fmt=fmt).save(a, str(tmp_path / "snap"))
+    assert path.endswith("snap-2.npz" if fmt == "npz" else "snap-2") and CK.latest_checkpoint(str(tmp_path / "snap")) == path
     P = U.pkg()
     hp2, bp2 = O.init_head_params(cfg, seed=999), O.init_backbone_params(cfg)
     bp2 = {k: v * 0.5 if k.endswith("/weights") else v for k, v in bp2.items()}
