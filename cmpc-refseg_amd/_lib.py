@@ -133,6 +133,7 @@ SIGNATURES = {
     "cmpc_l2norm_rows_fwd": [_I, _P, _P, _P, _P, _I, _I, _I, _P],
     "cmpc_l2norm_rows_bwd": [_I, _P, _P, _P, _P, _I, _I, _I, _I, _P],
     "cmpc_sample_stats": [_I, _P, _P, _I, _I, _I, _I, _P],
+    "cmpc_lowrank_nt": [_I, _P, _I, _L, _P, _I, _L, _P, _I, _L, _I, _I, _I, _I, _I, _F, _I, _P],
     "cmpc_mutan_fwd": [_I, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     "cmpc_mutan_bwd": [_I, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
     "cmpc_graph_softmax_fwd": [_I, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
@@ -219,8 +220,9 @@ def load():
     lib.cmpc_last_error.argtypes = []
     lib.cmpc_abi_version.restype = C.c_int
     lib.cmpc_abi_version.argtypes = []
-    lib.cmpc_crc32c.restype = C.c_uint32
-    lib.cmpc_crc32c.argtypes = [C.c_uint32, C.c_void_p, C.c_size_t]
+    if hasattr(lib, "cmpc_crc32c"):      # host utility (tf_bundle.py falls back to Python without it; older A/B builds lack it)
+        lib.cmpc_crc32c.restype = C.c_uint32
+        lib.cmpc_crc32c.argtypes = [C.c_uint32, C.c_void_p, C.c_size_t]
     for name, argtypes in SIGNATURES.items():
         fn = getattr(lib, name)          # AttributeError if a declared symbol is not exported
         fn.restype = C.c_int

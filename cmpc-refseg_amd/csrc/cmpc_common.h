@@ -186,13 +186,39 @@ __device__ __forceinline__ float act_grad_from_out(float y, int act) {
     }
 }
 
-// whole-sample LayerNorm statistics from double sums (tf.contrib.layers.layer_norm, eps 1e-12)
-__device__ __forceinline__ void ln_stats(const double* sums, double count, float& mean, float& rstd) {
-    const double m = sums[0] / count;
-    double var = sums[1] / count - m * m;
+// Whole-sample statistics (LayerNorm sums, their backward counterparts) live in "stat blocks": double [n_stats][STAT_PARTS][2], one
+// (sum, sum of squares) pair per producing workgroup, unused slots zero.  The producer's workgroups store their pairs (stat_store);
+// every consumer wave adds the 128 pairs itself in a fixed order (stat_load) -- no fold launch between the two kernels, and the
+// result does not depend on which workgroup finished first.
+constexpr int STAT_PARTS = 128;
+// called by ONE thread of workgroup `wgx` of `ngx` (<= STAT_PARTS) that feed statistic `sidx`; workgroup 0 also clears the unused slots
+__device__ __forceinline__ void stat_store(double* stats, int sidx, int wgx, int ngx, double s1, double s2) {
+    double* d = stats + ((long)sidx * STAT_PARTS + wgx) * 2;
+    d[0] = s1; d[1] = s2;
+    if (wgx == 0) for (int i = ngx; i < STAT_PARTS; ++i) { d[2 * i] = 0.0; d[2 * i + 1] = 0.0; }
+}
+// every lane of a full wave must take part
+__device__ __forceinline__ void stat_load(const double* stats, int sidx, double& s1, double& s2) {
+    const double* p = stats + (long)sidx * STAT_PARTS * 2;
+    const int lane = threadIdx.x & 63;
+    const double a1 = p[2 * lane], a2 = p[2 * lane + 1], b1 = p[2 * (lane + 64)], b2 = p[2 * (lane + 64) + 1];
+    s1 = wave_sum_d(a1 + b1); s2 = wave_sum_d(a2 + b2);
+}
+// whole-sample LayerNorm statistics (tf.contrib.layers.layer_norm, eps 1e-12) from statistic `sidx` of a stat block
+__device__ __forceinline__ void ln_stats(const double* stats, int sidx, double count, float& mean, float& rstd) {
+    double s1, s2;
+    stat_load(stats, sidx, s1, s2);
+    const double m = s1 / count;
+    double var = s2 / count - m * m;
     if (var < 0.0) var = 0.0;
     mean = (float)m;
     rstd = (float)(1.0 / sqrt(var + 1e-12));
+}
+// the two means of a backward statistic
+__device__ __forceinline__ void stat_means(const double* stats, int sidx, double count, float& m1, float& m2) {
+    double s1, s2;
+    stat_load(stats, sidx, s1, s2);
+    m1 = (float)(s1 / count); m2 = (float)(s2 / count);
 }
 
 #define CMPC_DISPATCH_DT(dt, ...)                                  \

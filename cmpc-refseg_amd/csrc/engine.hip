@@ -210,7 +210,8 @@ struct cmpc_engine_s {
     // buffer sets, so the lateral products' operand pointers alternate): a table that matches a cached one is not uploaded again
     void* tn_table[NBK][4] = {}; size_t tn_table_bytes = 0; std::vector<char> tn_shadow[NBK][4]; int tn_victim[NBK] = {};
     bool wgrad_overlap = true;          // issue the levels' / exchanges' dW beside the text encoder's backward chain
-    bool mutan_epilogue = false;        // the Mutan heads' tanh as the epilogue of their GEMM (measured slower in the 3-lane step: DESIGN.md)
+    bool lowrank = false;               // the graph's T-deep products through cmpc_lowrank_nt (16-bit storage, T <= 32, Cp = 8 * 2^j <= 2048)
+    bool mutan_epilogue = true;         // the Mutan heads' tanh as the epilogue of their GEMM (P is written once, as tanh; mutan_fwd only reads it)
     cmpc_fold_ctx fold;                 // deferred bias / LayerNorm / peephole gradient folds (one launch per backward pass)
     std::vector<cmpc_fold_desc> fold_descs, fold_shadow[NBK]; cmpc_fold_desc* fold_table[NBK] = {}; int fold_shadow_n[NBK];
     std::vector<Tap> taps;
@@ -484,8 +485,8 @@ void plan_workspace(E* e, Bump& zf, Bump& zb, Bump& g) {
         L.gw_w_t = g.take((size_t)B * N * Tp * es); L.gw_v_t = g.take((size_t)B * N * Tp * es);
         L.gsc = (float*)g.take((size_t)B * nch * 128 * F);
         L.Ztf = (float*)zf.take((size_t)B * Cp * Tp * F); L.Zt = g.take((size_t)B * Cp * Tp * es);
-        L.Y = g.take((size_t)R * Cp * es); L.sums1 = (double*)g.take((size_t)B * 2 * D);
-        L.G = g.take((size_t)R * Cp * es); L.U = g.take((size_t)R * Cp * es); L.sums2 = (double*)g.take((size_t)B * 2 * D);
+        L.Y = g.take((size_t)R * Cp * es); L.sums1 = (double*)g.take((size_t)B * STAT_PARTS * 2 * D);
+        L.G = g.take((size_t)R * Cp * es); L.U = g.take((size_t)R * Cp * es); L.sums2 = (double*)g.take((size_t)B * STAT_PARTS * 2 * D);
         L.X2 = g.take((size_t)R * Cp * es); L.rrow = (float*)g.take((size_t)R * F);
         L.sb = (float*)g.take((size_t)B * Mp * F); L.F = g.take((size_t)R * Mp * es);
         L.score = (float*)g.take((size_t)B * e->h * e->w * F); L.up = (float*)g.take((size_t)B * H * W * F);
@@ -494,7 +495,7 @@ void plan_workspace(E* e, Bump& zf, Bump& zb, Bump& g) {
         L.dfus = g.take((size_t)R * Mp * es); L.dscore = (float*)g.take((size_t)B * e->h * e->w * F);
         L.dpre = g.take((size_t)R * Mp * es); L.dsb = (float*)zb.take((size_t)B * Mp * F);
         L.dX1 = g.take((size_t)R * Cp * es); L.dX2 = g.take((size_t)R * Cp * es); L.dvl = (float*)g.take((size_t)B * Cp * F);
-        L.bs = (double*)g.take((size_t)B * 2 * D);
+        L.bs = (double*)g.take((size_t)B * STAT_PARTS * 2 * D);
         L.dU = g.take((size_t)R * Cp * es); L.dG = g.take((size_t)R * Cp * es); L.dY = g.take((size_t)R * Cp * es);
         L.Zf = (float*)zb.take((size_t)B * Tp * Cp * F); L.Z = g.take((size_t)B * Tp * Cp * es);
         L.dgw_w = (float*)g.take((size_t)B * N * Tp * F);
@@ -537,12 +538,12 @@ void plan_workspace(E* e, Bump& zf, Bump& zb, Bump& g) {
     // ---- ConvLSTM + final score
     for (int s = 0; s < 3; ++s) {
         ClstmStep& S = e->cl[s];
-        S.Yg = g.take((size_t)R * 4 * Mp * es); S.sums = (double*)g.take((size_t)5 * B * 2 * D);
+        S.Yg = g.take((size_t)R * 4 * Mp * es); S.sums = (double*)g.take((size_t)5 * B * STAT_PARTS * 2 * D);
         S.c_pre = g.take((size_t)R * Mp * es); S.c_new = g.take((size_t)R * Mp * es); S.h_new = g.take((size_t)R * Mp * es);
         S.dYg = g.take((size_t)R * 4 * Mp * es); S.dc_prev = g.take((size_t)R * Mp * es);
         S.dx = g.take((size_t)R * Mp * es); S.dh = g.take((size_t)R * Mp * es);
     }
-    e->cl_scr = g.take((size_t)R * Mp * es); e->cl_bs = (double*)g.take((size_t)5 * B * 2 * D);
+    e->cl_scr = g.take((size_t)R * Mp * es); e->cl_bs = (double*)g.take((size_t)5 * B * STAT_PARTS * 2 * D);
     e->score = (float*)g.take((size_t)B * e->h * e->w * F); e->up = (float*)g.take((size_t)B * H * W * F);
     e->sigm = (float*)g.take((size_t)B * H * W * F);
     e->loss = (float*)zf.take((size_t)B * F); e->iu = (int*)zf.take((size_t)2 * B * 4);
@@ -817,8 +818,9 @@ int level_fwd(E* e, hipStream_t st, int li, const float* target) {
       TnOpt z; z.nb2 = B; z.a_bs = (int64_t)N * Cp; z.d_bs = (int64_t)N * Tp; z.o_bs = (int64_t)Cp * Tp;     // Z^T = X1^T . gw_v
       CK(gemm_tn(e, st, dt, L.X1, Cp, Cp, L.gw_v_t, Tp, Tp, L.Ztf, Tp, N, C, T, OFF0, z));
       CK(cmpc_cast(DT_F32, L.Ztf, dt, L.Zt, (int64_t)B * Cp * Tp, st));
-      GemmOpt y; y.n_valid = C; y.batch = B; y.sC = (int64_t)N * Cp;
-      CK(gemm_nt(st, dt, {{L.gw_w_t, Tp, L.Zt, Tp, Tp, (int64_t)N * Tp, (int64_t)Cp * Tp}}, L.Y, Cp, N, Cp, y));
+      if (e->lowrank) CK(cmpc_lowrank_nt(dt, L.gw_w_t, Tp, (int64_t)N * Tp, L.Zt, Tp, (int64_t)Cp * Tp, L.Y, Cp, (int64_t)N * Cp, N, Cp, C, T, B, 1.0f, 0, st));
+      else { GemmOpt y; y.n_valid = C; y.batch = B; y.sC = (int64_t)N * Cp;
+             CK(gemm_nt(st, dt, {{L.gw_w_t, Tp, L.Zt, Tp, Tp, (int64_t)N * Tp, (int64_t)Cp * Tp}}, L.Y, Cp, N, Cp, y)); }
       CK(cmpc_sample_stats(dt, L.Y, L.sums1, B, N, Cp, C, st));
       const std::string ln1 = fmt("gconv_feat_ln_spa_graph_%s", lv), ln2 = fmt("gconv_update_ln_spa_graph_%s", lv);
       CK(cmpc_gconv_pre_fwd(dt, L.Y, L.X1, L.sums1, pptr(e, ln1 + "/gamma"), pptr(e, ln1 + "/beta"), L.G, B, N, Cp, C, st));
@@ -886,11 +888,13 @@ int level_bwd(E* e, hipStream_t st, int li, const float* target) {
       CK(cmpc_cast(DT_F32, L.dZtf, dt, L.dZt, (int64_t)B * Cp * Tp, st));
       CK(gemm_nt(st, dt, {{L.X1, Cp, L.dZ, Cp, Cp, (int64_t)N * Cp, (int64_t)Tp * Cp}}, L.dgw_v, Tp, N, Tp, gw));
       GemmOpt ax; ax.n_valid = C; ax.batch = B; ax.sC = (int64_t)N * Cp; ax.accumulate = 1;
-      CK(gemm_nt(st, dt, {{L.gw_v_t, Tp, L.dZt, Tp, Tp, (int64_t)N * Tp, (int64_t)Cp * Tp}}, L.dX1, Cp, N, Cp, ax));
+      if (e->lowrank) CK(cmpc_lowrank_nt(dt, L.gw_v_t, Tp, (int64_t)N * Tp, L.dZt, Tp, (int64_t)Cp * Tp, L.dX1, Cp, (int64_t)N * Cp, N, Cp, C, T, B, 1.0f, 1, st));
+      else CK(gemm_nt(st, dt, {{L.gw_v_t, Tp, L.dZt, Tp, Tp, (int64_t)N * Tp, (int64_t)Cp * Tp}}, L.dX1, Cp, N, Cp, ax));
       CK(cmpc_graph_softmax_bwd(dt, L.dgw_w, L.dgw_v, L.gw_w, L.gw_v, L.A0, L.pr, e->mask, L.dA0, L.dA0_t, L.dpr, L.gsc2, B, N, T, Tp, st));
       // A0 = scale * (X1 . PT^T) + k0s
       GemmOpt a0 = ax; a0.alpha = scale;
-      CK(gemm_nt(st, dt, {{L.dA0_t, Tp, L.PTt, B * Tp, Tp, (int64_t)N * Tp, (int64_t)Tp}}, L.dX1, Cp, N, Cp, a0));
+      if (e->lowrank) CK(cmpc_lowrank_nt(dt, L.dA0_t, Tp, (int64_t)N * Tp, L.PTt, B * Tp, (int64_t)Tp, L.dX1, Cp, (int64_t)N * Cp, N, Cp, C, T, B, scale, 1, st));
+      else CK(gemm_nt(st, dt, {{L.dA0_t, Tp, L.PTt, B * Tp, Tp, (int64_t)N * Tp, (int64_t)Tp}}, L.dX1, Cp, N, Cp, a0));
       TnOpt pt = zt; pt.alpha = scale;
       CK(gemm_tn(e, st, dt, L.dA0_t, Tp, Tp, L.X1, Cp, Cp, L.dPT, Cp, N, T, C, OFF0, pt));
       CK(colsum(st, DT_F32, L.dA0, R, Tp, Tp, T, nullptr, nullptr, nullptr, ACT_NONE, L.dk0s, Tp, N));
@@ -1220,6 +1224,8 @@ extern "C" int cmpc_create(const cmpc_cfg* c, cmpc_handle* out) {
     for (auto& d : e->deferred) d.reserve(128);
     if (const char* v = getenv("CMPC_WGRAD_OVERLAP")) e->wgrad_overlap = atoi(v) != 0;       // read once, at create
     if (const char* v = getenv("CMPC_MUTAN_EPILOGUE")) e->mutan_epilogue = atoi(v) != 0;
+    e->lowrank = e->dt != DT_F32 && e->T <= 32 && e->Cp <= 2048 && ((e->Cp / 8) & (e->Cp / 8 - 1)) == 0;
+    if (const char* v = getenv("CMPC_LOWRANK")) e->lowrank = e->lowrank && atoi(v) != 0;
     e->fold_descs.resize(e->fold.table_cap);
     for (int a = 0; a < E::NBK; ++a) { e->fold_shadow[a].resize(e->fold.table_cap); e->fold_shadow_n[a] = -1; }
     e->fold.descs = e->fold_descs.data(); e->fold.shadow = e->fold_shadow[E::NBK - 1].data();

@@ -12,15 +12,15 @@ __host__ inline int rows_grid(int N, int cap) { int g = (N + WPB - 1) / WPB; ret
 
 struct Sum2 { double a, b; };
 
-__device__ __forceinline__ void flush_sums(double s1, double s2, double* dst, double (*red)[WPB], int slot) {
+// this workgroup's pair of statistic `sidx` into the stat block (cmpc_common.h: the consumers add the pairs)
+__device__ __forceinline__ void flush_sums(double s1, double s2, double* stats, int sidx, double (*red)[WPB], int slot) {
     s1 = wave_sum_d(s1); s2 = wave_sum_d(s2);
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     if (lane == 0) { red[2 * slot][w] = s1; red[2 * slot + 1][w] = s2; }
     __syncthreads();
-    if (threadIdx.x == 0) {        // dst = this workgroup's partial pair (folded by reduce_parts_f64)
-        dst[0] = red[2 * slot][0] + red[2 * slot][1] + red[2 * slot][2] + red[2 * slot][3];
-        dst[1] = red[2 * slot + 1][0] + red[2 * slot + 1][1] + red[2 * slot + 1][2] + red[2 * slot + 1][3];
-    }
+    if (threadIdx.x == 0)
+        stat_store(stats, sidx, blockIdx.x, gridDim.x, red[2 * slot][0] + red[2 * slot][1] + red[2 * slot][2] + red[2 * slot][3],
+                   red[2 * slot + 1][0] + red[2 * slot + 1][1] + red[2 * slot + 1][2] + red[2 * slot + 1][3]);
     __syncthreads();
 }
 
@@ -80,10 +80,9 @@ __global__ __launch_bounds__(256) void clstm_a_kernel(T* __restrict__ Yg, const 
         }
         sj1 += aj1; sj2 += aj2; si1 += ai1; si2 += ai2; sf1 += af1; sf2 += af2;
     }
-    const long wg = (long)b * gridDim.x + blockIdx.x, nwg = (long)B * gridDim.x;
-    flush_sums(sj1, sj2, sums + (0 * nwg + wg) * 2, red, 0);
-    flush_sums(si1, si2, sums + (1 * nwg + wg) * 2, red, 1);
-    flush_sums(sf1, sf2, sums + (2 * nwg + wg) * 2, red, 2);
+    flush_sums(sj1, sj2, sums, 0 * B + b, red, 0);
+    flush_sums(si1, si2, sums, 1 * B + b, red, 1);
+    flush_sums(sf1, sf2, sums, 2 * B + b, red, 2);
 }
 
 
@@ -108,14 +107,14 @@ struct LnG { float* dbeta[5]; float* dgamma[5]; };
 // ---- forward B ---------------------------------------------------------------------------------
 template <typename T, int NB>
 __global__ __launch_bounds__(256) void clstm_b_kernel(T* __restrict__ Yg, const T* __restrict__ c_prev, const float* __restrict__ W_co,
-                                                     LnP ln, const double* sums, double* dpart, T* __restrict__ c_pre, int B, int N, int ld, int M) {
+                                                     LnP ln, const double* sums, double* stats_out, T* __restrict__ c_pre, int B, int N, int ld, int M) {
     __shared__ double red[4][WPB];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, b = blockIdx.y;
     const double cnt = (double)N * M;
     float mj, rj, mi, ri, mf, rf;
-    ln_stats(sums + (0 * B + b) * 2, cnt, mj, rj);
-    ln_stats(sums + (1 * B + b) * 2, cnt, mi, ri);
-    ln_stats(sums + (2 * B + b) * 2, cnt, mf, rf);
+    ln_stats(sums, 0 * B + b, cnt, mj, rj);
+    ln_stats(sums, 1 * B + b, cnt, mi, ri);
+    ln_stats(sums, 2 * B + b, cnt, mf, rf);
     float gj[NB][8], bj[NB][8], gi[NB][8], bi[NB][8], gf[NB][8], bf_[NB][8];
     load_vec<NB>(ln.gamma[0], gj, ld); load_vec<NB>(ln.beta[0], bj, ld); load_vec<NB>(ln.gamma[1], gi, ld);
     load_vec<NB>(ln.beta[1], bi, ld); load_vec<NB>(ln.gamma[2], gf, ld); load_vec<NB>(ln.beta[2], bf_, ld);
@@ -157,9 +156,8 @@ __global__ __launch_bounds__(256) void clstm_b_kernel(T* __restrict__ Yg, const 
         }
         so1 += ao1; so2 += ao2; sc1 += ac1; sc2 += ac2;
     }
-    const long wg = (long)b * gridDim.x + blockIdx.x, nwg = (long)B * gridDim.x;
-    flush_sums(so1, so2, dpart + (0 * nwg + wg) * 2, red, 0);
-    flush_sums(sc1, sc2, dpart + (1 * nwg + wg) * 2, red, 1);
+    flush_sums(so1, so2, stats_out, 3 * B + b, red, 0);
+    flush_sums(sc1, sc2, stats_out, 4 * B + b, red, 1);
 }
 
 // ---- forward C ---------------------------------------------------------------------------------
@@ -169,8 +167,8 @@ __global__ __launch_bounds__(256) void clstm_c_kernel(const T* __restrict__ Yg, 
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, b = blockIdx.y;
     const double cnt = (double)N * M;
     float mo, ro, mc, rc;
-    ln_stats(sums + (3 * B + b) * 2, cnt, mo, ro);
-    ln_stats(sums + (4 * B + b) * 2, cnt, mc, rc);
+    ln_stats(sums, 3 * B + b, cnt, mo, ro);
+    ln_stats(sums, 4 * B + b, cnt, mc, rc);
     float go[NB][8], bo[NB][8], gc[NB][8], bc[NB][8];
     load_vec<NB>(ln.gamma[3], go, ld); load_vec<NB>(ln.beta[3], bo, ld); load_vec<NB>(ln.gamma[4], gc, ld); load_vec<NB>(ln.beta[4], bc, ld);
     for (int n = blockIdx.x * WPB + w; n < N; n += gridDim.x * WPB) {
@@ -199,14 +197,14 @@ __global__ __launch_bounds__(256) void clstm_c_kernel(const T* __restrict__ Yg, 
 template <typename T, int NB>
 __global__ __launch_bounds__(256) void clstm_bwd1_kernel(const T* __restrict__ dh, const T* __restrict__ dc_new, const T* __restrict__ Yg,
                                                         const T* __restrict__ c_pre, LnP ln, const double* sums, T* __restrict__ dYg,
-                                                        T* __restrict__ scr, float* part, double* dpart, int B, int N, int ld, int M) {
+                                                        T* __restrict__ scr, float* part, double* stats_out, int B, int N, int ld, int M) {
     extern __shared__ float lds[];
     __shared__ double red[4][WPB];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, b = blockIdx.y;
     const double cnt = (double)N * M;
     float mo, ro, mc, rc;
-    ln_stats(sums + (3 * B + b) * 2, cnt, mo, ro);
-    ln_stats(sums + (4 * B + b) * 2, cnt, mc, rc);
+    ln_stats(sums, 3 * B + b, cnt, mo, ro);
+    ln_stats(sums, 4 * B + b, cnt, mc, rc);
     float go[NB][8], bo[NB][8], gc[NB][8], bc[NB][8];
     load_vec<NB>(ln.gamma[3], go, ld); load_vec<NB>(ln.beta[3], bo, ld); load_vec<NB>(ln.gamma[4], gc, ld); load_vec<NB>(ln.beta[4], bc, ld);
     float ago[NB][8], abo[NB][8], agc[NB][8], abc[NB][8];
@@ -245,9 +243,9 @@ __global__ __launch_bounds__(256) void clstm_bwd1_kernel(const T* __restrict__ d
         }
         so1 += ao1; so2 += ao2; sc1 += ac1; sc2 += ac2;
     }
-    const long wg = (long)b * gridDim.x + blockIdx.x, nwg = (long)B * gridDim.x;
-    flush_sums(so1, so2, dpart + (0 * nwg + wg) * 2, red, 0);
-    flush_sums(sc1, sc2, dpart + (1 * nwg + wg) * 2, red, 1);
+    flush_sums(so1, so2, stats_out, 3 * B + b, red, 0);
+    flush_sums(sc1, sc2, stats_out, 4 * B + b, red, 1);
+    const long wg = (long)b * gridDim.x + blockIdx.x;
     float* pr = part + wg * 4 * ld;                 // [dgamma_o, dbeta_o, dgamma_c, dbeta_c]
     colflush(ago, pr, ld, M, lds); colflush(abo, pr + ld, ld, M, lds);
     colflush(agc, pr + 2 * ld, ld, M, lds); colflush(abc, pr + 3 * ld, ld, M, lds);
@@ -258,19 +256,20 @@ template <typename T, int NB>
 __global__ __launch_bounds__(256) void clstm_bwd2_kernel(const T* __restrict__ Yg, const T* __restrict__ c_prev, const T* __restrict__ c_pre,
                                                         const float* __restrict__ W_co, LnP ln, const double* sums, const double* bsums_in,
                                                         T* __restrict__ dYg, const T* __restrict__ scr, T* __restrict__ dc_prev,
-                                                        float* part, double* dpart, int B, int N, int ld, int M) {
+                                                        float* part, double* stats_out, int B, int N, int ld, int M) {
     extern __shared__ float lds[];
     __shared__ double red[6][WPB];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, b = blockIdx.y;
     const double cnt = (double)N * M;
     float mj, rj, mi, ri, mf, rf, mo, ro, mc, rc;
-    ln_stats(sums + (0 * B + b) * 2, cnt, mj, rj);
-    ln_stats(sums + (1 * B + b) * 2, cnt, mi, ri);
-    ln_stats(sums + (2 * B + b) * 2, cnt, mf, rf);
-    ln_stats(sums + (3 * B + b) * 2, cnt, mo, ro);
-    ln_stats(sums + (4 * B + b) * 2, cnt, mc, rc);
-    const float o_m1 = (float)(bsums_in[(3 * B + b) * 2] / cnt), o_m2 = (float)(bsums_in[(3 * B + b) * 2 + 1] / cnt);
-    const float c_m1 = (float)(bsums_in[(4 * B + b) * 2] / cnt), c_m2 = (float)(bsums_in[(4 * B + b) * 2 + 1] / cnt);
+    ln_stats(sums, 0 * B + b, cnt, mj, rj);
+    ln_stats(sums, 1 * B + b, cnt, mi, ri);
+    ln_stats(sums, 2 * B + b, cnt, mf, rf);
+    ln_stats(sums, 3 * B + b, cnt, mo, ro);
+    ln_stats(sums, 4 * B + b, cnt, mc, rc);
+    float o_m1, o_m2, c_m1, c_m2;
+    stat_means(bsums_in, 3 * B + b, cnt, o_m1, o_m2);
+    stat_means(bsums_in, 4 * B + b, cnt, c_m1, c_m2);
     float gq[3][NB][8], bq[3][NB][8];
 #pragma unroll
     for (int q = 0; q < 3; ++q) { load_vec<NB>(ln.gamma[q], gq[q], ld); load_vec<NB>(ln.beta[q], bq[q], ld); }
@@ -332,10 +331,10 @@ __global__ __launch_bounds__(256) void clstm_bwd2_kernel(const T* __restrict__ Y
 #pragma unroll
         for (int q = 0; q < 6; ++q) s[q] += a[q];
     }
-    const long wg = (long)b * gridDim.x + blockIdx.x, nwg = (long)B * gridDim.x;
-    flush_sums(s[0], s[1], dpart + (0 * nwg + wg) * 2, red, 0);
-    flush_sums(s[2], s[3], dpart + (1 * nwg + wg) * 2, red, 1);
-    flush_sums(s[4], s[5], dpart + (2 * nwg + wg) * 2, red, 2);
+    flush_sums(s[0], s[1], stats_out, 0 * B + b, red, 0);
+    flush_sums(s[2], s[3], stats_out, 1 * B + b, red, 1);
+    flush_sums(s[4], s[5], stats_out, 2 * B + b, red, 2);
+    const long wg = (long)b * gridDim.x + blockIdx.x;
     float* pr = part + wg * 6 * ld;                 // [dgamma_q, dbeta_q] for q = j, i, f
 #pragma unroll
     for (int q = 0; q < 3; ++q) { colflush(ag[q], pr + (2 * q) * ld, ld, M, lds); colflush(ab[q], pr + (2 * q + 1) * ld, ld, M, lds); }
@@ -352,8 +351,8 @@ __global__ __launch_bounds__(256) void clstm_bwd3_kernel(const T* __restrict__ Y
     float mean[3], rstd[3], m1[3], m2[3];
 #pragma unroll
     for (int q = 0; q < 3; ++q) {
-        ln_stats(sums + (q * B + b) * 2, cnt, mean[q], rstd[q]);
-        m1[q] = (float)(bsums[(q * B + b) * 2] / cnt); m2[q] = (float)(bsums[(q * B + b) * 2 + 1] / cnt);
+        ln_stats(sums, q * B + b, cnt, mean[q], rstd[q]);
+        stat_means(bsums, q * B + b, cnt, m1[q], m2[q]);
     }
     for (int n = blockIdx.x * WPB + w; n < N; n += gridDim.x * WPB) {
         const long r = (long)b * N + n;
@@ -449,13 +448,9 @@ static int clstm_ws(long nwg, int ncol, int npair, int ld, float** part, double*
 extern "C" int cmpc_convlstm_a(int dt, void* Yg, const void* c_prev, const float* W_ci, const float* W_cf, double* sums,
                                int B, int N, int ld, int M, void* stream) {
     if (!ok("convlstm_a", dt, ld, M)) return CMPC_EINVAL;
-    const int gx = rows_grid(N, 100);
-    float* part; double* dpart;
-    if (clstm_ws((long)B * gx, 0, 3, ld, &part, &dpart, ST)) return CMPC_EHIP;
+    const int gx = rows_grid(N, 100);                       // <= STAT_PARTS workgroups per sample
     CLSTM_NB(ld, CMPC_DISPATCH_DT(dt, hipLaunchKernelGGL((clstm_a_kernel<T, NBX>), dim3(gx, B), dim3(256), 0, ST,
-                                             (T*)Yg, (const T*)c_prev, W_ci, W_cf, dpart, B, N, ld, M)));
-    for (int q = 0; q < 3; ++q)
-        if (cmpc_reduce_parts_f64(dpart + (long)q * B * gx * 2, B, gx, 2, sums + (long)q * B * 2, ST)) return CMPC_EHIP;
+                                             (T*)Yg, (const T*)c_prev, W_ci, W_cf, sums, B, N, ld, M)));
     return cmpc_check_launch("convlstm_a");
 }
 
@@ -463,12 +458,8 @@ extern "C" int cmpc_convlstm_b(int dt, void* Yg, const void* c_prev, const float
                                double* sums, void* c_pre, int B, int N, int ld, int M, void* stream) {
     if (!ok("convlstm_b", dt, ld, M)) return CMPC_EINVAL;
     const int gx = rows_grid(N, 100);
-    float* part; double* dpart;
-    if (clstm_ws((long)B * gx, 0, 2, ld, &part, &dpart, ST)) return CMPC_EHIP;
     CLSTM_NB(ld, CMPC_DISPATCH_DT(dt, hipLaunchKernelGGL((clstm_b_kernel<T, NBX>), dim3(gx, B), dim3(256), 0, ST,
-                                             (T*)Yg, (const T*)c_prev, W_co, to_lnp(ln), sums, dpart, (T*)c_pre, B, N, ld, M)));
-    for (int q = 0; q < 2; ++q)
-        if (cmpc_reduce_parts_f64(dpart + (long)q * B * gx * 2, B, gx, 2, sums + (long)(3 + q) * B * 2, ST)) return CMPC_EHIP;
+                                             (T*)Yg, (const T*)c_prev, W_co, to_lnp(ln), sums, sums, (T*)c_pre, B, N, ld, M)));
     return cmpc_check_launch("convlstm_b");
 }
 
@@ -490,23 +481,21 @@ extern "C" int cmpc_convlstm_bwd(int dt, const void* dh, const void* dc_new, con
     const int gx = rows_grid(N, 64);
     const long nwg = (long)B * gx;
     float* part; double* dpart;
-    if (clstm_ws(nwg, 6, 3, ld, &part, &dpart, ST)) return CMPC_EHIP;
+    if (clstm_ws(nwg, 6, 0, ld, &part, &dpart, ST)) return CMPC_EHIP;
     // pass 1: LN(o), LN(c) dxhat + their statistics / parameter gradients
     CLSTM_NB(ld, CMPC_DISPATCH_DT(dt, hipLaunchKernelGGL((clstm_bwd1_kernel<T, NBX>), dim3(gx, B), dim3(256), lds, ST,
-                           (const T*)dh, (const T*)dc_new, (const T*)Yg, (const T*)c_pre, to_lnp(ln), sums, (T*)dYg, (T*)scr, part, dpart, B, N, ld, M)));
+                           (const T*)dh, (const T*)dc_new, (const T*)Yg, (const T*)c_pre, to_lnp(ln), sums, (T*)dYg, (T*)scr, part, bsums, B, N, ld, M)));
     for (int q = 0; q < 2; ++q) {
-        if (cmpc_reduce_parts_f64(dpart + (long)q * nwg * 2, B, gx, 2, bsums + (long)(3 + q) * B * 2, ST)) return CMPC_EHIP;
         if (cmpc_reduce_parts_f32(part + (2 * q) * ld, 4 * ld, 1, (int)nwg, 1, ld, M, dln->dgamma[3 + q], 0, 0, 1, ST)) return CMPC_EHIP;
         if (cmpc_reduce_parts_f32(part + (2 * q + 1) * ld, 4 * ld, 1, (int)nwg, 1, ld, M, dln->dbeta[3 + q], 0, 0, 1, ST)) return CMPC_EHIP;
     }
     // pass 2: finish o, c; cell update; LN(j,i,f) dxhat + statistics.  Fresh partial rows: pass 1's may still be waiting for
     // a deferred fold (cmpc_fold_begin); without a collector this returns the same per-stream block, as before.
-    if (clstm_ws(nwg, 6, 3, ld, &part, &dpart, ST)) return CMPC_EHIP;
+    if (clstm_ws(nwg, 6, 0, ld, &part, &dpart, ST)) return CMPC_EHIP;
     CLSTM_NB(ld, CMPC_DISPATCH_DT(dt, hipLaunchKernelGGL((clstm_bwd2_kernel<T, NBX>), dim3(gx, B), dim3(256), lds, ST,
                            (const T*)Yg, (const T*)c_prev, (const T*)c_pre, W_co, to_lnp(ln), sums, bsums, (T*)dYg, (const T*)scr, (T*)dc_prev,
-                           part, dpart, B, N, ld, M)));
+                           part, bsums, B, N, ld, M)));
     for (int q = 0; q < 3; ++q) {
-        if (cmpc_reduce_parts_f64(dpart + (long)q * nwg * 2, B, gx, 2, bsums + (long)q * B * 2, ST)) return CMPC_EHIP;
         if (cmpc_reduce_parts_f32(part + (2 * q) * ld, 6 * ld, 1, (int)nwg, 1, ld, M, dln->dgamma[q], 0, 0, 1, ST)) return CMPC_EHIP;
         if (cmpc_reduce_parts_f32(part + (2 * q + 1) * ld, 6 * ld, 1, (int)nwg, 1, ld, M, dln->dbeta[q], 0, 0, 1, ST)) return CMPC_EHIP;
     }

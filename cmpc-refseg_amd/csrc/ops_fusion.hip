@@ -496,9 +496,97 @@ bool map_ok(const char* what, int ld, int C, int dt) {
     return true;
 }
 
+// ------------------------------------------------------------------------------------------
+// lowrank_nt: C[b][m, n] (+)= alpha * sum_{k < Kv} A[b][m, k] * Bt[b][n, k] for a SHORT reduction (Kv <= 32: the word axis of the
+// cross-modal graph, T = 20 -- Y = gw_w . Z, dX1 += gw_v . dZ, dX1 += scale * dA0 . PT of build_spa_graph / graph_conv,
+// CMPC_model.py:359-410).  20 MACs per output element: the product is a stream of C, not a GEMM -- an MFMA tile pipeline spends
+// its time in prologue / epilogue and holds a whole CU per workgroup (24 us per launch for 26 MB of output).  Here a thread owns 8
+// consecutive columns whose weights (Bt rows, k-pairs packed as they lie in memory) stay in registers, every wave reads a row of A
+// as wave-uniform 16-B loads and v_dot2_f32_{f16,bf16} accumulate in fp32; 64 VGPR-light waves per CU stream C at the store rate
+// and leave room for a neighbour stream's GEMM.
+// ------------------------------------------------------------------------------------------
+typedef _Float16 h2v __attribute__((ext_vector_type(2)));
+typedef __bf16 bf2v __attribute__((ext_vector_type(2)));
+template <typename T> __device__ __forceinline__ float dot2acc(uint32_t a, uint32_t b, float c);
+template <> __device__ __forceinline__ float dot2acc<f16_t>(uint32_t a, uint32_t b, float c) {
+    return __builtin_amdgcn_fdot2(__builtin_bit_cast(h2v, a), __builtin_bit_cast(h2v, b), c, false);
+}
+template <> __device__ __forceinline__ float dot2acc<bf16_t>(uint32_t a, uint32_t b, float c) {
+    return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf2v, a), __builtin_bit_cast(bf2v, b), c, false);
+}
+
+template <typename T, int KC>      // KC = 16-B chunks of k per row (8 elements each)
+__global__ __launch_bounds__(256) void lowrank_nt_kernel(const T* __restrict__ A, int lda, long sA, const T* __restrict__ Bt, int ldb, long sB,
+                                                         T* __restrict__ C, int ldc, long sC, int M, int N, int n_valid, int Kv,
+                                                         float alpha, int accumulate, int rows_per_block) {
+    const int tpr = N >> 3;                                   // threads per output row (a power of two <= 256: checked by the launcher)
+    const int tid = threadIdx.x, cg = tid & (tpr - 1), rsub = tid / tpr, rstep = 256 / tpr;
+    const int b = blockIdx.y, c0 = cg * 8;
+    A += b * sA; Bt += b * sB; C += b * sC;
+    uint32_t w[8][KC * 4];                                    // this thread's 8 weight rows, k-pairs
+#pragma unroll
+    for (int e = 0; e < 8; ++e)
+#pragma unroll
+        for (int q = 0; q < KC; ++q) {
+            uint4 v = *reinterpret_cast<const uint4*>(Bt + (long)(c0 + e) * ldb + q * 8);
+            uint32_t x[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {                      // elements q*8 + 2j, +1: zero what lies at or beyond Kv
+                const int k = q * 8 + 2 * j;
+                if (k >= Kv) x[j] = 0u; else if (k + 1 >= Kv) x[j] &= 0xffffu;
+                w[e][q * 4 + j] = (c0 + e < n_valid) ? x[j] : 0u;
+            }
+        }
+    const int r_end = min(M, (int)(blockIdx.x + 1) * rows_per_block);
+    for (int m = blockIdx.x * rows_per_block + rsub; m < r_end; m += rstep) {
+        const T* ar = A + (long)m * lda;
+        uint32_t a[KC * 4];
+#pragma unroll
+        for (int q = 0; q < KC; ++q) {
+            const uint4 v = *reinterpret_cast<const uint4*>(ar + q * 8);
+            a[q * 4] = v.x; a[q * 4 + 1] = v.y; a[q * 4 + 2] = v.z; a[q * 4 + 3] = v.w;
+        }
+        T* cr = C + (long)m * ldc + c0;
+        float o[8];
+        if (accumulate) ld8<T>(cr, o);
+        float acc[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            float s0 = 0.f, s1 = 0.f;                          // two chains per column
+#pragma unroll
+            for (int p = 0; p < KC * 4; p += 2) { s0 = dot2acc<T>(a[p], w[e][p], s0); s1 = dot2acc<T>(a[p + 1], w[e][p + 1], s1); }
+            acc[e] = (s0 + s1) * alpha;
+            if (accumulate) acc[e] += o[e];
+        }
+        st8<T>(cr, acc);
+    }
+}
+
 }  // namespace
 
 #define ST ((hipStream_t)stream)
+
+extern "C" int cmpc_lowrank_nt(int dt, const void* A, int lda, int64_t sA, const void* Bt, int ldb, int64_t sB, void* C, int ldc, int64_t sC,
+                               int M, int N, int n_valid, int Kv, int batch, float alpha, int accumulate, void* stream) {
+    if (!A || !Bt || !C || M <= 0 || N <= 0 || batch <= 0 || Kv <= 0) { cmpc_set_error("lowrank_nt: bad args"); return CMPC_EINVAL; }
+    if (dt != DT_BF16 && dt != DT_F16) { cmpc_set_error("lowrank_nt: 16-bit storage only"); return CMPC_EINVAL; }
+    const int tpr = N / 8, kc = (Kv + 7) / 8;
+    if (N % 8 || tpr > 256 || (tpr & (tpr - 1)) || Kv > 32 || lda < kc * 8 || ldb < kc * 8 || lda % 8 || ldb % 8 || ldc % 8 || sA % 8 || sB % 8 || sC % 8 ||
+        ((uintptr_t)A | (uintptr_t)Bt | (uintptr_t)C) % 16) {
+        cmpc_set_error("lowrank_nt: need N = 8 * 2^j <= 2048, Kv <= 32 and 16-B aligned rows (N=%d Kv=%d lda=%d ldb=%d ldc=%d)", N, Kv, lda, ldb, ldc);
+        return CMPC_EINVAL;
+    }
+    // one workgroup per CU and batch slice: the weights are register-resident per workgroup, so few, long row ranges
+    int per = (M * batch + 255) / 256; per = per < 16 ? 16 : per;
+    const int rstep = 256 / tpr; per = (per + rstep - 1) / rstep * rstep;
+    const dim3 grid((M + per - 1) / per, batch);
+#define LR_LAUNCH(TT, KC) hipLaunchKernelGGL((lowrank_nt_kernel<TT, KC>), grid, dim3(256), 0, ST, (const TT*)A, lda, (long)sA, (const TT*)Bt, ldb, (long)sB, \
+                                             (TT*)C, ldc, (long)sC, M, N, n_valid, Kv, alpha, accumulate, per)
+    if (dt == DT_F16) { if (kc <= 2) LR_LAUNCH(f16_t, 2); else if (kc == 3) LR_LAUNCH(f16_t, 3); else LR_LAUNCH(f16_t, 4); }
+    else { if (kc <= 2) LR_LAUNCH(bf16_t, 2); else if (kc == 3) LR_LAUNCH(bf16_t, 3); else LR_LAUNCH(bf16_t, 4); }
+#undef LR_LAUNCH
+    return cmpc_check_launch("lowrank_nt");
+}
 
 extern "C" int cmpc_mutan_fwd(int dt, void* P, const float* g, void* X1, float* rstd, int B, int N, int ld, int C, int pre_tanh, void* stream) {
     if (!map_ok("mutan_fwd", ld, C, dt)) return CMPC_EINVAL;

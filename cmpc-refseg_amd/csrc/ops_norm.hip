@@ -490,11 +490,8 @@ __global__ __launch_bounds__(256) void sample_stats_kernel(const T* __restrict__
     s1 = wave_sum_d(s1); s2 = wave_sum_d(s2);
     if (lane == 0) { red[0][w] = s1; red[1][w] = s2; }
     __syncthreads();
-    if (threadIdx.x == 0) {
-        double* d = dpart + ((long)b * gridDim.x + blockIdx.x) * 2;
-        d[0] = red[0][0] + red[0][1] + red[0][2] + red[0][3];
-        d[1] = red[1][0] + red[1][1] + red[1][2] + red[1][3];
-    }
+    if (threadIdx.x == 0)
+        stat_store(dpart, b, blockIdx.x, gridDim.x, red[0][0] + red[0][1] + red[0][2] + red[0][3], red[1][0] + red[1][1] + red[1][2] + red[1][3]);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -506,7 +503,7 @@ __global__ __launch_bounds__(256) void gconv_pre_fwd_kernel(const T* __restrict_
                                                            T* __restrict__ G, int N, int ld, int C) {
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, b = blockIdx.y;
     float mean, rstd;
-    ln_stats(sums + 2 * b, (double)N * C, mean, rstd);
+    ln_stats(sums, b, (double)N * C, mean, rstd);
     // per-channel LayerNorm parameters of this lane's columns (the masters are padded past C inside the
     // flat buffer, values beyond C are never used)
     float gmv[MAXBLK][8], btv[MAXBLK][8];
@@ -543,7 +540,7 @@ __global__ __launch_bounds__(256) void gconv_pre_bwd1_kernel(const T* __restrict
     __shared__ double red[2][WPB];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, b = blockIdx.y;
     float mean, rstd;
-    ln_stats(sums + 2 * b, (double)N * C, mean, rstd);
+    ln_stats(sums, b, (double)N * C, mean, rstd);
     float ag[MAXBLK][8], ab[MAXBLK][8], gmv[MAXBLK][8];
 #pragma unroll
     for (int k = 0; k < MAXBLK; ++k) {
@@ -584,10 +581,8 @@ __global__ __launch_bounds__(256) void gconv_pre_bwd1_kernel(const T* __restrict
     if (lane == 0) { red[0][w] = s1; red[1][w] = s2; }
     __syncthreads();
     const long wg = (long)b * gridDim.x + blockIdx.x;
-    if (threadIdx.x == 0) {
-        dpart[wg * 2] = red[0][0] + red[0][1] + red[0][2] + red[0][3];
-        dpart[wg * 2 + 1] = red[1][0] + red[1][1] + red[1][2] + red[1][3];
-    }
+    if (threadIdx.x == 0)
+        stat_store(dpart, b, blockIdx.x, gridDim.x, red[0][0] + red[0][1] + red[0][2] + red[0][3], red[1][0] + red[1][1] + red[1][2] + red[1][3]);
     colsum_flush(ag, part + wg * 2 * ld, ld, C, lds);
     colsum_flush(ab, part + wg * 2 * ld + ld, ld, C, lds);
 }
@@ -599,8 +594,9 @@ __global__ __launch_bounds__(256) void ln_bwd2_kernel(T* __restrict__ dY, const 
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, b = blockIdx.y;
     float mean, rstd;
     const double cnt = (double)N * C;
-    ln_stats(sums + 2 * b, cnt, mean, rstd);
-    const float m1 = (float)(bsums[2 * b] / cnt), m2 = (float)(bsums[2 * b + 1] / cnt);
+    ln_stats(sums, b, cnt, mean, rstd);
+    float m1, m2;
+    stat_means(bsums, b, cnt, m1, m2);
     for (int n = blockIdx.x * WPB + w; n < N; n += gridDim.x * WPB) {
         const long base = ((long)b * N + n) * ld;
         for (int c0 = lane * 8; c0 < ld; c0 += 512) {
@@ -622,7 +618,7 @@ __global__ __launch_bounds__(256) void gconv_post_fwd_kernel(const T* __restrict
                                                             T* __restrict__ out, float* __restrict__ rstd_row, int N, int ld, int C) {
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, b = blockIdx.y;
     float mean, rstd;
-    ln_stats(sums + 2 * b, (double)N * C, mean, rstd);
+    ln_stats(sums, b, (double)N * C, mean, rstd);
     // per-channel LayerNorm parameters of this lane's columns (the masters are padded past C inside the
     // flat buffer, values beyond C are never used)
     float gmv[MAXBLK][8], btv[MAXBLK][8];
@@ -674,7 +670,7 @@ __global__ __launch_bounds__(256) void gconv_post_bwd1_kernel(const T* __restric
     __shared__ double red[2][WPB];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, b = blockIdx.y;
     float mean, rstd;
-    ln_stats(sums + 2 * b, (double)N * C, mean, rstd);
+    ln_stats(sums, b, (double)N * C, mean, rstd);
     float ag[MAXBLK][8], ab[MAXBLK][8], gmv[MAXBLK][8];
 #pragma unroll
     for (int k = 0; k < MAXBLK; ++k) {
@@ -728,10 +724,8 @@ __global__ __launch_bounds__(256) void gconv_post_bwd1_kernel(const T* __restric
     if (lane == 0) { red[0][w] = s1; red[1][w] = s2; }
     __syncthreads();
     const long wg = (long)b * gridDim.x + blockIdx.x;
-    if (threadIdx.x == 0) {
-        dpart[wg * 2] = red[0][0] + red[0][1] + red[0][2] + red[0][3];
-        dpart[wg * 2 + 1] = red[1][0] + red[1][1] + red[1][2] + red[1][3];
-    }
+    if (threadIdx.x == 0)
+        stat_store(dpart, b, blockIdx.x, gridDim.x, red[0][0] + red[0][1] + red[0][2] + red[0][3], red[1][0] + red[1][1] + red[1][2] + red[1][3]);
     colsum_flush(ag, part + wg * 2 * ld, ld, C, lds);
     colsum_flush(ab, part + wg * 2 * ld + ld, ld, C, lds);
 }
@@ -839,10 +833,7 @@ extern "C" int cmpc_l2norm_rows_bwd(int dt, const void* dy, const void* y, const
 extern "C" int cmpc_sample_stats(int dt, const void* x, double* sums, int B, int N, int ld, int C, void* stream) {
     if (ld <= 0 || C > ld || ld % 8) { cmpc_set_error("sample_stats: bad ld/C"); return CMPC_EINVAL; }
     const int gx = rows_grid(N) > 128 ? 128 : rows_grid(N);
-    double* dpart = (double*)cmpc_ws((size_t)B * gx * 2 * sizeof(double), ST);
-    if (!dpart) return CMPC_EHIP;
-    CMPC_DISPATCH_DT(dt, hipLaunchKernelGGL((sample_stats_kernel<T>), dim3(gx, B), dim3(256), 0, ST, (const T*)x, dpart, N, ld, C));
-    if (cmpc_reduce_parts_f64(dpart, B, gx, 2, sums, ST)) return CMPC_EHIP;
+    CMPC_DISPATCH_DT(dt, hipLaunchKernelGGL((sample_stats_kernel<T>), dim3(gx, B), dim3(256), 0, ST, (const T*)x, sums, N, ld, C));
     return cmpc_check_launch("sample_stats");
 }
 
@@ -854,13 +845,10 @@ extern "C" int cmpc_gconv_pre_fwd(int dt, const void* Y, const void* X, const do
     return cmpc_check_launch("gconv_pre_fwd");
 }
 
-// workspace layout of the LN-backward first passes: [B*gx][2][ld] fp32 column partials, then [B*gx][2] fp64
-static int ln_bwd_ws(int B, int gx, int ld, float** part, double** dpart, hipStream_t st) {
-    const size_t fbytes = ((size_t)B * gx * 2 * ld * sizeof(float) + 15) / 16 * 16;
-    char* ws = (char*)cmpc_ws(fbytes + (size_t)B * gx * 2 * sizeof(double), st);
-    if (!ws) return CMPC_EHIP;
-    *part = (float*)ws; *dpart = (double*)(ws + fbytes);
-    return CMPC_OK;
+// workspace of the LN-backward first passes: [B*gx][2][ld] fp32 column partials (the fp64 pairs go to the caller's stat block)
+static int ln_bwd_ws(int B, int gx, int ld, float** part, hipStream_t st) {
+    *part = (float*)cmpc_ws((size_t)B * gx * 2 * ld * sizeof(float), st);
+    return *part ? CMPC_OK : CMPC_EHIP;
 }
 
 extern "C" int cmpc_gconv_pre_bwd(int dt, const void* dG, const void* G, const void* Y, const double* sums, const float* gamma,
@@ -868,11 +856,10 @@ extern "C" int cmpc_gconv_pre_bwd(int dt, const void* dG, const void* G, const v
                                   int B, int N, int ld, int C, void* stream) {
     if (!map_ok("gconv_pre_bwd", ld, C, dt)) return CMPC_EINVAL;
     const int gx = rows_grid(N) > 64 ? 64 : rows_grid(N);
-    float* part; double* dpart;
-    if (ln_bwd_ws(B, gx, ld, &part, &dpart, ST)) return CMPC_EHIP;
+    float* part;
+    if (ln_bwd_ws(B, gx, ld, &part, ST)) return CMPC_EHIP;
     CMPC_DISPATCH_DT(dt, hipLaunchKernelGGL((gconv_pre_bwd1_kernel<T>), dim3(gx, B), dim3(256), WPB * ld * sizeof(float), ST,
-                           (const T*)dG, (const T*)G, (const T*)Y, sums, gamma, (T*)dX, accumulate_dX, (T*)dY, part, dpart, N, ld, C));
-    if (cmpc_reduce_parts_f64(dpart, B, gx, 2, bsums, ST)) return CMPC_EHIP;
+                           (const T*)dG, (const T*)G, (const T*)Y, sums, gamma, (T*)dX, accumulate_dX, (T*)dY, part, bsums, N, ld, C));
     if (cmpc_reduce_parts_f32(part, 2 * ld, 1, B * gx, 1, ld, C, dgamma, 0, 0, 1, ST)) return CMPC_EHIP;
     if (cmpc_reduce_parts_f32(part + ld, 2 * ld, 1, B * gx, 1, ld, C, dbeta, 0, 0, 1, ST)) return CMPC_EHIP;
     CMPC_DISPATCH_DT(dt, hipLaunchKernelGGL((ln_bwd2_kernel<T>), dim3(rows_grid(N), B), dim3(256), 0, ST, (T*)dY, (const T*)Y, sums, bsums, N, ld, C));
@@ -892,11 +879,10 @@ extern "C" int cmpc_gconv_post_bwd(int dt, const void* dout, const void* out, co
                                    int B, int N, int ld, int C, void* stream) {
     if (!map_ok("gconv_post_bwd", ld, C, dt)) return CMPC_EINVAL;
     const int gx = rows_grid(N) > 64 ? 64 : rows_grid(N);
-    float* part; double* dpart;
-    if (ln_bwd_ws(B, gx, ld, &part, &dpart, ST)) return CMPC_EHIP;
+    float* part;
+    if (ln_bwd_ws(B, gx, ld, &part, ST)) return CMPC_EHIP;
     CMPC_DISPATCH_DT(dt, hipLaunchKernelGGL((gconv_post_bwd1_kernel<T>), dim3(gx, B), dim3(256), WPB * ld * sizeof(float), ST,
-                           (const T*)dout, (const T*)out, rstd_row, (const T*)U, sums, gamma, (T*)dU, part, dpart, N, ld, C));
-    if (cmpc_reduce_parts_f64(dpart, B, gx, 2, bsums, ST)) return CMPC_EHIP;
+                           (const T*)dout, (const T*)out, rstd_row, (const T*)U, sums, gamma, (T*)dU, part, bsums, N, ld, C));
     if (cmpc_reduce_parts_f32(part, 2 * ld, 1, B * gx, 1, ld, C, dgamma, 0, 0, 1, ST)) return CMPC_EHIP;
     if (cmpc_reduce_parts_f32(part + ld, 2 * ld, 1, B * gx, 1, ld, C, dbeta, 0, 0, 1, ST)) return CMPC_EHIP;
     CMPC_DISPATCH_DT(dt, hipLaunchKernelGGL((ln_bwd2_kernel<T>), dim3(rows_grid(N), B), dim3(256), 0, ST, (T*)dU, (const T*)U, sums, bsums, N, ld, C));

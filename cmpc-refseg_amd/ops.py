@@ -75,6 +75,12 @@ def gemm_nt(dt, segs: Sequence[Tuple], C, ldc, M, N, n_valid=None, batch=1, sC=0
     _lib.call("cmpc_gemm_nt", ctypes.byref(a), _st())
 
 
+def lowrank_nt(dt, A, lda, sA, Bt, ldb, sB, C, ldc, sC, M, N, Kv, n_valid=None, batch=1, alpha=1.0, accumulate=False):
+    """C[b][m, n] (+)= alpha * sum_{k < Kv} A[b][m, k] Bt[b][n, k] (16-bit storage, Kv <= 32): cmpc_lowrank_nt."""
+    _lib.call("cmpc_lowrank_nt", dt, _p(A), lda, sA, _p(Bt), ldb, sB, _p(C), ldc, sC, M, N, N if n_valid is None else n_valid, Kv, batch,
+              float(alpha), int(accumulate), _st())
+
+
 def gemm_tn(dt, A, lda, Ka, D, ldd, Nd, out, ldo, R, Kv, Nv, offs=((0, 0, 0),), nb2=1, a_bs=0, d_bs=0, o_bs=0,
             alpha=1.0, rsplit=None, wg=None):
     """out[k, n] += alpha * sum_r A[r, k] D[r, n]; offs: (a_off, d_off, o_off) per inner batch (elements).

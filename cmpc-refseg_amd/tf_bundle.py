@@ -60,10 +60,10 @@ def crc32c(data, crc: int = 0) -> int:
         return crc
     try:
         from . import _lib
-        lib = _lib.load()
+        fn = _lib.load().cmpc_crc32c
     except Exception:
         return _crc32c_py(crc, a.tobytes())
-    return int(lib.cmpc_crc32c(crc, a.ctypes.data, a.size))
+    return int(fn(crc, a.ctypes.data, a.size))
 
 
 def mask_crc(c: int) -> int:

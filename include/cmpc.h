@@ -112,7 +112,11 @@ int cmpc_l2norm_rows_bwd(int dt, const void* dy, const void* y, const float* rst
                          int accumulate, void* stream);
 
 /* ---- whole-sample statistics for tf.contrib.layers.layer_norm (CMPC_model.py:364,370;
- *      util/cell.py:53-66): sums[b] = {sum x, sum x^2} over (n, c<C), float64 ---------------- */
+ *      util/cell.py:53-66): {sum x, sum x^2} over (n, c<C) of every sample, float64, as a STAT BLOCK:
+ *      double [n_stats][CMPC_STAT_PARTS][2], one pair per producing workgroup (unused slots zero); the kernels
+ *      that consume a statistic add its pairs themselves in a fixed order, so no fold launch sits between
+ *      producer and consumer.  Every `sums` / `bsums` argument below is such a block --------------------- */
+#define CMPC_STAT_PARTS 128
 int cmpc_sample_stats(int dt, const void* x, double* sums, int B, int N, int ld, int C, void* stream);
 
 /* ---- mutan_fusion (CMPC_model.py:295-328): P [R, 5*ld] holds the five vis_trans pre-activations
@@ -120,6 +124,11 @@ int cmpc_sample_stats(int dt, const void* x, double* sums, int B, int N, int ld,
  *      tanh(P_h), X1 = l2norm(tanh(sum_h tanh(P_h) * g_h)).  pre_tanh != 0: P already holds the tanh
  *      values (the GEMM ran with ACT_TANH) and is only read ----------------------------------- */
 int cmpc_mutan_fwd(int dt, void* P, const float* g, void* X1, float* rstd, int B, int N, int ld, int C, int pre_tanh, void* stream);
+/* ---- short-reduction product of the cross-modal graph (CMPC_model.py:359-410: Y = gw_w . Z, dX1 += gw_v . dZ,
+ *      dX1 += scale * dA0 . PT): C[b][m, n] (+)= alpha * sum_{k < Kv} A[b][m, k] * Bt[b][n, k], Kv <= 32 (the word axis),
+ *      16-bit storage, fp32 accumulation; columns n >= n_valid contribute zero.  A streaming kernel, not a GEMM -------- */
+int cmpc_lowrank_nt(int dt, const void* A, int lda, int64_t sA, const void* Bt, int ldb, int64_t sB, void* C, int ldc, int64_t sC,
+                    int M, int N, int n_valid, int Kv, int batch, float alpha, int accumulate, void* stream);
 /* in: Th (tanh values), dX1; out: Th overwritten by dP_h, dg[b][5*ld] += column sums */
 int cmpc_mutan_bwd(int dt, void* Th, const float* g, const void* X1, const float* rstd, const void* dX1,
                    float* dg, int B, int N, int ld, int C, void* stream);
@@ -138,7 +147,7 @@ int cmpc_graph_softmax_bwd(int dt, const float* dgw_w, const float* dgw_v, const
 /* G = relu(X + LN(Y; gamma, beta)) */
 int cmpc_gconv_pre_fwd(int dt, const void* Y, const void* X, const double* sums, const float* gamma, const float* beta,
                        void* G, int B, int N, int ld, int C, void* stream);
-/* dX (+)= dG*[G>0]; dY = LN-backward; dgamma/dbeta += ; bsums: scratch double[B][2] */
+/* dX (+)= dG*[G>0]; dY = LN-backward; dgamma/dbeta += ; bsums: scratch stat block of B statistics */
 int cmpc_gconv_pre_bwd(int dt, const void* dG, const void* G, const void* Y, const double* sums, const float* gamma,
                        void* dX, int accumulate_dX, void* dY, float* dgamma, float* dbeta, double* bsums,
                        int B, int N, int ld, int C, void* stream);
@@ -166,7 +175,7 @@ int cmpc_exchange_combine_bwd(int dt, const void* dout, const void* out, const f
 
 /* ---- ConvLSTMCell.call (util/cell.py:36-79), one time step; Yg [R, 4*ld] = [x|h].kernel with
  *      gate blocks j,i,f,o; peepholes W_c* are [N, M] fp32 (row stride M); LayerNorm vectors
- *      in the order j,i,f,o,c; sums / bsums are double[5][B][2] in the same order ------------ */
+ *      in the order j,i,f,o,c; sums / bsums are stat blocks of 5*B statistics, [j,i,f,o,c][B] -- */
 typedef struct { const float* beta[5]; const float* gamma[5]; } cmpc_convlstm_ln;
 typedef struct { float* dbeta[5]; float* dgamma[5]; } cmpc_convlstm_dln;
 /* A: i += W_ci*c_prev, f += W_cf*c_prev (skipped when c_prev NULL); sums[j,i,f] <- stats */
@@ -181,7 +190,7 @@ int cmpc_convlstm_c(int dt, const void* Yg, const void* c_pre, const cmpc_convls
                     void* c_new, void* h, int B, int N, int ld, int M, void* stream);
 /* backward of C,B,A in three passes.  dYg [R,4*ld] receives d(pre-LN gate inputs = GEMM output);
  * dc_prev the state gradient (untouched when c_prev NULL); LN / peephole gradients accumulate
- * (atomics); scr [R, ld] dt scratch; bsums double[5][B][2] scratch */
+ * (atomics); scr [R, ld] dt scratch; bsums: scratch stat block of 5*B statistics */
 int cmpc_convlstm_bwd(int dt, const void* dh, const void* dc_new, const void* Yg, const void* c_prev, const void* c_pre,
                       const float* W_ci, const float* W_cf, const float* W_co,
                       const cmpc_convlstm_ln* ln, const double* sums, void* dYg, void* dc_prev,
