@@ -133,7 +133,7 @@ SIGNATURES = {
     "cmpc_l2norm_rows_fwd": [_I, _P, _P, _P, _P, _I, _I, _I, _P],
     "cmpc_l2norm_rows_bwd": [_I, _P, _P, _P, _P, _I, _I, _I, _I, _P],
     "cmpc_sample_stats": [_I, _P, _P, _I, _I, _I, _I, _P],
-    "cmpc_lowrank_nt": [_I, _P, _I, _L, _P, _I, _L, _P, _I, _L, _I, _I, _I, _I, _I, _F, _I, _P],
+    "cmpc_lowrank_nn": [_I, _P, _I, _L, _P, _I, _L, _P, _I, _L, _I, _I, _I, _I, _I, _F, _I, _P],
     "cmpc_mutan_fwd": [_I, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     "cmpc_mutan_bwd": [_I, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
     "cmpc_graph_softmax_fwd": [_I, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P],

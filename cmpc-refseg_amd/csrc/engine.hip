@@ -210,7 +210,7 @@ struct cmpc_engine_s {
     // buffer sets, so the lateral products' operand pointers alternate): a table that matches a cached one is not uploaded again
     void* tn_table[NBK][4] = {}; size_t tn_table_bytes = 0; std::vector<char> tn_shadow[NBK][4]; int tn_victim[NBK] = {};
     bool wgrad_overlap = true;          // issue the levels' / exchanges' dW beside the text encoder's backward chain
-    bool lowrank = false;               // the graph's T-deep products through cmpc_lowrank_nt (16-bit storage, T <= 32, Cp = 8 * 2^j <= 2048)
+    bool lowrank = false;               // the graph's T-deep products through cmpc_lowrank_nn (16-bit storage, T <= 24, Cp = 4 * 2^j <= 1024)
     bool mutan_epilogue = true;         // the Mutan heads' tanh as the epilogue of their GEMM (P is written once, as tanh; mutan_fwd only reads it)
     cmpc_fold_ctx fold;                 // deferred bias / LayerNorm / peephole gradient folds (one launch per backward pass)
     std::vector<cmpc_fold_desc> fold_descs, fold_shadow[NBK]; cmpc_fold_desc* fold_table[NBK] = {}; int fold_shadow_n[NBK];
@@ -497,7 +497,7 @@ void plan_workspace(E* e, Bump& zf, Bump& zb, Bump& g) {
         L.dX1 = g.take((size_t)R * Cp * es); L.dX2 = g.take((size_t)R * Cp * es); L.dvl = (float*)g.take((size_t)B * Cp * F);
         L.bs = (double*)g.take((size_t)B * STAT_PARTS * 2 * D);
         L.dU = g.take((size_t)R * Cp * es); L.dG = g.take((size_t)R * Cp * es); L.dY = g.take((size_t)R * Cp * es);
-        L.Zf = (float*)zb.take((size_t)B * Tp * Cp * F); L.Z = g.take((size_t)B * Tp * Cp * es);
+        L.Zf = (float*)(e->lowrank ? zf : zb).take((size_t)B * Tp * Cp * F); L.Z = g.take((size_t)B * Tp * Cp * es);     // lowrank: Z = gw_v^T . X1 is a forward product
         L.dgw_w = (float*)g.take((size_t)B * N * Tp * F);
         L.dZf = (float*)zb.take((size_t)B * Tp * Cp * F); L.dZ = g.take((size_t)B * Tp * Cp * es);
         L.dZtf = (float*)zb.take((size_t)B * Cp * Tp * F); L.dZt = g.take((size_t)B * Cp * Tp * es);
@@ -808,19 +808,25 @@ int level_fwd(E* e, hipStream_t st, int li, const float* target) {
       GemmOpt b; b.n_valid = C;
       CK(gemm_nt(st, DT_F32, {{L.Wd, Cp, opp(e, t2n), Cp, Cp}}, L.PTf, Cp, B * Tp, Cp, b));
       CK(cmpc_cast(DT_F32, L.PTf, dt, L.PT, (int64_t)B * Tp * Cp, st));
-      CK(transpose_cast(st, L.PTf, dt, L.PTt, B * Tp, Cp));                 // PT^T [Cp][B*Tp] (operand of dX1 += dA0 . PT)
+      if (!e->lowrank) CK(transpose_cast(st, L.PTf, dt, L.PTt, B * Tp, Cp));   // PT^T [Cp][B*Tp] (GEMM operand of dX1 += dA0 . PT)
       CK(cmpc_rowdot1(DT_F32, L.Wd, pptr(e, fmt("spa_graph_trans2_%s/biases", lv)), 0, L.k0s, 1, B * Tp, Cp, C, scale, st));
       GemmOpt c; c.batch = B; c.sC = (int64_t)N * Tp; c.c_f32 = 1; c.alpha = scale; c.sbias = L.k0s; c.ld_sbias = Tp; c.rows_per_sample = N;
       CK(gemm_nt(st, dt, {{L.X1, Cp, L.PT, Cp, Cp, (int64_t)N * Cp, (int64_t)Tp * Cp}}, L.A0, Tp, N, Tp, c));
       hipLaunchKernelGGL(col_get_kernel, dim3((B * T + 255) / 256), dim3(256), 0, st, e->parse, 4, 2, L.pr, B * T);
       CK(cmpc_check_launch("col_get"));
       CK(cmpc_graph_softmax_fwd(dt, L.A0, L.pr, e->mask, L.gw_w, L.gw_v, L.gw_w_t, L.gw_v_t, L.gsc, B, N, T, Tp, st));
-      TnOpt z; z.nb2 = B; z.a_bs = (int64_t)N * Cp; z.d_bs = (int64_t)N * Tp; z.o_bs = (int64_t)Cp * Tp;     // Z^T = X1^T . gw_v
-      CK(gemm_tn(e, st, dt, L.X1, Cp, Cp, L.gw_v_t, Tp, Tp, L.Ztf, Tp, N, C, T, OFF0, z));
-      CK(cmpc_cast(DT_F32, L.Ztf, dt, L.Zt, (int64_t)B * Cp * Tp, st));
-      if (e->lowrank) CK(cmpc_lowrank_nt(dt, L.gw_w_t, Tp, (int64_t)N * Tp, L.Zt, Tp, (int64_t)Cp * Tp, L.Y, Cp, (int64_t)N * Cp, N, Cp, C, T, B, 1.0f, 0, st));
-      else { GemmOpt y; y.n_valid = C; y.batch = B; y.sC = (int64_t)N * Cp;
-             CK(gemm_nt(st, dt, {{L.gw_w_t, Tp, L.Zt, Tp, Tp, (int64_t)N * Tp, (int64_t)Cp * Tp}}, L.Y, Cp, N, Cp, y)); }
+      if (e->lowrank) {      // Z = gw_v^T . X1 [T, C] k-major (kept for the backward pass), Y = gw_w . Z as a stream of Y
+          TnOpt zt; zt.nb2 = B; zt.a_bs = (int64_t)N * Tp; zt.d_bs = (int64_t)N * Cp; zt.o_bs = (int64_t)Tp * Cp;
+          CK(gemm_tn(e, st, dt, L.gw_v_t, Tp, Tp, L.X1, Cp, Cp, L.Zf, Cp, N, T, C, OFF0, zt));
+          CK(cmpc_cast(DT_F32, L.Zf, dt, L.Z, (int64_t)B * Tp * Cp, st));
+          CK(cmpc_lowrank_nn(dt, L.gw_w_t, Tp, (int64_t)N * Tp, L.Z, Cp, (int64_t)Tp * Cp, L.Y, Cp, (int64_t)N * Cp, N, Cp, C, T, B, 1.0f, 0, st));
+      } else {
+          TnOpt z; z.nb2 = B; z.a_bs = (int64_t)N * Cp; z.d_bs = (int64_t)N * Tp; z.o_bs = (int64_t)Cp * Tp;     // Z^T = X1^T . gw_v
+          CK(gemm_tn(e, st, dt, L.X1, Cp, Cp, L.gw_v_t, Tp, Tp, L.Ztf, Tp, N, C, T, OFF0, z));
+          CK(cmpc_cast(DT_F32, L.Ztf, dt, L.Zt, (int64_t)B * Cp * Tp, st));
+          GemmOpt y; y.n_valid = C; y.batch = B; y.sC = (int64_t)N * Cp;
+          CK(gemm_nt(st, dt, {{L.gw_w_t, Tp, L.Zt, Tp, Tp, (int64_t)N * Tp, (int64_t)Cp * Tp}}, L.Y, Cp, N, Cp, y));
+      }
       CK(cmpc_sample_stats(dt, L.Y, L.sums1, B, N, Cp, C, st));
       const std::string ln1 = fmt("gconv_feat_ln_spa_graph_%s", lv), ln2 = fmt("gconv_update_ln_spa_graph_%s", lv);
       CK(cmpc_gconv_pre_fwd(dt, L.Y, L.X1, L.sums1, pptr(e, ln1 + "/gamma"), pptr(e, ln1 + "/beta"), L.G, B, N, Cp, C, st));
@@ -877,23 +883,27 @@ int level_bwd(E* e, hipStream_t st, int li, const float* target) {
                             L.bs, B, N, Cp, C, st));
       // Y = gw_w . Z,  Z = gw_v^T . X1
       TnOpt zt; zt.nb2 = B; zt.a_bs = (int64_t)N * Tp; zt.d_bs = (int64_t)N * Cp; zt.o_bs = (int64_t)Tp * Cp;
-      CK(gemm_tn(e, st, dt, L.gw_v_t, Tp, Tp, L.X1, Cp, Cp, L.Zf, Cp, N, T, C, OFF0, zt));
-      CK(cmpc_cast(DT_F32, L.Zf, dt, L.Z, (int64_t)B * Tp * Cp, st));
+      if (!e->lowrank) {     // (lowrank: Z is the forward pass's)
+          CK(gemm_tn(e, st, dt, L.gw_v_t, Tp, Tp, L.X1, Cp, Cp, L.Zf, Cp, N, T, C, OFF0, zt));
+          CK(cmpc_cast(DT_F32, L.Zf, dt, L.Z, (int64_t)B * Tp * Cp, st));
+      }
       GemmOpt gw; gw.batch = B; gw.sC = (int64_t)N * Tp; gw.c_f32 = 1;
       CK(gemm_nt(st, dt, {{L.dY, Cp, L.Z, Cp, Cp, (int64_t)N * Cp, (int64_t)Tp * Cp}}, L.dgw_w, Tp, N, Tp, gw));
       CK(gemm_tn(e, st, dt, L.gw_w_t, Tp, Tp, L.dY, Cp, Cp, L.dZf, Cp, N, T, C, OFF0, zt));
       CK(cmpc_cast(DT_F32, L.dZf, dt, L.dZ, (int64_t)B * Tp * Cp, st));
-      TnOpt z2; z2.nb2 = B; z2.a_bs = (int64_t)N * Cp; z2.d_bs = (int64_t)N * Tp; z2.o_bs = (int64_t)Cp * Tp;
-      CK(gemm_tn(e, st, dt, L.dY, Cp, Cp, L.gw_w_t, Tp, Tp, L.dZtf, Tp, N, C, T, OFF0, z2));
-      CK(cmpc_cast(DT_F32, L.dZtf, dt, L.dZt, (int64_t)B * Cp * Tp, st));
+      if (!e->lowrank) {     // dZ^T, the GEMM operand of dX1 += gw_v . dZ
+          TnOpt z2; z2.nb2 = B; z2.a_bs = (int64_t)N * Cp; z2.d_bs = (int64_t)N * Tp; z2.o_bs = (int64_t)Cp * Tp;
+          CK(gemm_tn(e, st, dt, L.dY, Cp, Cp, L.gw_w_t, Tp, Tp, L.dZtf, Tp, N, C, T, OFF0, z2));
+          CK(cmpc_cast(DT_F32, L.dZtf, dt, L.dZt, (int64_t)B * Cp * Tp, st));
+      }
       CK(gemm_nt(st, dt, {{L.X1, Cp, L.dZ, Cp, Cp, (int64_t)N * Cp, (int64_t)Tp * Cp}}, L.dgw_v, Tp, N, Tp, gw));
       GemmOpt ax; ax.n_valid = C; ax.batch = B; ax.sC = (int64_t)N * Cp; ax.accumulate = 1;
-      if (e->lowrank) CK(cmpc_lowrank_nt(dt, L.gw_v_t, Tp, (int64_t)N * Tp, L.dZt, Tp, (int64_t)Cp * Tp, L.dX1, Cp, (int64_t)N * Cp, N, Cp, C, T, B, 1.0f, 1, st));
+      if (e->lowrank) CK(cmpc_lowrank_nn(dt, L.gw_v_t, Tp, (int64_t)N * Tp, L.dZ, Cp, (int64_t)Tp * Cp, L.dX1, Cp, (int64_t)N * Cp, N, Cp, C, T, B, 1.0f, 1, st));
       else CK(gemm_nt(st, dt, {{L.gw_v_t, Tp, L.dZt, Tp, Tp, (int64_t)N * Tp, (int64_t)Cp * Tp}}, L.dX1, Cp, N, Cp, ax));
       CK(cmpc_graph_softmax_bwd(dt, L.dgw_w, L.dgw_v, L.gw_w, L.gw_v, L.A0, L.pr, e->mask, L.dA0, L.dA0_t, L.dpr, L.gsc2, B, N, T, Tp, st));
       // A0 = scale * (X1 . PT^T) + k0s
       GemmOpt a0 = ax; a0.alpha = scale;
-      if (e->lowrank) CK(cmpc_lowrank_nt(dt, L.dA0_t, Tp, (int64_t)N * Tp, L.PTt, B * Tp, (int64_t)Tp, L.dX1, Cp, (int64_t)N * Cp, N, Cp, C, T, B, scale, 1, st));
+      if (e->lowrank) CK(cmpc_lowrank_nn(dt, L.dA0_t, Tp, (int64_t)N * Tp, L.PT, Cp, (int64_t)Tp * Cp, L.dX1, Cp, (int64_t)N * Cp, N, Cp, C, T, B, scale, 1, st));
       else CK(gemm_nt(st, dt, {{L.dA0_t, Tp, L.PTt, B * Tp, Tp, (int64_t)N * Tp, (int64_t)Tp}}, L.dX1, Cp, N, Cp, a0));
       TnOpt pt = zt; pt.alpha = scale;
       CK(gemm_tn(e, st, dt, L.dA0_t, Tp, Tp, L.X1, Cp, Cp, L.dPT, Cp, N, T, C, OFF0, pt));
@@ -1174,6 +1184,9 @@ extern "C" int cmpc_create(const cmpc_cfg* c, cmpc_handle* out) {
     e->H = c->H; e->W = c->W; e->V = c->vocab_size;
     e->C = c->v_emb_dim; e->Cp = pad64(e->C); e->M = c->mlp_dim; e->Mp = pad64(e->M); e->G = c->glove_dim; e->Gp = pad64(e->G);
     e->P = c->parse_dim; e->Pp = pad64(e->P); e->Tp = 64; e->RNN = c->rnn_size; e->dt = c->dtype; e->esz = c->dtype == DT_F32 ? 4 : 2;
+    // the graph's T-deep products as streaming kernels (cmpc_lowrank_nn); decided before the workspace is planned (Z moves to the forward pass)
+    e->lowrank = e->dt != DT_F32 && e->T <= 24 && e->Cp <= 1024 && ((e->Cp / 4) & (e->Cp / 4 - 1)) == 0;
+    if (const char* v = getenv("CMPC_LOWRANK")) e->lowrank = e->lowrank && atoi(v) != 0;          // read once, at create
     build_manifest(e);
     plan_operands(e);
     if (plan_only) {
@@ -1224,8 +1237,6 @@ extern "C" int cmpc_create(const cmpc_cfg* c, cmpc_handle* out) {
     for (auto& d : e->deferred) d.reserve(128);
     if (const char* v = getenv("CMPC_WGRAD_OVERLAP")) e->wgrad_overlap = atoi(v) != 0;       // read once, at create
     if (const char* v = getenv("CMPC_MUTAN_EPILOGUE")) e->mutan_epilogue = atoi(v) != 0;
-    e->lowrank = e->dt != DT_F32 && e->T <= 32 && e->Cp <= 2048 && ((e->Cp / 8) & (e->Cp / 8 - 1)) == 0;
-    if (const char* v = getenv("CMPC_LOWRANK")) e->lowrank = e->lowrank && atoi(v) != 0;
     e->fold_descs.resize(e->fold.table_cap);
     for (int a = 0; a < E::NBK; ++a) { e->fold_shadow[a].resize(e->fold.table_cap); e->fold_shadow_n[a] = -1; }
     e->fold.descs = e->fold_descs.data(); e->fold.shadow = e->fold_shadow[E::NBK - 1].data();

@@ -497,11 +497,11 @@ bool map_ok(const char* what, int ld, int C, int dt) {
 }
 
 // ------------------------------------------------------------------------------------------
-// lowrank_nt: C[b][m, n] (+)= alpha * sum_{k < Kv} A[b][m, k] * Bt[b][n, k] for a SHORT reduction (Kv <= 32: the word axis of the
+// lowrank_nn: C[b][m, n] (+)= alpha * sum_{k < Kv} A[b][m, k] * Bk[b][k, n] for a SHORT reduction (Kv <= 24: the word axis of the
 // cross-modal graph, T = 20 -- Y = gw_w . Z, dX1 += gw_v . dZ, dX1 += scale * dA0 . PT of build_spa_graph / graph_conv,
 // CMPC_model.py:359-410).  20 MACs per output element: the product is a stream of C, not a GEMM -- an MFMA tile pipeline spends
 // its time in prologue / epilogue and holds a whole CU per workgroup (24 us per launch for 26 MB of output).  Here a thread owns 8
-// consecutive columns whose weights (Bt rows, k-pairs packed as they lie in memory) stay in registers, every wave reads a row of A
+// consecutive columns whose weights stay in registers as k-pairs (Bk is k-major, so the loads are whole lines; two rows are zipped into pairs once), every wave reads a row of A
 // as wave-uniform 16-B loads and v_dot2_f32_{f16,bf16} accumulate in fp32; 64 VGPR-light waves per CU stream C at the store rate
 // and leave room for a neighbour stream's GEMM.
 // ------------------------------------------------------------------------------------------
@@ -515,77 +515,120 @@ template <> __device__ __forceinline__ float dot2acc<bf16_t>(uint32_t a, uint32_
     return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf2v, a), __builtin_bit_cast(bf2v, b), c, false);
 }
 
-template <typename T, int KC>      // KC = 16-B chunks of k per row (8 elements each)
-__global__ __launch_bounds__(256) void lowrank_nt_kernel(const T* __restrict__ A, int lda, long sA, const T* __restrict__ Bt, int ldb, long sB,
-                                                         T* __restrict__ C, int ldc, long sC, int M, int N, int n_valid, int Kv,
-                                                         float alpha, int accumulate, int rows_per_block) {
-    const int tpr = N >> 3;                                   // threads per output row (a power of two <= 256: checked by the launcher)
-    const int tid = threadIdx.x, cg = tid & (tpr - 1), rsub = tid / tpr, rstep = 256 / tpr;
-    const int b = blockIdx.y, c0 = cg * 8;
-    A += b * sA; Bt += b * sB; C += b * sC;
-    uint32_t w[8][KC * 4];                                    // this thread's 8 weight rows, k-pairs
+template <typename T> __device__ __forceinline__ void ld4(const T* p, float (&v)[4]);
+template <> __device__ __forceinline__ void ld4<f16_t>(const f16_t* p, float (&v)[4]) {
+    typedef _Float16 h4v __attribute__((ext_vector_type(4)));
+    const h4v a = *reinterpret_cast<const h4v*>(p);
 #pragma unroll
-    for (int e = 0; e < 8; ++e)
+    for (int e = 0; e < 4; ++e) v[e] = (float)a[e];
+}
+template <> __device__ __forceinline__ void ld4<bf16_t>(const bf16_t* p, float (&v)[4]) {
+    const uint2 a = *reinterpret_cast<const uint2*>(p);
+    v[0] = __uint_as_float(a.x << 16); v[1] = __uint_as_float(a.x & 0xffff0000u); v[2] = __uint_as_float(a.y << 16); v[3] = __uint_as_float(a.y & 0xffff0000u);
+}
+template <typename T> __device__ __forceinline__ void st4(T* p, const float (&v)[4]);
+template <> __device__ __forceinline__ void st4<f16_t>(f16_t* p, const float (&v)[4]) {
+    typedef _Float16 h4v __attribute__((ext_vector_type(4)));
+    h4v a;
 #pragma unroll
-        for (int q = 0; q < KC; ++q) {
-            uint4 v = *reinterpret_cast<const uint4*>(Bt + (long)(c0 + e) * ldb + q * 8);
-            uint32_t x[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {                      // elements q*8 + 2j, +1: zero what lies at or beyond Kv
-                const int k = q * 8 + 2 * j;
-                if (k >= Kv) x[j] = 0u; else if (k + 1 >= Kv) x[j] &= 0xffffu;
-                w[e][q * 4 + j] = (c0 + e < n_valid) ? x[j] : 0u;
-            }
-        }
-    const int r_end = min(M, (int)(blockIdx.x + 1) * rows_per_block);
-    for (int m = blockIdx.x * rows_per_block + rsub; m < r_end; m += rstep) {
-        const T* ar = A + (long)m * lda;
-        uint32_t a[KC * 4];
-#pragma unroll
-        for (int q = 0; q < KC; ++q) {
-            const uint4 v = *reinterpret_cast<const uint4*>(ar + q * 8);
-            a[q * 4] = v.x; a[q * 4 + 1] = v.y; a[q * 4 + 2] = v.z; a[q * 4 + 3] = v.w;
-        }
-        T* cr = C + (long)m * ldc + c0;
-        float o[8];
-        if (accumulate) ld8<T>(cr, o);
-        float acc[8];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            float s0 = 0.f, s1 = 0.f;                          // two chains per column
-#pragma unroll
-            for (int p = 0; p < KC * 4; p += 2) { s0 = dot2acc<T>(a[p], w[e][p], s0); s1 = dot2acc<T>(a[p + 1], w[e][p + 1], s1); }
-            acc[e] = (s0 + s1) * alpha;
-            if (accumulate) acc[e] += o[e];
-        }
-        st8<T>(cr, acc);
-    }
+    for (int e = 0; e < 4; ++e) a[e] = (f16_t)v[e];
+    *reinterpret_cast<h4v*>(p) = a;
+}
+template <> __device__ __forceinline__ void st4<bf16_t>(bf16_t* p, const float (&v)[4]) {
+    uint2 a;
+    a.x = (uint32_t)f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16); a.y = (uint32_t)f2bf(v[2]) | ((uint32_t)f2bf(v[3]) << 16);
+    *reinterpret_cast<uint2*>(p) = a;
 }
 
+template <typename T, int KC>      // KC = 16-B chunks of k per row (8 elements each)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 8)))
+void lowrank_nn_kernel(const T* __restrict__ A, int lda, long sA, const T* __restrict__ Bk, int ldb, long sB,
+                       T* __restrict__ C, int ldc, long sC, int M, int N, int n_valid, int Kv,
+                       float alpha, int accumulate, int rows_per_block) {
+    const int tpr = N >> 2;                                   // threads per output row (a power of two <= 256: checked by the launcher)
+    const int tid = threadIdx.x, cg = tid & (tpr - 1), rsub = tid / tpr, rstep = 256 / tpr;
+    const int b = blockIdx.y, c0 = cg * 4;
+    A += b * sA; Bk += b * sB; C += b * sC;
+    uint32_t w[4][KC * 4];                                    // this thread's 4 columns, k-pairs (k, k+1) in the low / high half
+#pragma unroll
+    for (int p = 0; p < KC * 4; ++p) {
+        uint2 lo = make_uint2(0u, 0u), hi = make_uint2(0u, 0u);          // rows 2p and 2p+1 of Bk, columns c0..c0+3 (8 B, coalesced)
+        if (2 * p < Kv) lo = *reinterpret_cast<const uint2*>(Bk + (long)(2 * p) * ldb + c0);
+        if (2 * p + 1 < Kv) hi = *reinterpret_cast<const uint2*>(Bk + (long)(2 * p + 1) * ldb + c0);
+        w[0][p] = (lo.x & 0xffffu) | (hi.x << 16); w[1][p] = (lo.x >> 16) | (hi.x & 0xffff0000u);
+        w[2][p] = (lo.y & 0xffffu) | (hi.y << 16); w[3][p] = (lo.y >> 16) | (hi.y & 0xffff0000u);
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+        if (c0 + e >= n_valid) {
+#pragma unroll
+            for (int p = 0; p < KC * 4; ++p) w[e][p] = 0u;
+        }
+    const int r_end = min(M, (int)(blockIdx.x + 1) * rows_per_block);
+    // The row loop is a chain of dependent loads (A row, the old C when accumulating): RB rows per trip, every load of the trip
+    // issued before the first dot product, so that a wave has RB rows of latency in flight instead of one.
+    constexpr int RB = 4;               // (scalar A loads with 6-8 rows in flight, possible when a workgroup shares every row, measured slower)
+    for (int m0 = blockIdx.x * rows_per_block + rsub; m0 < r_end; m0 += RB * rstep) {
+        uint32_t a[RB][KC * 4];
+        float o[RB][4];
+#pragma unroll
+        for (int r = 0; r < RB; ++r) {
+            const int m = min(m0 + r * rstep, M - 1);           // rows past the range: a valid address, result dropped
+            const T* ar = A + (long)m * lda;
+#pragma unroll
+            for (int q = 0; q < KC; ++q) {
+                const uint4 v = *reinterpret_cast<const uint4*>(ar + q * 8);
+                a[r][q * 4] = v.x; a[r][q * 4 + 1] = v.y; a[r][q * 4 + 2] = v.z; a[r][q * 4 + 3] = v.w;
+            }
+#pragma unroll
+            for (int p = 0; p < KC * 4; ++p) { if (2 * p >= Kv) a[r][p] = 0u; else if (2 * p + 1 >= Kv) a[r][p] &= 0xffffu; }   // pad columns of A may hold anything
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[r][e] = 0.f;
+            if (accumulate) ld4<T>(C + (long)m * ldc + c0, o[r]);
+        }
+#pragma unroll
+        for (int r = 0; r < RB; ++r) {
+            const int m = m0 + r * rstep;
+            if (m < r_end) {
+                float acc[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float s0 = 0.f, s1 = 0.f;                  // two chains per column
+#pragma unroll
+                    for (int p = 0; p < KC * 4; p += 2) { s0 = dot2acc<T>(a[r][p], w[e][p], s0); s1 = dot2acc<T>(a[r][p + 1], w[e][p + 1], s1); }
+                    acc[e] = (s0 + s1) * alpha + o[r][e];
+                }
+                st4<T>(C + (long)m * ldc + c0, acc);
+            }
+        }
+    }
+}
 }  // namespace
 
 #define ST ((hipStream_t)stream)
 
-extern "C" int cmpc_lowrank_nt(int dt, const void* A, int lda, int64_t sA, const void* Bt, int ldb, int64_t sB, void* C, int ldc, int64_t sC,
+extern "C" int cmpc_lowrank_nn(int dt, const void* A, int lda, int64_t sA, const void* Bk, int ldb, int64_t sB, void* C, int ldc, int64_t sC,
                                int M, int N, int n_valid, int Kv, int batch, float alpha, int accumulate, void* stream) {
-    if (!A || !Bt || !C || M <= 0 || N <= 0 || batch <= 0 || Kv <= 0) { cmpc_set_error("lowrank_nt: bad args"); return CMPC_EINVAL; }
-    if (dt != DT_BF16 && dt != DT_F16) { cmpc_set_error("lowrank_nt: 16-bit storage only"); return CMPC_EINVAL; }
-    const int tpr = N / 8, kc = (Kv + 7) / 8;
-    if (N % 8 || tpr > 256 || (tpr & (tpr - 1)) || Kv > 32 || lda < kc * 8 || ldb < kc * 8 || lda % 8 || ldb % 8 || ldc % 8 || sA % 8 || sB % 8 || sC % 8 ||
-        ((uintptr_t)A | (uintptr_t)Bt | (uintptr_t)C) % 16) {
-        cmpc_set_error("lowrank_nt: need N = 8 * 2^j <= 2048, Kv <= 32 and 16-B aligned rows (N=%d Kv=%d lda=%d ldb=%d ldc=%d)", N, Kv, lda, ldb, ldc);
+    if (!A || !Bk || !C || M <= 0 || N <= 0 || batch <= 0 || Kv <= 0) { cmpc_set_error("lowrank_nn: bad args"); return CMPC_EINVAL; }
+    if (dt != DT_BF16 && dt != DT_F16) { cmpc_set_error("lowrank_nn: 16-bit storage only"); return CMPC_EINVAL; }
+    const int tpr = N / 4, kc = (Kv + 7) / 8;
+    if (N % 4 || tpr > 256 || (tpr & (tpr - 1)) || Kv > 24 || lda < kc * 8 || ldb < N || lda % 8 || ldb % 4 || ldc % 4 || sA % 8 || sB % 4 || sC % 4 ||
+        (uintptr_t)A % 16 || ((uintptr_t)Bk | (uintptr_t)C) % 8) {
+        cmpc_set_error("lowrank_nn: need N = 4 * 2^j <= 1024, Kv <= 24, lda >= 8*ceil(Kv/8) and aligned rows (N=%d Kv=%d lda=%d ldb=%d ldc=%d)", N, Kv, lda, ldb, ldc);
         return CMPC_EINVAL;
     }
-    // one workgroup per CU and batch slice: the weights are register-resident per workgroup, so few, long row ranges
-    int per = (M * batch + 255) / 256; per = per < 16 ? 16 : per;
-    const int rstep = 256 / tpr; per = (per + rstep - 1) / rstep * rstep;
+    // ~4 workgroups per CU (the row loop is a chain of dependent loads); a workgroup re-reads its weights (Kv x N, L2) per ~12 rows
+    const int rstep = 256 / tpr;
+    const int rb = 4;                                        // rows per trip of the kernel
+    int per = (M * batch + 1023) / 1024; per = per < rb * rstep ? rb * rstep : per;
+    per = (per + rb * rstep - 1) / (rb * rstep) * (rb * rstep);
     const dim3 grid((M + per - 1) / per, batch);
-#define LR_LAUNCH(TT, KC) hipLaunchKernelGGL((lowrank_nt_kernel<TT, KC>), grid, dim3(256), 0, ST, (const TT*)A, lda, (long)sA, (const TT*)Bt, ldb, (long)sB, \
+#define LR_LAUNCH(TT, KC) hipLaunchKernelGGL((lowrank_nn_kernel<TT, KC>), grid, dim3(256), 0, ST, (const TT*)A, lda, (long)sA, (const TT*)Bk, ldb, (long)sB, \
                                              (TT*)C, ldc, (long)sC, M, N, n_valid, Kv, alpha, accumulate, per)
-    if (dt == DT_F16) { if (kc <= 2) LR_LAUNCH(f16_t, 2); else if (kc == 3) LR_LAUNCH(f16_t, 3); else LR_LAUNCH(f16_t, 4); }
-    else { if (kc <= 2) LR_LAUNCH(bf16_t, 2); else if (kc == 3) LR_LAUNCH(bf16_t, 3); else LR_LAUNCH(bf16_t, 4); }
+    if (dt == DT_F16) { if (kc <= 2) LR_LAUNCH(f16_t, 2); else LR_LAUNCH(f16_t, 3); }
+    else { if (kc <= 2) LR_LAUNCH(bf16_t, 2); else LR_LAUNCH(bf16_t, 3); }
 #undef LR_LAUNCH
-    return cmpc_check_launch("lowrank_nt");
+    return cmpc_check_launch("lowrank_nn");
 }
 
 extern "C" int cmpc_mutan_fwd(int dt, void* P, const float* g, void* X1, float* rstd, int B, int N, int ld, int C, int pre_tanh, void* stream) {

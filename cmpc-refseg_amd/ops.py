@@ -75,9 +75,9 @@ def gemm_nt(dt, segs: Sequence[Tuple], C, ldc, M, N, n_valid=None, batch=1, sC=0
     _lib.call("cmpc_gemm_nt", ctypes.byref(a), _st())
 
 
-def lowrank_nt(dt, A, lda, sA, Bt, ldb, sB, C, ldc, sC, M, N, Kv, n_valid=None, batch=1, alpha=1.0, accumulate=False):
-    """C[b][m, n] (+)= alpha * sum_{k < Kv} A[b][m, k] Bt[b][n, k] (16-bit storage, Kv <= 32): cmpc_lowrank_nt."""
-    _lib.call("cmpc_lowrank_nt", dt, _p(A), lda, sA, _p(Bt), ldb, sB, _p(C), ldc, sC, M, N, N if n_valid is None else n_valid, Kv, batch,
+def lowrank_nn(dt, A, lda, sA, Bk, ldb, sB, C, ldc, sC, M, N, Kv, n_valid=None, batch=1, alpha=1.0, accumulate=False):
+    """C[b][m, n] (+)= alpha * sum_{k < Kv} A[b][m, k] Bk[b][k, n] (16-bit storage, Kv <= 24, Bk k-major): cmpc_lowrank_nn."""
+    _lib.call("cmpc_lowrank_nn", dt, _p(A), lda, sA, _p(Bk), ldb, sB, _p(C), ldc, sC, M, N, N if n_valid is None else n_valid, Kv, batch,
               float(alpha), int(accumulate), _st())
 
 

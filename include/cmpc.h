@@ -125,9 +125,10 @@ int cmpc_sample_stats(int dt, const void* x, double* sums, int B, int N, int ld,
  *      values (the GEMM ran with ACT_TANH) and is only read ----------------------------------- */
 int cmpc_mutan_fwd(int dt, void* P, const float* g, void* X1, float* rstd, int B, int N, int ld, int C, int pre_tanh, void* stream);
 /* ---- short-reduction product of the cross-modal graph (CMPC_model.py:359-410: Y = gw_w . Z, dX1 += gw_v . dZ,
- *      dX1 += scale * dA0 . PT): C[b][m, n] (+)= alpha * sum_{k < Kv} A[b][m, k] * Bt[b][n, k], Kv <= 32 (the word axis),
- *      16-bit storage, fp32 accumulation; columns n >= n_valid contribute zero.  A streaming kernel, not a GEMM -------- */
-int cmpc_lowrank_nt(int dt, const void* A, int lda, int64_t sA, const void* Bt, int ldb, int64_t sB, void* C, int ldc, int64_t sC,
+ *      dX1 += scale * dA0 . PT): C[b][m, n] (+)= alpha * sum_{k < Kv} A[b][m, k] * Bk[b][k, n], Kv <= 24 (the word axis),
+ *      Bk k-major, 16-bit storage, fp32 accumulation; columns n >= n_valid contribute zero, columns k >= Kv of A are
+ *      ignored.  A streaming kernel, not a GEMM ------------------------------------------------------------------- */
+int cmpc_lowrank_nn(int dt, const void* A, int lda, int64_t sA, const void* Bk, int ldb, int64_t sB, void* C, int ldc, int64_t sC,
                     int M, int N, int n_valid, int Kv, int batch, float alpha, int accumulate, void* stream);
 /* in: Th (tanh values), dX1; out: Th overwritten by dP_h, dg[b][5*ld] += column sums */
 int cmpc_mutan_bwd(int dt, void* Th, const float* g, const void* X1, const float* rstd, const void* dX1,

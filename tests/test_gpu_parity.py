@@ -148,18 +148,18 @@ def test_gemm_tn_grouped_against_torch():
 
 
 @pytest.mark.parametrize("dt,tdt", [(1, torch.bfloat16), (2, torch.float16)])
-def test_lowrank_nt_against_torch(dt, tdt):
+def test_lowrank_nn_against_torch(dt, tdt):
     """The short-reduction streaming product of the cross-modal graph (Y = gw_w . Z and the two dX1 updates, CMPC_model.py:359-410):
-    batched, strided weights (the PT^T layout), Kv not a multiple of 8 with garbage beyond Kv, pad columns, alpha, accumulate."""
+    batched, k-major weights, Kv not a multiple of 8 with garbage beyond Kv in A, pad columns, alpha, accumulate."""
     ops, dev = _ops(), torch.device("cuda:0")
     torch.manual_seed(11)
     for (B, M, N, nv, Kv, ld, acc, alpha) in ((8, 1600, 1024, 1000, 20, 64, False, 1.0), (8, 1600, 1024, 1000, 20, 64, True, 0.0316), (2, 37, 64, 24, 5, 64, True, 1.0),
-                                              (3, 100, 256, 256, 32, 32, False, 2.0), (1, 300, 2048, 2040, 17, 24, True, 1.0)):
+                                              (3, 100, 256, 256, 24, 24, False, 2.0), (1, 300, 512, 508, 17, 24, True, 1.0)):
         A = torch.randn(B, M, ld, device=dev).to(tdt)                       # columns >= Kv hold garbage: must be ignored
-        W = torch.randn(N, B * ld, device=dev).to(tdt)                      # Bt of batch b = W[:, b*ld : b*ld + ld] (ldb = B*ld, sB = ld)
+        W = torch.randn(B, 64, N, device=dev).to(tdt)                       # Bk of batch b = W[b] (rows >= Kv: garbage, must be ignored)
         C = torch.randn(B, M, N, device=dev).to(tdt); C0 = C.clone()
-        ops.lowrank_nt(dt, A, ld, M * ld, W, B * ld, ld, C, N, M * N, M, N, Kv, n_valid=nv, batch=B, alpha=alpha, accumulate=acc)
-        ref = torch.stack([A[b, :, :Kv].float() @ W[:, b * ld: b * ld + Kv].float().t() for b in range(B)]) * alpha
+        ops.lowrank_nn(dt, A, ld, M * ld, W, N, 64 * N, C, N, M * N, M, N, Kv, n_valid=nv, batch=B, alpha=alpha, accumulate=acc)
+        ref = torch.stack([A[b, :, :Kv].float() @ W[b, :Kv].float() for b in range(B)]) * alpha
         ref[:, :, nv:] = 0
         if acc:
             ref = ref + C0.float()
@@ -168,7 +168,7 @@ def test_lowrank_nt_against_torch(dt, tdt):
         if acc and nv < N:
             assert torch.equal(C[:, :, nv:], C0[:, :, nv:])
     with pytest.raises(Exception):
-        ops.lowrank_nt(dt, A, ld, M * ld, W, B * ld, ld, C, N, M * N, M, N, 40)      # Kv > 32
+        ops.lowrank_nn(dt, A, ld, M * ld, W, N, 64 * N, C, N, M * N, M, N, 25)      # Kv > 24
 
 
 @pytest.mark.parametrize("dt,tdt", [(1, torch.bfloat16), (2, torch.float16)])
