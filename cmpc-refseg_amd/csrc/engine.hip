@@ -786,21 +786,14 @@ int parser_bwd(E* e, hipStream_t st) {
 // ------------------------------------------------------------------------------------------
 // stages of one pyramid level
 // ------------------------------------------------------------------------------------------
-int level_fwd(E* e, hipStream_t st, int li, const float* target) {
+// The language side of a level -- everything that depends on the text encoder only (the five lang_trans heads, the word-side
+// operands of build_spa_graph, the tiled-language share of the fusion conv): ~8 small fp32 launches that run while the backbone
+// is still producing the visual features.
+int level_lang_fwd(E* e, hipStream_t st, int li) {
     LevelBuf& L = e->lv[li]; const char* lv = LEVELS[li];
-    const int B = e->B, N = e->N, T = e->T, R = e->R, C = e->C, Cp = e->Cp, Tp = e->Tp, M = e->M, Mp = e->Mp, dt = e->dt;
-    // -- lateral 1x1 conv + l2_normalize (CMPC_model.py:108-113)
-    { GemmOpt o; o.n_valid = C; o.bias = pptr(e, fmt("%s_lateral/biases", lv));
-      CK(gemm_nt(st, dt, {{L.feat, L.cin, opp(e, fmt("lat_%s.t", lv)), L.cin, L.cin}}, L.X0, Cp, R, Cp, o));
-      CK(cmpc_l2norm_rows_fwd(dt, L.X0, L.X0, L.lat_rstd, nullptr, R, Cp, C, st)); }
-    // -- mutan_fusion (:295-328)
+    const int B = e->B, T = e->T, C = e->C, Cp = e->Cp, Tp = e->Tp, M = e->M, Mp = e->Mp, dt = e->dt;
     { GemmOpt o; o.bias = (const float*)opp(e, fmt("mlang_%s.b", lv)); o.act = ACT_TANH;
-      CK(gemm_nt(st, DT_F32, {{e->vl, Cp, opp(e, fmt("mlang_%s.t", lv)), Cp, Cp}}, L.g, 5 * Cp, B, 5 * Cp, o));
-      const int ldk = Cp + 64; const std::string k = fmt("mutan_%s.t", lv);
-      GemmOpt p; p.bias = (const float*)opp(e, fmt("mutan_%s.b", lv)); if (e->mutan_epilogue) p.act = ACT_TANH;
-      CK(gemm_nt(st, dt, {{L.X0, Cp, opp(e, k), ldk, Cp}, {e->spatial, 64, opp(e, k, 0, Cp), ldk, 64}}, L.P, 5 * Cp, R, 5 * Cp, p));
-      CK(cmpc_mutan_fwd(dt, L.P, L.g, L.X1, L.mut_rstd, B, N, Cp, C, e->mutan_epilogue ? 1 : 0, st)); }
-    // -- build_spa_graph + graph_conv (:359-410); adjacency never formed, trans2 folded into the word side
+      CK(gemm_nt(st, DT_F32, {{e->vl, Cp, opp(e, fmt("mlang_%s.t", lv)), Cp, Cp}}, L.g, 5 * Cp, B, 5 * Cp, o)); }
     { const float scale = 1.0f / sqrtf((float)C);
       const std::string t2n = fmt("t2_%s.n", lv);
       GemmOpt a; a.n_valid = C; a.batch = B; a.sC = (int64_t)Tp * Cp; a.bias = pptr(e, fmt("words_trans_%s/biases", lv));
@@ -810,10 +803,30 @@ int level_fwd(E* e, hipStream_t st, int li, const float* target) {
       CK(cmpc_cast(DT_F32, L.PTf, dt, L.PT, (int64_t)B * Tp * Cp, st));
       if (!e->lowrank) CK(transpose_cast(st, L.PTf, dt, L.PTt, B * Tp, Cp));   // PT^T [Cp][B*Tp] (GEMM operand of dX1 += dA0 . PT)
       CK(cmpc_rowdot1(DT_F32, L.Wd, pptr(e, fmt("spa_graph_trans2_%s/biases", lv)), 0, L.k0s, 1, B * Tp, Cp, C, scale, st));
+      hipLaunchKernelGGL(col_get_kernel, dim3((B * T + 255) / 256), dim3(256), 0, st, e->parse, 4, 2, L.pr, B * T);
+      CK(cmpc_check_launch("col_get")); }
+    { GemmOpt s; s.n_valid = M;
+      CK(gemm_nt(st, DT_F32, {{e->vl, Cp, opp(e, fmt("fusl_%s.t", lv)), Cp, Cp}}, L.sb, Mp, B, Mp, s)); }
+    return CMPC_OK;
+}
+
+// the visual side (after level_lang_fwd, once the backbone taps are complete)
+int level_fwd(E* e, hipStream_t st, int li, const float* target) {
+    LevelBuf& L = e->lv[li]; const char* lv = LEVELS[li];
+    const int B = e->B, N = e->N, T = e->T, R = e->R, C = e->C, Cp = e->Cp, Tp = e->Tp, M = e->M, Mp = e->Mp, dt = e->dt;
+    // -- lateral 1x1 conv + l2_normalize (CMPC_model.py:108-113)
+    { GemmOpt o; o.n_valid = C; o.bias = pptr(e, fmt("%s_lateral/biases", lv));
+      CK(gemm_nt(st, dt, {{L.feat, L.cin, opp(e, fmt("lat_%s.t", lv)), L.cin, L.cin}}, L.X0, Cp, R, Cp, o));
+      CK(cmpc_l2norm_rows_fwd(dt, L.X0, L.X0, L.lat_rstd, nullptr, R, Cp, C, st)); }
+    // -- mutan_fusion (:295-328)
+    { const int ldk = Cp + 64; const std::string k = fmt("mutan_%s.t", lv);
+      GemmOpt p; p.bias = (const float*)opp(e, fmt("mutan_%s.b", lv)); if (e->mutan_epilogue) p.act = ACT_TANH;
+      CK(gemm_nt(st, dt, {{L.X0, Cp, opp(e, k), ldk, Cp}, {e->spatial, 64, opp(e, k, 0, Cp), ldk, 64}}, L.P, 5 * Cp, R, 5 * Cp, p));
+      CK(cmpc_mutan_fwd(dt, L.P, L.g, L.X1, L.mut_rstd, B, N, Cp, C, e->mutan_epilogue ? 1 : 0, st)); }
+    // -- build_spa_graph + graph_conv (:359-410); adjacency never formed, trans2 folded into the word side
+    { const float scale = 1.0f / sqrtf((float)C);
       GemmOpt c; c.batch = B; c.sC = (int64_t)N * Tp; c.c_f32 = 1; c.alpha = scale; c.sbias = L.k0s; c.ld_sbias = Tp; c.rows_per_sample = N;
       CK(gemm_nt(st, dt, {{L.X1, Cp, L.PT, Cp, Cp, (int64_t)N * Cp, (int64_t)Tp * Cp}}, L.A0, Tp, N, Tp, c));
-      hipLaunchKernelGGL(col_get_kernel, dim3((B * T + 255) / 256), dim3(256), 0, st, e->parse, 4, 2, L.pr, B * T);
-      CK(cmpc_check_launch("col_get"));
       CK(cmpc_graph_softmax_fwd(dt, L.A0, L.pr, e->mask, L.gw_w, L.gw_v, L.gw_w_t, L.gw_v_t, L.gsc, B, N, T, Tp, st));
       if (e->lowrank) {      // Z = gw_v^T . X1 [T, C] k-major (kept for the backward pass), Y = gw_w . Z as a stream of Y
           TnOpt zt; zt.nb2 = B; zt.a_bs = (int64_t)N * Tp; zt.d_bs = (int64_t)N * Cp; zt.o_bs = (int64_t)Tp * Cp;
@@ -835,9 +848,7 @@ int level_fwd(E* e, hipStream_t st, int li, const float* target) {
       CK(cmpc_sample_stats(dt, L.U, L.sums2, B, N, Cp, C, st));
       CK(cmpc_gconv_post_fwd(dt, L.U, L.sums2, pptr(e, ln2 + "/gamma"), pptr(e, ln2 + "/beta"), L.X2, L.rrow, B, N, Cp, C, st)); }
     // -- fusion 1x1 over [vis_la_sp | spa_graph | tile(valid_lang) | spatial] (:338-344); the concat is never formed
-    { GemmOpt s; s.n_valid = M;
-      CK(gemm_nt(st, DT_F32, {{e->vl, Cp, opp(e, fmt("fusl_%s.t", lv)), Cp, Cp}}, L.sb, Mp, B, Mp, s));
-      const int ldk = 2 * Cp + 64; const std::string k = fmt("fus_%s.t", lv);
+    { const int ldk = 2 * Cp + 64; const std::string k = fmt("fus_%s.t", lv);
       GemmOpt f; f.n_valid = M; f.bias = pptr(e, fmt("fusion_%s/biases", lv)); f.sbias = L.sb; f.ld_sbias = Mp; f.rows_per_sample = N; f.act = ACT_RELU;
       CK(gemm_nt(st, dt, {{L.X1, Cp, opp(e, k), ldk, Cp}, {L.X2, Cp, opp(e, k, 0, Cp), ldk, Cp}, {e->spatial, 64, opp(e, k, 0, 2 * Cp), ldk, 64}},
                  L.F, Mp, R, Mp, f)); }
@@ -953,14 +964,19 @@ int level_bwd(E* e, hipStream_t st, int li, const float* target) {
 // ------------------------------------------------------------------------------------------
 // stage: gated_exchange_module + l2_normalize, CMPC_model.py:194-259,271-284 (key folded into the query)
 // ------------------------------------------------------------------------------------------
+// the language side of an exchange module (query and folded key: functions of nec_lang only), run before the visual features exist
+int exchange_lang_fwd(E* e, hipStream_t st, int xi) {
+    ExgBuf& X = e->ex[xi]; const char* lv = EXG[xi];
+    const int B = e->B, Cp = e->Cp, M = e->M, Mp = e->Mp;
+    GemmOpt q; q.n_valid = M; q.bias = pptr(e, fmt("lang_query_%sgv_f1/biases", lv));
+    CK(gemm_nt(st, DT_F32, {{e->nec, Cp, opp(e, fmt("query_%s.t", lv)), Cp, Cp}}, X.q, Mp, B, Mp, q));
+    GemmOpt k; k.n_valid = M;
+    return gemm_nt(st, DT_F32, {{X.q, Mp, opp(e, fmt("key_%s.n", lv)), Mp, Mp}}, X.kq, Mp, B, Mp, k);
+}
 int exchange_fwd(E* e, hipStream_t st, int xi, const void* feat, const void* f1, const void* f2) {
     ExgBuf& X = e->ex[xi]; const char* lv = EXG[xi];
     const int B = e->B, N = e->N, R = e->R, Cp = e->Cp, M = e->M, Mp = e->Mp, dt = e->dt;
     const float s = 1.0f / sqrtf((float)M);
-    GemmOpt q; q.n_valid = M; q.bias = pptr(e, fmt("lang_query_%sgv_f1/biases", lv));
-    CK(gemm_nt(st, DT_F32, {{e->nec, Cp, opp(e, fmt("query_%s.t", lv)), Cp, Cp}}, X.q, Mp, B, Mp, q));
-    GemmOpt k; k.n_valid = M;
-    CK(gemm_nt(st, DT_F32, {{X.q, Mp, opp(e, fmt("key_%s.n", lv)), Mp, Mp}}, X.kq, Mp, B, Mp, k));
     CK(cmpc_rowdot1(dt, feat, X.kq, Mp, X.logits, B, N, Mp, M, s, st));
     CK(cmpc_softmax_n_fwd(X.logits, X.attn, B, N, st));
     CK(cmpc_wcolsum(dt, feat, X.attn, X.pooled, Mp, B, N, Mp, M, 1.0f, st));
@@ -1476,16 +1492,19 @@ extern "C" int cmpc_forward(cmpc_handle e, const cmpc_feeds* f, const cmpc_fetch
     CK(text_fwd(e, main, f->words, f->seq_len));
     CK(parser_fwd(e, main));
     CK(cmpc_lang_pool_fwd(e->parse, e->wf, e->vl, e->vl_rstd, B, e->T, Cp, e->RNN, 2, main));      // valid_lang: entity + attribute
+    CK(cmpc_lang_pool_fwd(e->parse, e->wf, e->nec, e->nec_rstd, B, e->T, Cp, e->RNN, 3, main));    // nec_lang: + relation
     CK(params_ready(e, main, 1));
     CK(mark(e, "fwd:text_done", main));
-    if (f->feats_ready) HCK(hipStreamWaitEvent(main, (hipEvent_t)f->feats_ready, 0));
-    CK(mark(e, "fwd:feats_ready", main));
+    // Everything that is a function of the text alone (the levels' language operands, the exchange modules' queries) goes first, on
+    // the lanes, while the backbone (caller's side stream) is still running; each lane then waits for the visual features itself.
     hipStream_t st[3];
     CK(fork_lanes(e, main, st));
+    for (int i = 0; i < 3; ++i) { CK(level_lang_fwd(e, st[i], i)); CK(exchange_lang_fwd(e, st[i], i)); CK(exchange_lang_fwd(e, st[i], 3 + i)); }
+    if (f->feats_ready) for (int i = 0; i < (e->cfg.n_lanes > 1 ? 3 : 1); ++i) HCK(hipStreamWaitEvent(st[i], (hipEvent_t)f->feats_ready, 0));
+    CK(mark(e, "fwd:feats_ready", st[0]));
     const char* lvm[3] = {"fwd:level_c5_done", "fwd:level_c4_done", "fwd:level_c3_done"};
     for (int i = 0; i < 3; ++i) { CK(level_fwd(e, st[i], i, f->target_fine)); CK(mark(e, lvm[i], st[i])); }
     CK(join_lanes(e, main));
-    CK(cmpc_lang_pool_fwd(e->parse, e->wf, e->nec, e->nec_rstd, B, e->T, Cp, e->RNN, 3, main));    // nec_lang: + relation
     // gated_exchange_fusion_lstm_2times (:261-293): fusion maps in EXG order c3, c4, c5 = lv[2], lv[1], lv[0]
     const void* fz[3] = {e->lv[2].F, e->lv[1].F, e->lv[0].F};
     const int o1[3] = {1, 0, 0}, o2[3] = {2, 2, 1};                           // (c3: c4,c5) (c4: c3,c5) (c5: c3,c4)
