@@ -1083,13 +1083,22 @@ int clstm_bwd(E* e, hipStream_t st, hipEvent_t* dx_ready) {
         for (int g = 0; g < 4; ++g) { ox.push_back({0, (int64_t)g * Mp, (int64_t)g * M}); oh.push_back({0, (int64_t)g * Mp, (int64_t)M * 4 * M + (int64_t)g * M}); }
         CK(gemm_tn(e, st, dt, xs[s], Mp, Mp, S.dYg, 4 * Mp, Mp, gk, 4 * M, R, M, M, ox, d));
         GemmOpt o; o.n_valid = M;
-        CK(gemm_nt(st, dt, {{S.dYg, 4 * Mp, opp(e, "clstm.n"), 4 * Mp, 4 * Mp}}, S.dx, Mp, R, Mp, o));
-        if (dx_ready && dx_ready[s]) HCK(hipEventRecord(dx_ready[s], st));
+        // the input gradient of step s feeds the round-2 exchange module s, not the recurrence: with lanes it is computed on that
+        // module's lane, so that the serial chain on `st` is gate backward -> dh product -> next step only
+        hipStream_t xst = st;
+        if (dx_ready && dx_ready[s] && e->cfg.n_lanes > 1) {
+            hipEvent_t ev = next_event(e);
+            HCK(hipEventRecord(ev, st));
+            xst = e->lane[s];
+            HCK(hipStreamWaitEvent(xst, ev, 0));
+        }
         if (s > 0) {
             CK(gemm_tn(e, st, dt, h_prev, Mp, Mp, S.dYg, 4 * Mp, Mp, gk, 4 * M, R, M, M, oh, d));
             CK(gemm_nt(st, dt, {{S.dYg, 4 * Mp, opp(e, "clstm.n", Mp, 0), 4 * Mp, 4 * Mp}}, S.dh, Mp, R, Mp, o));
             dh = S.dh; dc = S.dc_prev;
         }
+        CK(gemm_nt(xst, dt, {{S.dYg, 4 * Mp, opp(e, "clstm.n"), 4 * Mp, 4 * Mp}}, S.dx, Mp, R, Mp, o));
+        if (dx_ready && dx_ready[s]) HCK(hipEventRecord(dx_ready[s], xst));
     }
     return CMPC_OK;
 }
