@@ -1616,11 +1616,13 @@ extern "C" int cmpc_backward(cmpc_handle e, void* stream) {
     CK(join_lanes(e, main));
     CK(mark(e, "bwd:exch1_done", main));
     HOSTPROF("exch1");
-    CK(flush_bucket(e, main, 0));              // exchange modules, ConvLSTM, final score: gradients final
-    // pyramid levels (lane i = level i = c5, c4, c3 = exchange input 2 - i); the language-side sums run on main meanwhile
+    // pyramid levels (lane i = level i = c5, c4, c3 = exchange input 2 - i); the language-side sums run on main meanwhile, and so do
+    // the weight-gradient products of the bucket that has just become final (exchange modules, ConvLSTM, final score): issued AFTER
+    // the fork, they run beside the levels instead of holding the three lanes back for their ~0.4 ms
     CK(fork_lanes(e, main, st));
     CK(add_n(main, DT_F32, e->dnec, {e->ex[0].dnec, e->ex[1].dnec, e->ex[2].dnec, e->ex[3].dnec, e->ex[4].dnec, e->ex[5].dnec}, false, (long)B * Cp));
     CK(cmpc_lang_pool_bwd(e->dnec, e->nec, e->nec_rstd, e->parse, e->wf, e->dparse, e->dwf, B, T, Cp, e->RNN, 3, main));
+    CK(flush_bucket(e, main, 0));
     for (int i = 0; i < 3; ++i) {
         const void* src[3];
         fan_in(0, 2 - i, src);
