@@ -2,7 +2,7 @@
 # same-box A/B of library builds / switches, alternating: each argument is "tag[:lib.so][:ENV=VAL...]" (default: prev = build/libcmpc_prev.so
 # against the in-tree build).  Prints ms_per_step of bench.py per variant and round.
 VARS=("$@"); [ ${#VARS[@]} -eq 0 ] && VARS=("prev:build/libcmpc_prev.so" "cur")
-for i in 1 2 3; do
+for i in $(seq 1 ${ROUNDS:-3}); do
   for v in "${VARS[@]}"; do
     IFS=: read -r tag lib envs <<< "$v"
     r=$( ( [ -n "$lib" ] && export CMPC_LIB_PATH=$PWD/$lib; for e in ${envs//,/ }; do export $e; done
