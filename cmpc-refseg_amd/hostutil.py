@@ -6,9 +6,11 @@
   image feed            trainval_model.py:90-91,229-230,371   (RGB -> BGR, minus the channel means)
   mask IoU bookkeeping  util/eval_tools.py:31-35, trainval_model.py:267-296   (I/U, cumulative IoU, precision@X)
 
-Resizing (util/im_processing.py:7-41) goes through scikit-image in the reference (third-party, not installed
-here); `resize_and_pad_geometry` / `resize_and_crop_geometry` return the geometry those functions compute so that any
-resampler can be plugged in -- the resampled pixel values themselves are parity-unpinned.
+Resizing (util/im_processing.py:7-41) goes through scikit-image in the reference (third-party, not installed here, and its
+`resize` defaults changed between releases).  `resize_and_pad_geometry` / `resize_and_crop_geometry` return the geometry those
+functions compute (pinned by hand-worked cases); `resize_and_pad` / `resize_and_crop` fill it with a restatement of
+`skimage.transform.resize` as scikit-image >= 0.19 documents it (order 1, mode "reflect", anti-aliasing Gaussian when shrinking,
+uint8 scaled to [0, 1]) on scipy.ndimage -- the resampled pixel values are PARITY-UNPINNED (no scikit-image to compare with).
 """
 from __future__ import annotations
 
@@ -69,6 +71,46 @@ def resize_and_crop_geometry(im_h: int, im_w: int, out_h: int, out_w: int) -> Tu
     scale = max(out_h / im_h, out_w / im_w)
     rh, rw = int(np.round(im_h * scale)), int(np.round(im_w * scale))
     return rh, rw, int(np.floor(rh - out_h) / 2), int(np.floor(rw - out_w) / 2)
+
+
+def skimage_like_resize(im: np.ndarray, out_h: int, out_w: int) -> np.ndarray:
+    """skimage.transform.resize(im, [out_h, out_w]) as scikit-image >= 0.19 documents its defaults: integer images become floats in
+    [0, 1] (img_as_float), bilinear (order=1), mode="reflect" (numpy.pad's: ndimage "mirror"), anti_aliasing on when an axis shrinks
+    (Gaussian, sigma = (scale - 1) / 2 per shrinking axis), pixel-area grid (ndimage.zoom grid_mode=True); channels are not resized.
+    Parity-unpinned (module header)."""
+    from scipy import ndimage as ndi
+    a = np.asarray(im)
+    if a.dtype == np.bool_:
+        a = a.astype(np.float64)
+    elif np.issubdtype(a.dtype, np.integer):
+        a = a.astype(np.float64) / float(np.iinfo(a.dtype).max)
+    else:
+        a = a.astype(np.float64)
+    h, w = a.shape[:2]
+    if (h, w) == (out_h, out_w):
+        return a
+    factors = (h / out_h, w / out_w)
+    extra = (1,) * (a.ndim - 2)
+    if max(factors) > 1:
+        sigma = tuple(max(0.0, (f - 1) / 2) for f in factors) + (0,) * (a.ndim - 2)
+        a = ndi.gaussian_filter(a, sigma, mode="mirror")
+    return ndi.zoom(a, (out_h / h, out_w / w) + extra, order=1, mode="mirror", grid_mode=True)
+
+
+def resize_and_pad(im: np.ndarray, input_h: int, input_w: int) -> np.ndarray:
+    """im_processing.resize_and_pad (util/im_processing.py:7-23): aspect-preserving resize to fit, centred on a zero canvas."""
+    rh, rw, top, left = resize_and_pad_geometry(im.shape[0], im.shape[1], input_h, input_w)
+    r = skimage_like_resize(im, rh, rw)
+    out = np.zeros((input_h, input_w) + r.shape[2:], dtype=r.dtype)
+    out[top: top + rh, left: left + rw, ...] = r
+    return out
+
+
+def resize_and_crop(im: np.ndarray, input_h: int, input_w: int) -> np.ndarray:
+    """im_processing.resize_and_crop (util/im_processing.py:25-41): aspect-preserving resize to cover, centre crop."""
+    rh, rw, top, left = resize_and_crop_geometry(im.shape[0], im.shape[1], input_h, input_w)
+    r = skimage_like_resize(im, rh, rw)
+    return np.ascontiguousarray(r[top: top + input_h, left: left + input_w, ...])
 
 
 def compute_mask_IU(masks: np.ndarray, target: np.ndarray) -> Tuple[int, int]:

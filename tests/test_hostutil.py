@@ -96,3 +96,32 @@ def test_saver_rotation_and_names(tmp_path):
         assert {k.replace("|", "/") for k in np.load(only_bb).files} == {"conv1/weights", "bn_conv1/gamma"}
     finally:
         torch.cuda.synchronize = orig
+
+
+def test_resize_and_pad_crop_pixels():
+    """Pixel resize (parity-unpinned restatement of skimage.transform.resize, hostutil header): the properties that hold for any
+    correct bilinear resampler -- geometry of util/im_processing.py:7-41, constants stay constant, zero padding outside, identity at
+    equal size, [0, 1] range for uint8 input, monotone ramps stay monotone, the mean is preserved when shrinking."""
+    H = importlib.import_module("cmpc-refseg_amd.hostutil")
+    rng = np.random.default_rng(0)
+    im = rng.integers(0, 256, (240, 427, 3), dtype=np.uint8)
+    out = H.resize_and_pad(im, 320, 320)
+    rh, rw, top, left = H.resize_and_pad_geometry(240, 427, 320, 320)
+    assert out.shape == (320, 320, 3) and out.dtype == np.float64 and (rh, rw) == (180, 320) and (top, left) == (70, 0)
+    assert out[:top].max() == 0 and out[top + rh:].max() == 0 and 0 <= out.min() and out.max() <= 1
+    assert abs(out[top: top + rh].mean() - im.mean() / 255) < 2e-3                  # shrinking keeps the mean
+    const = np.full((100, 50, 3), 200, np.uint8)
+    r = H.resize_and_pad(const, 64, 64)
+    rh, rw, top, left = H.resize_and_pad_geometry(100, 50, 64, 64)
+    assert np.allclose(r[top: top + rh, left: left + rw], 200 / 255, atol=1e-12) and r[:, :left].max() == 0
+    sq = rng.integers(0, 256, (320, 320, 3), dtype=np.uint8)
+    assert np.array_equal(H.resize_and_pad(sq, 320, 320), sq / 255.0)
+    ramp = np.tile(np.linspace(0, 1, 50)[None, :], (20, 1))
+    up = H.skimage_like_resize(ramp, 40, 100)
+    assert up.shape == (40, 100) and np.all(np.diff(up[7]) >= -1e-12) and abs(up[:, 50].mean() - 0.5) < 0.02
+    crop = H.resize_and_crop(im, 320, 320)
+    rh, rw, top, left = H.resize_and_crop_geometry(240, 427, 320, 320)
+    assert crop.shape == (320, 320, 3) and rh == 320 and rw == 569 and left == 124 and crop.max() <= 1
+    mask = np.zeros((60, 80), bool); mask[20:40, 30:50] = True
+    m = H.resize_and_pad(mask, 320, 320)
+    assert m.shape == (320, 320) and abs(m.sum() / (320 * 320) - 400 / (60 * 80) * (240 * 320) / (320 * 320)) < 5e-3
