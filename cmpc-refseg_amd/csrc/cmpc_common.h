@@ -51,7 +51,6 @@ int cmpc_fold_flush(cmpc_fold_ctx* ctx, hipStream_t st);
 int cmpc_fold_flush_ranges(cmpc_fold_ctx* ctx, const float* const* lo, const float* const* hi, int nr, cmpc_fold_desc* table_dev,
                            cmpc_fold_desc* shadow, int* shadow_n, hipStream_t st);
 // out[o*nval + v] = sum_{i<ninner} part[(o*ninner+i)*nval + v]
-int cmpc_reduce_parts_f64(const double* part, int nouter, int ninner, int nval, double* out, hipStream_t st);
 
 __device__ __forceinline__ float bf2f(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
 __device__ __forceinline__ bf16_t f2bf(float f) {

@@ -5,7 +5,7 @@
 //            and the dX = dY . W^T products in backward.  Up to 3 K-segments share one
 //            accumulator (the reference's channel concats at CMPC_model.py:339,238 and
 //            util/cell.py:39 are never materialised).
-//  gemm_tn : out[K,N] += sum_r A[r,K]^T . D[r,N]   (weight gradients, fp32 atomics, split over r)
+//  gemm_tn : out[K,N] += sum_r A[r,K]^T . D[r,N]   (weight gradients; one writer per element: split reductions through slabs + a fold)
 //
 // Operands are T = bf16 (v_mfma_f32_16x16x32_bf16) or T = f32 (v_mfma_f32_16x16x4_f32, exact
 // fp32 - the parity mode).  Both use the same byte-level LDS image: a lane's 16-byte chunk is
@@ -1090,8 +1090,8 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const cmpc_gemm_tn_args
 // descriptor table lives in device memory (written by tn_desc_upload_kernel, a few descriptors per launch through
 // the kernel-argument segment); workgroup slot s walks the item list s, s+grid, ... (items = (product, output tile,
 // reduction split, batch) sorted by decreasing length, so the tail of the launch is made of short items).  With
-// every product in flight none needs a deep split of its reduction, so the fp32-atomic epilogue (8-20 us of a
-// 37-57 us stand-alone launch) shrinks to one pass, and there is one launch tail instead of one per group.
+// every product in flight none needs a deep split of its reduction (few slabs to fold), and there is one launch tail
+// instead of one per group.
 // The grid is at most two workgroups per CU, so the launch does not sit in the workgroup dispatcher for its whole
 // duration (a 4600-workgroup grid starves the small kernels of every other stream: 14 -> 51 ms per step).
 struct TnGroupDesc {

@@ -1,7 +1,7 @@
 // Row / whole-sample normalisation kernels and small map utilities (HBM-bound, wave-per-row).
 // Layout: map [B*N, ld] of T (bf16 or f32), C valid channels, 16-byte vector accesses, fp32 math,
-// wave64 shuffle reductions; per-sample sums in float64 atomics, per-column sums reduced through
-// LDS then one fp32 atomic per column per workgroup.
+// wave64 shuffle reductions; per-sample sums as float64 stat blocks (one pair per workgroup, summed by the consumers:
+// cmpc_common.h), per-column sums as per-workgroup partial rows folded in a fixed order (reduce_parts_*): no atomics.
 #include "cmpc_common.h"
 #include "../../include/cmpc.h"
 #include <stdarg.h>
@@ -88,18 +88,9 @@ __global__ __launch_bounds__(256) void reduce_parts_f32_kernel(const float* __re
         *dst = accumulate ? *dst + s : s;
     }
 }
-__global__ __launch_bounds__(64) void reduce_parts_f64_kernel(const double* __restrict__ part, int ninner, int nval, double* __restrict__ out) {
-    const int lane = threadIdx.x, o = blockIdx.x;
-    for (int v = 0; v < nval; ++v) {
-        double s = 0.0;
-        for (int i = lane; i < ninner; i += 64) s += part[((long)o * ninner + i) * nval + v];
-        s = wave_sum_d(s);
-        if (lane == 0) out[(long)o * nval + v] = s;
-    }
-}
 // every recorded fold in one launch: a block owns 64 columns of one (fold, outer index) and walks ALL its partial rows in a fixed
-// order (no split of a column between blocks), so a fold's result does not depend on scheduling; folds that share a target meet
-// in the final atomic add
+// order (no split of a column between blocks), so a fold's result does not depend on scheduling; folds that share a target are
+// chained behind one head and summed by the same block
 __global__ __launch_bounds__(256) void reduce_parts_grouped_kernel(const cmpc_fold_desc* __restrict__ table, int ndesc) {
     __shared__ float red[4][64];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -213,10 +204,6 @@ int cmpc_reduce_parts_f32(const float* part, long part_stride, int nouter, int n
     hipLaunchKernelGGL(reduce_parts_f32_kernel, dim3((cols + 63) / 64, nouter), dim3(256), 0, st, part, part_stride, ninner, nseg, seg_ld, seg_C,
                        out, ld_out, out_seg, accumulate);
     return cmpc_check_launch("reduce_parts_f32");
-}
-int cmpc_reduce_parts_f64(const double* part, int nouter, int ninner, int nval, double* out, hipStream_t st) {
-    hipLaunchKernelGGL(reduce_parts_f64_kernel, dim3(nouter), dim3(64), 0, st, part, ninner, nval, out);
-    return cmpc_check_launch("reduce_parts_f64");
 }
 extern "C" int cmpc_abi_version(void) { return 1; }
 
