@@ -277,6 +277,27 @@ def test_head_16bit_within_tolerance(case, dtype, tap_tol, loss_tol, grad_tol):
     assert max(errs.values()) < grad_tol, errs
 
 
+@pytest.mark.parametrize("switch", ["CMPC_LOWRANK", "CMPC_MUTAN_EPILOGUE", "CMPC_WGRAD_OVERLAP"])
+def test_alternative_paths_agree(case, switch, monkeypatch):
+    """The A/B switches read by cmpc_create select paths that are also the fall-backs of other configurations (the graph's T-deep
+    products through gemm_nt when T > 24 / C > 1024, the Mutan tanh inside mutan_fwd, the dW launches after the text encoder): on the
+    same f16 inputs they agree with the default path to rounding (every tap, the loss, a gradient per stage)."""
+    def run():
+        m = _model(case, "f16")
+        o = m.loss_and_grads([f.to(m.device) for f in case["feats"]], case["words"], case["tgt"], case["sl"])
+        torch.cuda.synchronize()
+        taps = {k: v.float().cpu().clone() for k, v in U.product_taps_as_oracle(o, case["cfg"]).items()}
+        return taps, float(o["loss_all"]), {k: v.cpu().clone() for k, v in m.store.grad_dict().items()}
+    ta, la, ga = run()
+    monkeypatch.setenv(switch, "0")
+    tb, lb, gb = run()
+    for k in ta:
+        assert U.rel_err(tb[k], ta[k]) < 3e-3, (switch, k)
+    assert abs(la - lb) <= 2e-3 * abs(la)
+    for n in ("text_objseg/gconv_update_spa_graph_c4/DW", "text_objseg/vis_trans_c4_head3/DW", "text_objseg/c3_lateral/DW", "text_objseg/rnn/lstm_cell/kernel"):
+        assert U.rel_err(gb[n], ga[n]) < 3e-2, (switch, n)
+
+
 def test_train_steps_match_tf_adam(case):
     """Four full train steps (backbone included; its last passes replay the captured backbone graph): parameters after
     TF-Adam with poly LR, L2 on DW and x2 on biases."""
