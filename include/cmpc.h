@@ -388,6 +388,15 @@ int cmpc_kernel_timing_read(cmpc_handle h, double* ms, double* flops, double* by
 /* number of kernel launches / memsets the last forward+backward+optimizer_step issued (host-side counter) */
 int cmpc_launch_count(cmpc_handle h, int64_t* n);
 
+/* ---- Dense CRF post-processing of the evaluation script (test.py:309-322: pydensecrf DenseCRF2D(W, H, 2), unary -log(1-p) / -log(p),
+ *      addPairwiseGaussian(sxy, compat), addPairwiseBilateral(sxy, srgb, rgbim, compat), inference(iters), argmax).  sigm [H*W] fp32
+ *      probabilities and rgb [H*W*3] uint8 are device pointers; q_out [2][H*W] fp32 (label 0, label 1) and / or mask_out [H*W] uint8
+ *      receive the result.  The Gaussian kernels are evaluated exactly inside a 4-sigma window where the library filters through a
+ *      permutohedral lattice: same recursion and normalisation, parity-unpinned against the library (not installed, not in the
+ *      reference tree) ------------------------------------------------------------------------------------------------------ */
+int cmpc_dense_crf(const float* sigm, const unsigned char* rgb, int H, int W, float sxy_g, float compat_g, float sxy_b, float srgb,
+                   float compat_b, int iters, float* q_out, unsigned char* mask_out, void* stream);
+
 /* Host utility (no GPU): CRC-32C of `n` bytes, continuing from `crc` (0 to start) -- the checksum of TensorFlow's tensor-bundle
  * checkpoints (trainval_model.py:46-63 restores / saves them; cmpc-refseg_amd/tf_bundle.py reads and writes the format). */
 uint32_t cmpc_crc32c(uint32_t crc, const void* data, size_t n);
