@@ -14,5 +14,7 @@ python scripts/summarize_profile.py $O/stats $O/r02_bench_b8_f16_kernel_stats.cs
 python scripts/pmc_traffic.py $O/fetch $O/write gemm_nt_v $O/r02_gemm_nt_traffic.json
 python scripts/pmc_mfma.py $O/mfma $O/r02_mfma_busy.txt
 timeout -k 10 300 python scripts/phase_timeline.py > $O/r02_phase_timeline.txt 2>/dev/null
+# phase trace of the 256 x 256 gemm_nt kernel (needs build/libcmpc_trace.so: scripts/build_trace_lib.sh, run before gpurun)
+if [ -f build/libcmpc_trace.so ]; then (export CMPC_LIB_PATH=$PWD/build/libcmpc_trace.so; for s in "12800 1024 1024" "12800 5120 1088" "12800 1024 5120"; do timeout -k 10 100 python scripts/v5_trace.py $s; done) > $O/r02_gemm_nt_v5_phase_trace.txt 2>/dev/null; fi
 rm -rf $O/stats $O/fetch $O/write $O/mfma
 ls -la $O
