@@ -119,6 +119,7 @@ _PP = C.POINTER(C.c_void_p)
 
 # name -> argtypes (return type is always int).  Must list every symbol include/cmpc.h declares.
 SIGNATURES = {
+    "cmpc_gemm_nt_pair": [_P, _P, _P],
     "cmpc_gemm_nt": [C.POINTER(GemmNtArgs), _P],
     "cmpc_gemm_tn": [C.POINTER(GemmTnArgs), _P],
     "cmpc_gemm_tn_grouped": [C.POINTER(GemmTnArgs), C.c_int, _P],

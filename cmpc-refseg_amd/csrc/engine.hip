@@ -605,6 +605,18 @@ inline int valid_extent(const E* e, int x) {
     return x;
 }
 
+cmpc_gemm_nt_args nt_args(int dt, std::initializer_list<Seg> segs, void* C, int ldc, int M, int N, const GemmOpt& o) {
+    cmpc_gemm_nt_args a; memset(&a, 0, sizeof(a));
+    a.dtype = dt; a.nseg = (int)segs.size();
+    int i = 0;
+    for (const Seg& s : segs) { a.A[i] = s.A; a.lda[i] = s.lda; a.Bt[i] = s.Bt; a.ldb[i] = s.ldb; a.K[i] = s.K; a.sA[i] = s.sA; a.sB[i] = s.sB; ++i; }
+    a.C = C; a.ldc = ldc; a.sC = o.sC; a.c_f32 = o.c_f32;
+    a.M = M; a.N = N; a.n_valid = o.n_valid < 0 ? N : o.n_valid; a.batch = o.batch;
+    a.bias = o.bias; a.sbias = o.sbias; a.ld_sbias = o.ld_sbias; a.pbias = o.pbias; a.ld_pbias = o.ld_pbias;
+    a.rows_per_sample = o.rows_per_sample; a.act = o.act; a.alpha = o.alpha; a.accumulate = o.accumulate;
+    return a;
+}
+
 int gemm_nt(hipStream_t st, int dt, std::initializer_list<Seg> segs, void* C, int ldc, int M, int N, const GemmOpt& o = GemmOpt()) {
     E* te = t_cur;
     if (te && te->timing && dt != DT_F32 && N >= 128 && M >= 512) {        // the launches that dispatch to the 16-bit MFMA pipelines
@@ -624,15 +636,34 @@ int gemm_nt(hipStream_t st, int dt, std::initializer_list<Seg> segs, void* C, in
         te->tbytes.push_back(2.0 * (rows * (kalg + nv) + nv * kalg));        // A and C once per row, the weight once (bf16)
         return rc;
     }
-    cmpc_gemm_nt_args a; memset(&a, 0, sizeof(a));
-    a.dtype = dt; a.nseg = (int)segs.size();
-    int i = 0;
-    for (const Seg& s : segs) { a.A[i] = s.A; a.lda[i] = s.lda; a.Bt[i] = s.Bt; a.ldb[i] = s.ldb; a.K[i] = s.K; a.sA[i] = s.sA; a.sB[i] = s.sB; ++i; }
-    a.C = C; a.ldc = ldc; a.sC = o.sC; a.c_f32 = o.c_f32;
-    a.M = M; a.N = N; a.n_valid = o.n_valid < 0 ? N : o.n_valid; a.batch = o.batch;
-    a.bias = o.bias; a.sbias = o.sbias; a.ld_sbias = o.ld_sbias; a.pbias = o.pbias; a.ld_pbias = o.ld_pbias;
-    a.rows_per_sample = o.rows_per_sample; a.act = o.act; a.alpha = o.alpha; a.accumulate = o.accumulate;
+    const cmpc_gemm_nt_args a = nt_args(dt, segs, C, ldc, M, N, o);
     return cmpc_gemm_nt(&a, st);
+}
+
+// two independent single-segment products of one shape in one launch (cmpc_gemm_nt_pair); the timing hook books them as one launch
+struct NtJob { Seg seg; void* C; int ldc; GemmOpt o; };
+int gemm_nt_pair(hipStream_t st, int dt, const NtJob& x, const NtJob& y, int M, int N) {
+    E* te = t_cur;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    const bool timed = te && te->timing && dt != DT_F32 && N >= 128 && M >= 512;
+    if (timed) {
+        if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) { cmpc_set_error("timing: hipEventCreate"); return CMPC_EHIP; }
+        (void)hipEventRecord(e0, st);
+    }
+    const cmpc_gemm_nt_args a = nt_args(dt, {x.seg}, x.C, x.ldc, M, N, x.o), b = nt_args(dt, {y.seg}, y.C, y.ldc, M, N, y.o);
+    const int rc = cmpc_gemm_nt_pair(&a, &b, st);
+    if (timed) {
+        (void)hipEventRecord(e1, st);
+        double fl = 0, by = 0;
+        for (const NtJob* j : {&x, &y}) {
+            const double kalg = valid_extent(te, j->seg.K), nv = valid_extent(te, j->o.n_valid < 0 ? N : j->o.n_valid), rows = (double)M;
+            fl += 2.0 * rows * nv * kalg; by += 2.0 * (rows * (kalg + nv) + nv * kalg);
+        }
+        te->tev.push_back(e0); te->tev.push_back(e1);
+        te->tshape.push_back({2 * M, N, x.seg.K, 1});
+        te->tflops.push_back(fl); te->tbytes.push_back(by);
+    }
+    return rc;
 }
 
 struct TnOpt { int nb2 = 1; int64_t a_bs = 0, d_bs = 0, o_bs = 0; float alpha = 1.f; bool defer = false; };
@@ -985,12 +1016,14 @@ int exchange_fwd(E* e, hipStream_t st, int xi, const void* feat, const void* f1,
     CK(gemm_nt(st, DT_F32, {{X.pooled, Mp, opp(e, gvk), ldk, Mp}, {e->nec, Cp, opp(e, gvk, 0, Mp), ldk, Cp}}, X.gvpre, Mp, B, Mp, g));
     CK(cmpc_l2norm_all_fwd(X.gvpre, X.gv, X.rs1, B * Mp, st));
     const void* fx[2] = {f1, f2}; const char* fn[2] = {"f1", "f2"};
+    NtJob tj[2];
     for (int i = 0; i < 2; ++i) {
         GemmOpt a; a.n_valid = M; a.bias = pptr(e, fmt("lang_feat_%s_%s/biases", lv, fn[i])); a.act = ACT_SIGMOID;
         CK(gemm_nt(st, DT_F32, {{X.gv, Mp, opp(e, fmt("lfeat_%s_%s.t", lv, fn[i])), Mp, Mp}}, X.g[i], Mp, B, Mp, a));
         GemmOpt b; b.n_valid = M; b.bias = pptr(e, fmt("trans_feat_%s_%s/biases", lv, fn[i])); b.act = ACT_RELU;
-        CK(gemm_nt(st, dt, {{fx[i], Mp, opp(e, fmt("tfeat_%s_%s.t", lv, fn[i])), Mp, Mp}}, X.r[i], Mp, R, Mp, b));
+        tj[i] = NtJob{Seg{fx[i], Mp, opp(e, fmt("tfeat_%s_%s.t", lv, fn[i])), Mp, Mp}, X.r[i], Mp, b};
     }
+    CK(gemm_nt_pair(st, dt, tj[0], tj[1], R, Mp));         // the two trans_feat 1x1 convs: one launch
     return cmpc_exchange_combine_fwd(dt, feat, X.r[0], X.r[1], X.g[0], X.g[1], Mp, X.out, X.rstd, B, N, Mp, M, st);
 }
 // outputs: X.dfeat, X.dfs[0] (d f1), X.dfs[1] (d f2), X.dnec
@@ -1002,11 +1035,13 @@ int exchange_bwd(E* e, hipStream_t st, int xi, const void* dout, const void* fea
     CK(cmpc_exchange_combine_bwd(dt, dout, X.out, X.rstd, X.r[0], X.r[1], X.g[0], X.g[1], Mp, X.dfeat, 0, X.dp[0], X.dp[1], X.dg[0], X.dg[1],
                                  B, N, Mp, M, st));
     const void* fx[2] = {f1, f2}; const char* fn[2] = {"f1", "f2"};
+    NtJob dj[2];
     for (int i = 0; i < 2; ++i) {
         CK(colsum(st, dt, X.dp[i], R, Mp, Mp, M, gptr(e, fmt("trans_feat_%s_%s/biases", lv, fn[i]))));
         CK(gemm_tn(e, st, dt, fx[i], Mp, Mp, X.dp[i], Mp, Mp, gptr(e, fmt("trans_feat_%s_%s/DW", lv, fn[i])), M, R, M, M, OFF0, d));
         GemmOpt o; o.n_valid = M;
-        CK(gemm_nt(st, dt, {{X.dp[i], Mp, opp(e, fmt("tfeat_%s_%s.n", lv, fn[i])), Mp, Mp}}, X.dfs[i], Mp, R, Mp, o));
+        dj[i] = NtJob{Seg{X.dp[i], Mp, opp(e, fmt("tfeat_%s_%s.n", lv, fn[i])), Mp, Mp}, X.dfs[i], Mp, o};
+        if (i == 1) CK(gemm_nt_pair(st, dt, dj[0], dj[1], R, Mp));       // d f1 and d f2: one launch
         CK(colsum(st, DT_F32, X.dg[i], B, Mp, Mp, M, gptr(e, fmt("lang_feat_%s_%s/biases", lv, fn[i])), X.g[i], X.dg[i], ACT_SIGMOID));
         CK(gemm_tn(e, st, DT_F32, X.gv, Mp, Mp, X.dg[i], Mp, Mp, gptr(e, fmt("lang_feat_%s_%s/DW", lv, fn[i])), M, B, M, M, OFF0, d));
         GemmOpt a; a.n_valid = M; a.accumulate = i == 1;

@@ -294,8 +294,9 @@ __device__ __forceinline__ void glds16s(const void* sbase, uint32_t voff, uint32
 //  * the last k-tile peeled out of the loop (see the loop);
 //  * v2's epilogue (a register-direct epilogue with 8-byte stores was measured slower: 7.3 vs 5.5 us per tile).
 // ------------------------------------------------------------------------------------------
+// blk / nwg: this workgroup's index among the nwg workgroups of product p (a paired launch runs two products in one grid)
 template <typename T, int BM>
-__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void gemm_nt_v4_kernel(const cmpc_gemm_nt_args p) {
+__device__ __forceinline__ void gemm_nt_v4_body(const cmpc_gemm_nt_args& p, const int blk, const int nwg) {
     constexpr int BN = 128;
     constexpr int EPC = 16 / (int)sizeof(T);
     constexpr int BK = BKB / (int)sizeof(T);
@@ -309,8 +310,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wid / WAVES_N, wn = wid % WAVES_N;
-    const int gx = (p.N + BN - 1) / BN, nwg = gridDim.x;
-    const int xq = nwg >> 3, xr = nwg & 7, xcd = blockIdx.x & 7, xi = blockIdx.x >> 3;
+    const int gx = (p.N + BN - 1) / BN;
+    const int xq = nwg >> 3, xr = nwg & 7, xcd = blk & 7, xi = blk >> 3;
     const int tix = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + xi;
     const int m0 = (tix / gx) * BM, n0 = (tix % gx) * BN;
     const long bz = blockIdx.z;
@@ -443,6 +444,21 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_wave_barrier();
     gemm_nt_epilogue<T, WR, WC>(p, slab, lane, m0 + wm * WR, n0 + wn * WC, bz);
+}
+
+template <typename T, int BM>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void gemm_nt_v4_kernel(const cmpc_gemm_nt_args p) {
+    gemm_nt_v4_body<T, BM>(p, blockIdx.x, gridDim.x);
+}
+// Two independent products of the same tile configuration in ONE grid (the two gated branches of an exchange module, forward and
+// backward: 2 x 200 workgroups of a 12 800 x 512 product fill the chip where one leaves a fifth of it idle).  na % 8 == 0, so that
+// both halves keep the XCD-aware tile order.
+struct NtPair { cmpc_gemm_nt_args a, b; int na; };
+template <typename T, int BM>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void gemm_nt_v4_pair_kernel(const NtPair pp) {
+    const bool first = (int)blockIdx.x < pp.na;
+    const cmpc_gemm_nt_args& p = first ? pp.a : pp.b;
+    gemm_nt_v4_body<T, BM>(p, first ? blockIdx.x : blockIdx.x - pp.na, first ? pp.na : gridDim.x - pp.na);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1274,6 +1290,54 @@ extern "C" int cmpc_debug_v5_trace(unsigned long long* out, int n_words) {
     return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_v5_trace), sizeof(unsigned long long) * n_words) == hipSuccess ? 0 : -1;
 }
 #endif
+
+static int nt_validate(const cmpc_gemm_nt_args* a) {
+    if (!a || a->nseg < 1 || a->nseg > 3 || a->M <= 0 || a->N <= 0 || a->batch <= 0) { cmpc_set_error("gemm_nt: bad args"); return CMPC_EINVAL; }
+    if (a->dtype != DT_F32 && a->dtype != DT_BF16 && a->dtype != DT_F16) { cmpc_set_error("gemm_nt: bad dtype"); return CMPC_EINVAL; }
+    const int esz = a->dtype == DT_F32 ? 4 : 2;
+    const int bk = BKB / esz;
+    for (int s = 0; s < a->nseg; ++s) {
+        if (a->K[s] <= 0 || a->K[s] % bk || (a->lda[s] * esz) % 16 || (a->ldb[s] * esz) % 16 || !a->A[s] || !a->Bt[s]) {
+            cmpc_set_error("gemm_nt: segment %d: K=%d must be a multiple of %d and rows 16-B aligned", s, a->K[s], bk);
+            return CMPC_EINVAL;
+        }
+    }
+    if (a->N % 4 || a->ldc % 4 || !a->C) { cmpc_set_error("gemm_nt: N/ldc must be multiples of 4"); return CMPC_EINVAL; }
+    return CMPC_OK;
+}
+
+// does this product dispatch to the 256 x 128 fragment-double-buffered pipeline (the one a paired launch exists for)?
+static bool nt_is_v4_256(const cmpc_gemm_nt_args* a) {
+    if (a->dtype == DT_F32 || !(a->N >= 128 && a->M >= 512) || a->batch != 1) return false;
+    int ktot = 0; bool off32 = true;
+    for (int s = 0; s < a->nseg; ++s) { ktot += a->K[s]; off32 = off32 && ((long)a->M * a->lda[s] * 2 < (1L << 32)) && ((long)a->N * a->ldb[s] * 2 < (1L << 32)); }
+    if (a->N >= 1024 && a->M >= 2048 && off32) return false;                                  // v5
+    const bool big = (long)((a->M + 255) / 256) * ((a->N + 127) / 128) * a->batch >= 192;
+    return big && (ktot < 2048 || (ktot < 4096 && a->N >= 1024));
+}
+
+extern "C" int cmpc_gemm_nt_pair(const cmpc_gemm_nt_args* a, const cmpc_gemm_nt_args* b, void* stream) {
+    int rc = nt_validate(a); if (rc != CMPC_OK) return rc;
+    rc = nt_validate(b); if (rc != CMPC_OK) return rc;
+    const int na = a ? ((a->M + 255) / 256) * ((a->N + 127) / 128) : 0;
+    if (a->dtype == b->dtype && nt_is_v4_256(a) && nt_is_v4_256(b) && na % 8 == 0) {
+        const int nb = ((b->M + 255) / 256) * ((b->N + 127) / 128);
+        constexpr int LDS = 3 * (256 + 128) * BKB;
+        NtPair pp; pp.a = *a; pp.b = *b; pp.na = na;
+        if (a->dtype == DT_BF16) {
+            static const bool attr = ((void)hipFuncSetAttribute((const void*)gemm_nt_v4_pair_kernel<bf16_t, 256>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS), true);
+            (void)attr;
+            hipLaunchKernelGGL((gemm_nt_v4_pair_kernel<bf16_t, 256>), dim3(na + nb), dim3(512), LDS, (hipStream_t)stream, pp);
+        } else {
+            static const bool attr = ((void)hipFuncSetAttribute((const void*)gemm_nt_v4_pair_kernel<f16_t, 256>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS), true);
+            (void)attr;
+            hipLaunchKernelGGL((gemm_nt_v4_pair_kernel<f16_t, 256>), dim3(na + nb), dim3(512), LDS, (hipStream_t)stream, pp);
+        }
+        return cmpc_check_launch("gemm_nt(pair)");
+    }
+    rc = cmpc_gemm_nt(a, stream);              // any other combination: two launches
+    return rc != CMPC_OK ? rc : cmpc_gemm_nt(b, stream);
+}
 
 extern "C" int cmpc_gemm_nt(const cmpc_gemm_nt_args* a, void* stream) {
     if (!a || a->nseg < 1 || a->nseg > 3 || a->M <= 0 || a->N <= 0 || a->batch <= 0) {

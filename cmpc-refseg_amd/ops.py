@@ -75,6 +75,25 @@ def gemm_nt(dt, segs: Sequence[Tuple], C, ldc, M, N, n_valid=None, batch=1, sC=0
     _lib.call("cmpc_gemm_nt", ctypes.byref(a), _st())
 
 
+def _nt_args(dt, segs, C, ldc, M, N, n_valid=None, bias=None, act=ACT_NONE, alpha=1.0, accumulate=False):
+    a = GemmNtArgs()
+    a.dtype, a.nseg = dt, len(segs)
+    for i, s in enumerate(segs):
+        A, lda, Bt, ldb, K = s[:5]
+        a.A[i], a.lda[i], a.Bt[i], a.ldb[i], a.K[i] = _p(A), lda, _p(Bt), ldb, K
+    a.C, a.ldc = _p(C), ldc
+    a.M, a.N, a.n_valid, a.batch = M, N, (N if n_valid is None else n_valid), 1
+    a.bias = _p(bias)
+    a.act, a.alpha, a.accumulate = act, alpha, int(accumulate)
+    return a
+
+
+def gemm_nt_pair(dt, j1, j2, M, N):
+    """Two independent products (dicts: segs, C, ldc, n_valid, bias, act) in one launch where possible: cmpc_gemm_nt_pair."""
+    a, b = (_nt_args(dt, j["segs"], j["C"], j["ldc"], M, N, j.get("n_valid"), j.get("bias"), j.get("act", ACT_NONE)) for j in (j1, j2))
+    _lib.call("cmpc_gemm_nt_pair", ctypes.byref(a), ctypes.byref(b), _st())
+
+
 def lowrank_nn(dt, A, lda, sA, Bk, ldb, sB, C, ldc, sC, M, N, Kv, n_valid=None, batch=1, alpha=1.0, accumulate=False):
     """C[b][m, n] (+)= alpha * sum_{k < Kv} A[b][m, k] Bk[b][k, n] (16-bit storage, Kv <= 24, Bk k-major): cmpc_lowrank_nn."""
     _lib.call("cmpc_lowrank_nn", dt, _p(A), lda, sA, _p(Bk), ldb, sB, _p(C), ldc, sC, M, N, N if n_valid is None else n_valid, Kv, batch,

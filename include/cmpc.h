@@ -49,6 +49,9 @@ typedef struct {
     int accumulate;            /* C += result */
 } cmpc_gemm_nt_args;
 int cmpc_gemm_nt(const cmpc_gemm_nt_args* a, void* stream);
+/* two independent products in one launch when both take the 256 x 128-tile 16-bit pipeline (otherwise: two launches) -- the two gated
+ * branches of a gated_exchange_module (CMPC_model.py:245-259), forward and backward */
+int cmpc_gemm_nt_pair(const cmpc_gemm_nt_args* a, const cmpc_gemm_nt_args* b, void* stream);
 
 typedef struct {
     int dtype;

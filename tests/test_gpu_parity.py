@@ -198,6 +198,22 @@ def test_gemm_nt_pipelines_agree_with_torch(dt, tdt):
         assert U.rel_err(C.float().cpu(), ref.cpu()) < (1e-2 if dt == 1 else 2e-3), (dt, M, N, Ks)
         if nv < N:      # pad columns: the product contributes exact zeros
             assert torch.equal(C[:, nv:], C0[:, nv:])
+        if (M, N) == (12800, 512) and len(Ks) == 1:   # the paired launch (two products, one grid) against two single launches
+            A2 = torch.randn(M, K, device=dev).to(tdt); Bt2 = (0.25 * torch.randn(N, K, device=dev)).to(tdt)
+            outs = []
+            for paired in (True, False):
+                C1 = torch.zeros(M, N, device=dev).to(tdt); C2 = torch.zeros(M, N, device=dev).to(tdt)
+                j1 = dict(segs=[(A[0], K, Bt, K, K)], C=C1, ldc=N, n_valid=nv, bias=bias, act=1)
+                j2 = dict(segs=[(A2, K, Bt2, K, K)], C=C2, ldc=N, n_valid=nv - 4, act=0)
+                if paired:
+                    ops.gemm_nt_pair(dt, j1, j2, M, N)
+                else:
+                    for j in (j1, j2):
+                        ops.gemm_nt(dt, j["segs"], j["C"], N, M, N, n_valid=j["n_valid"], bias=j.get("bias"), act=j["act"])
+                torch.cuda.synchronize()
+                outs.append((C1.clone(), C2.clone()))
+            assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+            assert U.rel_err(outs[0][1].float().cpu(), (A2.float() @ Bt2.float().t()).cpu() * (torch.arange(N) < nv - 4)) < (1e-2 if dt == 1 else 2e-3)
         if N >= 1024:   # the 256 x 256 kernel's fp32-output path (c_f32), batched, with alpha
             nb = 2; Mb = M // nb
             Cf = torch.randn(nb * Mb, N, device=dev); Cf0 = Cf.clone()
