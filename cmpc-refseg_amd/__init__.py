@@ -10,12 +10,12 @@ from .params import HeadCfg, ParamStore, head_param_specs, init_head_params   # 
 
 
 def __getattr__(name):
-    # model / ops import torch.cuda-facing code lazily so that CPU-only tooling can still
+    # model / backbone import torch.cuda-facing code lazily so that CPU-only tooling can still
     # inspect the manifest and the C ABI.
     if name in ("LSTM_model", "get_segmentation_model"):
         from . import model
         return getattr(model, name)
-    if name in ("model", "ops", "backbone", "dist"):
+    if name in ("model", "backbone", "dist", "engine", "checkpoint", "hostutil"):
         import importlib
         return importlib.import_module(f"{__name__}.{name}")
     raise AttributeError(name)

@@ -13,6 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libcmpc_hip.so")
 
 DT_F32, DT_BF16, DT_F16 = 0, 1, 2
+ABI_VERSION = 2          # CMPC_ABI_VERSION of include/cmpc.h this binding was written against
 ACT_NONE, ACT_RELU, ACT_TANH, ACT_SIGMOID = 0, 1, 2, 3
 
 
@@ -169,7 +170,7 @@ SIGNATURES = {
     "cmpc_lang_pool_bwd": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     "cmpc_pack_weights": [_P, _P, _P, _P, _I, _I, _P],
     "cmpc_pack_weights_range": [_P, _P, _P, _P, _P, _I, _I, _I, _P],
-    "cmpc_adam_step": [_P, _P, _P, _P, _P, _I, _F, _F, _F, _F, _F, _P],
+    "cmpc_adam_step": [_P, _P, _P, _P, _P, _I, _F, _F, _F, _F, _F, _P, _P],
     # whole-path entry points (handle = void*)
     "cmpc_default_cfg": [C.POINTER(EngineCfg)],
     "cmpc_create": [C.POINTER(EngineCfg), _PP],
@@ -222,6 +223,9 @@ def load():
     lib.cmpc_last_error.argtypes = []
     lib.cmpc_abi_version.restype = C.c_int
     lib.cmpc_abi_version.argtypes = []
+    if lib.cmpc_abi_version() != ABI_VERSION:
+        raise CmpcError(f"{LIB_PATH} exports ABI version {lib.cmpc_abi_version()}, this binding needs {ABI_VERSION}: rebuild it "
+                        f"(`make -C cmpc-refseg_amd/csrc`)")
     if hasattr(lib, "cmpc_crc32c"):      # host utility (tf_bundle.py falls back to Python without it; older A/B builds lack it)
         lib.cmpc_crc32c.restype = C.c_uint32
         lib.cmpc_crc32c.argtypes = [C.c_uint32, C.c_void_p, C.c_size_t]

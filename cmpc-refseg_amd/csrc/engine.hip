@@ -188,7 +188,7 @@ struct cmpc_engine_s {
     void* de1[3];                   // gradients of the round-1 outputs (c3, c4, c5)
     ClstmStep cl[3]; void* cl_scr; double* cl_bs;
     float *score, *up, *sigm, *loss; int* iu; float *dscore; void* dfused;
-    float* scalars;
+    float* scalars; int* nonfinite;      // nonfinite[b]: gradient elements of bucket b the last optimizer step skipped (inf / nan)
     bool have_target = false;
     const int32_t* seq_len_feed = nullptr; const float* target_feed = nullptr;      // caller-owned feeds the backward pass re-reads
     hipStream_t last_main = nullptr; long l0 = 0;
@@ -549,9 +549,13 @@ void plan_workspace(E* e, Bump& zf, Bump& zb, Bump& g) {
     e->loss = (float*)zf.take((size_t)B * F); e->iu = (int*)zf.take((size_t)2 * B * 4);
     e->dscore = (float*)g.take((size_t)B * e->h * e->w * F); e->dfused = g.take((size_t)R * Mp * es);
     e->scalars = (float*)g.take(256);
+    e->nonfinite = (int*)zb.take(256);
     e->tn_table_bytes = (size_t)128 << 10;
     for (int a = 0; a < E::NBK; ++a) for (int b = 0; b < 4; ++b) e->tn_table[a][b] = g.take(e->tn_table_bytes);
-    e->fold.cap = (size_t)2048 << 20;                       // partial rows of the deferred folds (~2 MB each, ~110 per step) and the per-part slabs of the split dW reductions
+    // partial rows of the deferred folds (~2 MB each, ~110 per step at B*N = 12800, Cp = 1024) and the per-part slabs of the split dW
+    // reductions: both scale with the rows x widest map of the plan; 2 GiB at the benchmark's sizes, 32 MiB floor for tiny handles.  A
+    // request that does not fit is served from the per-stream scratch and folded at once (cmpc_ws / cmpc_reduce_parts_f32): same bits.
+    e->fold.cap = up256(((size_t)32 << 20) + (size_t)(2147483648.0 * ((double)R * Cp / (12800.0 * 1024.0))));
     e->fold.arena = (char*)g.take(e->fold.cap);
     e->fold.table_cap = 1024;
     for (int a = 0; a < E::NBK; ++a) e->fold_table[a] = (cmpc_fold_desc*)g.take(sizeof(cmpc_fold_desc) * e->fold.table_cap);
@@ -559,6 +563,7 @@ void plan_workspace(E* e, Bump& zf, Bump& zb, Bump& g) {
     tap(e, "fused", e->cl[2].h_new, vd, {R, Mp});
     tap(e, "pred", e->score, 0, {B, e->h, e->w, 1}); tap(e, "up", e->up, 0, {B, H, W, 1}); tap(e, "sigm", e->sigm, 0, {B, H, W, 1});
     tap(e, "iu", e->iu, 3, {2, B}); tap(e, "loss_vec", e->loss, 0, {B}); tap(e, "scalars", e->scalars, 0, {6});
+    tap(e, "grad_nonfinite", e->nonfinite, 3, {E::NBK});
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1183,7 +1188,7 @@ extern "C" int cmpc_default_cfg(cmpc_cfg* c) {
     c->vocab_size = 12112; c->v_emb_dim = 1000; c->mlp_dim = 500; c->rnn_size = 1000; c->glove_dim = 300; c->parse_dim = 500;
     c->start_lr = 0.00025; c->end_lr = 0.00001; c->lr_power = 0.9; c->lr_decay_step = 800000; c->weight_decay = 0.0005f;
     c->loss_w[0] = 0.7f; c->loss_w[1] = c->loss_w[2] = c->loss_w[3] = 0.1f;
-    c->dtype = DT_BF16; c->n_lanes = 3; c->device = 0; c->loss_scale = 0.f;
+    c->dtype = DT_F16; c->n_lanes = 3; c->device = 0; c->loss_scale = 0.f;
     return CMPC_OK;
 }
 
@@ -1718,7 +1723,7 @@ extern "C" int cmpc_optimizer_bucket(cmpc_handle e, int b, float gscale, void* s
     const double lr_t = lr * sqrt(1.0 - pow(b2, t)) / (1.0 - pow(b1, t));
     for (const auto& r : e->bucket_segs[b])
         CK(cmpc_adam_step(e->params, e->grads, e->adam_m, e->adam_v, e->segs_dev + r.first, r.second - r.first, (float)lr_t, (float)b1, (float)b2, 1e-8f,
-                          gscale / e->cfg.loss_scale, st));
+                          gscale / e->cfg.loss_scale, e->nonfinite + b, st));
     for (const auto& r : e->bucket_tiles[b])
         CK(cmpc_pack_weights_range(e->params, e->arena, e->descs_dev, e->tile_prefix_dev, e->tile_desc_dev, e->ndesc, r.first, r.second, st));
     if (b == E::NBK - 1) {                         // the text encoder's bucket is the last to become final: the step is complete

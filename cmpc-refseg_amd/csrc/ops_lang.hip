@@ -318,13 +318,18 @@ __global__ __launch_bounds__(256) void pack_kernel(const float* __restrict__ mas
 }
 
 // tf.train.AdamOptimizer:  m = b1 m + (1-b1) g;  v = b2 v + (1-b2) g^2;  p -= lr_t m / (sqrt(v) + eps)
+// Overflow guard (f16 storage saturates to inf): an element whose gradient is not finite is left untouched -- parameter and both
+// moments -- and counted in *nonfinite, so that one overflowing batch cannot poison the Adam state; the count is surfaced by the handle.
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
-                                                  const cmpc_adam_seg* __restrict__ segs, float lr_t, float b1, float b2, float eps, float gscale) {
+                                                  const cmpc_adam_seg* __restrict__ segs, float lr_t, float b1, float b2, float eps, float gscale,
+                                                  int* __restrict__ nonfinite) {
     const cmpc_adam_seg s = segs[blockIdx.x];
     for (int i = threadIdx.x; i < s.count; i += 256) {
         const long o = s.off + i;
         const float pv = p[o];
-        const float gr = g[o] * gscale * s.gmult + s.wd * pv;
+        const float gin = g[o];
+        if (!(fabsf(gin) <= 3.4028235e38f)) { if (nonfinite) atomicAdd(nonfinite, 1); continue; }      // inf or nan
+        const float gr = gin * gscale * s.gmult + s.wd * pv;
         const float mn = b1 * m[o] + (1.f - b1) * gr;
         const float vn = b2 * v[o] + (1.f - b2) * gr * gr;
         m[o] = mn; v[o] = vn;
@@ -400,8 +405,8 @@ extern "C" int cmpc_pack_weights(const float* master, void* arena, const cmpc_pa
 }
 
 extern "C" int cmpc_adam_step(float* params, const float* grads, float* m, float* v, const cmpc_adam_seg* segs_dev, int nseg,
-                              float lr_t, float beta1, float beta2, float eps, float gscale, void* stream) {
+                              float lr_t, float beta1, float beta2, float eps, float gscale, int* nonfinite, void* stream) {
     if (nseg <= 0) return CMPC_OK;
-    hipLaunchKernelGGL(adam_kernel, dim3(nseg), dim3(256), 0, ST, params, grads, m, v, segs_dev, lr_t, beta1, beta2, eps, gscale);
+    hipLaunchKernelGGL(adam_kernel, dim3(nseg), dim3(256), 0, ST, params, grads, m, v, segs_dev, lr_t, beta1, beta2, eps, gscale, nonfinite);
     return cmpc_check_launch("adam_step");
 }

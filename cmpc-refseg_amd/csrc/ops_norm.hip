@@ -205,7 +205,7 @@ int cmpc_reduce_parts_f32(const float* part, long part_stride, int nouter, int n
                        out, ld_out, out_seg, accumulate);
     return cmpc_check_launch("reduce_parts_f32");
 }
-extern "C" int cmpc_abi_version(void) { return 1; }
+extern "C" int cmpc_abi_version(void) { return CMPC_ABI_VERSION; }
 
 namespace {
 

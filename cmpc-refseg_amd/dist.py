@@ -16,7 +16,7 @@ import torch.distributed as dist
 def init_from_env(backend: str = "nccl", device: torch.device | None = None):
     """RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT come from torch.distributed.run."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or os.environ.get("CMPC_DP_SINGLE")) and not dist.is_initialized():      # CMPC_DP_SINGLE: a group of one rank (tests)
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         kw = {"device_id": device} if (device is not None and backend == "nccl") else {}
@@ -28,17 +28,12 @@ def world_size() -> int:
     return dist.get_world_size() if dist.is_initialized() else 1
 
 
-def allreduce_grads_(flat: torch.Tensor) -> float:
-    """Sum the flat gradient buffer over all ranks in place; returns the scale (1/world) the
-    optimizer must apply."""
-    w = world_size()
-    if w > 1:
-        dist.all_reduce(flat, op=dist.ReduceOp.SUM)
-    return 1.0 / w
+def is_initialized() -> bool:
+    return dist.is_initialized()
 
 
 def broadcast_params_(flat: torch.Tensor, src: int = 0):
-    if world_size() > 1:
+    if dist.is_initialized():
         dist.broadcast(flat, src)
 
 
@@ -47,7 +42,7 @@ def allreduce_bucket_(eng, b: int, ranges, comm_stream: torch.cuda.Stream, max_e
     event cmpc_backward recorded when the bucket became final, then its ranges are all-reduced in chunks of <= max_elems (64 MB) on
     that stream -- while the rest of the backward pass is still running on the compute streams.  The caller orders the bucket's
     optimizer update after `comm_stream`."""
-    if world_size() <= 1:
+    if not dist.is_initialized():
         return
     eng.bucket_wait(b, comm_stream)
     with torch.cuda.stream(comm_stream):

@@ -15,6 +15,7 @@ backbone.py, replayed from a captured HIP graph) runs on a side stream beside th
 from __future__ import annotations
 
 import os
+import warnings
 from typing import Dict, Optional
 
 import numpy as np
@@ -42,7 +43,7 @@ class LSTM_model(object):
                  keep_prob_mlp=1.0, num_rnn_layers=1, optimizer='adam', weight_decay=0.0005, mode='eval',
                  conv5=False, glove_dim=300, emb_name='Gref', emb_dir='data',
                  # --- extensions (not in the reference signature) ---
-                 device="cuda:0", dtype="bf16", c4_dim=1024, c3_dim=512, parse_dim=500,
+                 device="cuda:0", dtype="f16", c4_dim=1024, c3_dim=512, parse_dim=500,
                  backbone_width=64, backbone_blocks=(3, 4, 23, 3), head_params: Optional[Dict] = None,
                  backbone_params: Optional[Dict] = None, seed=1234, n_lanes: Optional[int] = None, **ignored):
         # `ignored` swallows kwargs the reference driver passes but CMPC_model does not accept
@@ -55,6 +56,11 @@ class LSTM_model(object):
             raise NotImplementedError("dropout / stacked LSTM are unused by the reference graph")
         if dtype not in ("bf16", "f16", "f32"):
             raise ValueError("dtype must be 'bf16', 'f16' or 'f32'")
+        if dtype == "bf16":
+            # diagnostic mode: same kernels and rate as f16, but 8-bit significands miss BASELINE's 1e-4 mean-IoU bar on some inputs
+            # (measured up to 1.6e-4).  The default, f16 storage, meets it.
+            warnings.warn("dtype='bf16' is a diagnostic mode: mean-IoU delta vs the fp32 reference path up to 1.6e-4 (bar 1e-4); "
+                          "use the default dtype='f16' (same MFMA rate) for parity", stacklevel=2)
         if not torch.cuda.is_available():
             raise RuntimeError("LSTM_model needs an MI355X (gfx950): the CMPC head has no CPU path")
         _lib.load()
@@ -92,7 +98,7 @@ class LSTM_model(object):
             self.backbone_vars = dict(backbone_params if backbone_params is not None else bb.init_params(backbone_width, backbone_blocks))
             self.backbone.load_tf(self.backbone_vars)
             self.backbone = self.backbone.to(self.device).to(tdt(self.dt)).to(memory_format=torch.channels_last).eval()
-        self.world = 1
+        self.world, self.dp_on = 1, False
         self.last = {}
         self._inflight = []
         self._bb_graph_on = os.environ.get("CMPC_BACKBONE_GRAPH", "1") != "0"
@@ -259,9 +265,9 @@ class LSTM_model(object):
             cur = torch.cuda.current_stream(self.device)
             ost = self.opt_stream if self.opt_stream is not None else cur
             gscale = 1.0 / self.world
-            buckets = self.eng.grad_buckets() if self.world > 1 else None
+            buckets = self.eng.grad_buckets() if self.dp_on else None
             for b in range(self.eng.n_buckets):
-                if self.world > 1:
+                if self.dp_on:
                     dist.allreduce_bucket_(self.eng, b, buckets[b], self.comm_stream)
                     ost.wait_stream(self.comm_stream)
                 with torch.cuda.stream(ost):
@@ -272,6 +278,9 @@ class LSTM_model(object):
         scal = {k: sv[i] for i, k in enumerate(self._SCALARS)}
         scal["mean_IOU"] = scal.pop("mIoU")
         scal["learning_rate"] = lr
+        # int32[n_buckets] device tensor, valid once the step has finished: gradient elements whose update was skipped because they were
+        # inf / nan (f16 storage overflow).  Non-zero = lower cmpc_cfg.loss_scale; the Adam state of those elements is untouched.
+        scal["grad_nonfinite"] = self.eng.tap("grad_nonfinite")
         self.last = scal
         return self.eng.step, scal
 
@@ -296,9 +305,12 @@ class LSTM_model(object):
 
     def enable_data_parallel(self):
         """One process per GPU; rank 0's weights are broadcast; gradients are summed bucket by bucket while the backward pass
-        runs (dist.allreduce_buckets_) and divided by the world size in the Adam kernel."""
+        runs (dist.allreduce_bucket_) and divided by the world size in the Adam kernel.  Active whenever a process group exists -- also a
+        group of ONE rank, so that the RCCL path (collectives on engine-owned hipMalloc memory, issued on the communication stream
+        behind the bucket events) can be exercised on a single GPU."""
         self.world = dist.world_size()
-        if self.world > 1:
+        self.dp_on = dist.is_initialized()
+        if self.dp_on:
             with torch.cuda.device(self.device):
                 torch.cuda.synchronize(self.device)
                 dist.broadcast_params_(self.eng.params, 0)

@@ -389,7 +389,7 @@ class ParamStore:
         b1, b2 = 0.9, 0.999
         lr_t = lr * math.sqrt(1 - b2 ** t) / (1 - b1 ** t)
         _lib.call("cmpc_adam_step", self.params.data_ptr(), self.grads.data_ptr(), self.m.data_ptr(), self.v.data_ptr(),
-                  self.segs_dev.data_ptr(), self.nseg, lr_t, b1, b2, 1e-8, gscale, self._stream())
+                  self.segs_dev.data_ptr(), self.nseg, lr_t, b1, b2, 1e-8, gscale, None, self._stream())
         self.step = t
         if on_stage0 is None:
             self.pack()

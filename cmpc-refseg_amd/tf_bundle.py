@@ -385,3 +385,15 @@ def read_checkpoint_state(directory: str) -> Optional[str]:
             p = line.split(":", 1)[1].strip().strip('"')
             return p if os.path.isabs(p) else os.path.join(directory, p)
     return None
+
+
+def read_checkpoint_state_all(directory: str) -> List[str]:
+    """all_model_checkpoint_paths of the `checkpoint` state file, in the order written (oldest save first); [] without the file."""
+    path = os.path.join(directory, "checkpoint")
+    if not os.path.exists(path):
+        return []
+    out = []
+    for line in open(path):
+        if line.startswith("all_model_checkpoint_paths:"):
+            out.append(line.split(":", 1)[1].strip().strip('"'))
+    return out

@@ -26,6 +26,10 @@ extern "C" {
 #endif
 
 const char* cmpc_last_error(void);
+/* Bumped whenever an exported signature or structure changes incompatibly; a binding must refuse a library whose version differs
+ * (cmpc-refseg_amd/_lib.py does).  2: stat blocks (double[n][CMPC_STAT_PARTS][2]) replace double[B][2] sums, cmpc_mutan_fwd gained
+ * pre_tanh, cmpc_adam_step gained `nonfinite`, cmpc_cfg gained `model` */
+#define CMPC_ABI_VERSION 2
 int cmpc_abi_version(void);
 
 /* ---- GEMMs: every _conv 1x1 (CMPC_model.py:412-417), tf.matmul (:173,187,226,235,362,384,400)
@@ -57,7 +61,7 @@ typedef struct {
     int dtype;
     const void* A; int lda; int Ka;     /* rows of lda elements; Ka = columns READABLE from A + a_off[i] */
     const void* D; int ldd; int Nd;     /* rows of ldd elements; Nd = columns READABLE from D + d_off[i] (block width when d_off selects a column block) */
-    float* out; int ldo;                /* out[k, n] += alpha * sum_r A[r,k] D[r,n]  (fp32 atomics) */
+    float* out; int ldo;                /* out[k, n] += alpha * sum_r A[r,k] D[r,n]  (one writer per element; split reductions go through slabs folded in a fixed order) */
     int R, Kv, Nv;                      /* reduction length, valid output rows / cols */
     int nb; int64_t a_off[8], d_off[8], o_off[8];  /* inner batch: element offsets */
     int nb2; int64_t a_bs, d_bs, o_bs;  /* outer batch: strides */
@@ -194,7 +198,7 @@ int cmpc_convlstm_c(int dt, const void* Yg, const void* c_pre, const cmpc_convls
                     void* c_new, void* h, int B, int N, int ld, int M, void* stream);
 /* backward of C,B,A in three passes.  dYg [R,4*ld] receives d(pre-LN gate inputs = GEMM output);
  * dc_prev the state gradient (untouched when c_prev NULL); LN / peephole gradients accumulate
- * (atomics); scr [R, ld] dt scratch; bsums: scratch stat block of 5*B statistics */
+ * (per-workgroup partial rows folded in a fixed order); scr [R, ld] dt scratch; bsums: scratch stat block of 5*B statistics */
 int cmpc_convlstm_bwd(int dt, const void* dh, const void* dc_new, const void* Yg, const void* c_prev, const void* c_pre,
                       const float* W_ci, const float* W_cf, const float* W_co,
                       const cmpc_convlstm_ln* ln, const double* sums, void* dYg, void* dc_prev,
@@ -262,8 +266,10 @@ int cmpc_pack_weights_range(const float* master, void* arena, const cmpc_pack_de
                             int ndesc, int tile_begin, int tile_end, void* stream);
 
 typedef struct { int64_t off; int count; float wd; float gmult; } cmpc_adam_seg;
+/* Overflow guard: an element whose gradient is inf / nan is left untouched (parameter and both moments) and counted in *nonfinite
+ * (device int, optional) -- f16 storage saturates to inf, and one such batch must not poison the Adam state */
 int cmpc_adam_step(float* params, const float* grads, float* m, float* v, const cmpc_adam_seg* segs_dev, int nseg,
-                   float lr_t, float beta1, float beta2, float eps, float gscale, void* stream);
+                   float lr_t, float beta1, float beta2, float eps, float gscale, int* nonfinite, void* stream);
 
 /* =====================================================================================================
  * Whole-path entry points (SURVEY.md 8b, row "C-ABI"): one handle = one LSTM_model graph
@@ -299,7 +305,7 @@ typedef struct {
     int device;                         /* HIP device ordinal; -1 = planning only (manifest, operand plan, workspace size:
                                            no GPU is touched; every compute entry point then returns CMPC_EINVAL) */
 } cmpc_cfg;
-/* fills *cfg with the reference's defaults (CMPC_model.py:15-40), bf16, 3 lanes, device 0 */
+/* fills *cfg with the reference's defaults (CMPC_model.py:15-40), f16 storage (the 16-bit mode that meets the 1e-4 mean-IoU bar), 3 lanes, device 0 */
 int cmpc_default_cfg(cmpc_cfg* cfg);
 int cmpc_create(const cmpc_cfg* cfg, cmpc_handle* out);
 int cmpc_destroy(cmpc_handle h);

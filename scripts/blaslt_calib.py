@@ -2,7 +2,7 @@
 head's dominant bf16 shapes, next to this library's gemm_nt on the same operands."""
 import importlib, sys, os, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-ops = importlib.import_module("cmpc-refseg_amd.ops")
+ops = importlib.import_module("tests.opwrap")
 importlib.import_module("cmpc-refseg_amd")._lib.load()
 dev = torch.device("cuda:0")
 def t(fn, n=30):

@@ -5,7 +5,7 @@ import torch
 from tests import util as U
 from importlib import import_module
 U.pkg()
-ops = import_module("cmpc-refseg_amd.ops")
+ops = import_module("tests.opwrap")
 dev = torch.device("cuda:0")
 torch.manual_seed(0)
 def bench(fn, n=20):

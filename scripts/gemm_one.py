@@ -5,7 +5,7 @@ import torch
 from tests import util as U
 from importlib import import_module
 U.pkg()
-ops = import_module("cmpc-refseg_amd.ops")
+ops = import_module("tests.opwrap")
 kind, M, N, K = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4])
 reps = int(sys.argv[5]) if len(sys.argv) > 5 else 5
 dev = torch.device("cuda:0")

@@ -5,7 +5,7 @@ import torch
 from tests import util as U
 P = U.pkg()
 from importlib import import_module
-ops = import_module("cmpc-refseg_amd.ops")
+ops = import_module("tests.opwrap")
 dev = torch.device("cuda:0")
 torch.manual_seed(0)
 ok = True

@@ -2,7 +2,7 @@
 Prints per shape: us, TFLOP/s, and the launch-weighted total per step.  usage: python scripts/nt_ab.py [tag]"""
 import importlib, os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-ops = importlib.import_module("cmpc-refseg_amd.ops"); importlib.import_module("cmpc-refseg_amd")._lib.load()
+ops = importlib.import_module("tests.opwrap"); importlib.import_module("cmpc-refseg_amd")._lib.load()
 dev = torch.device("cuda:0")
 torch.manual_seed(0)
 tag = sys.argv[1] if len(sys.argv) > 1 else "cur"

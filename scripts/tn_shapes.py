@@ -3,7 +3,7 @@ With one workgroup per CU and no split, a 64-row step of a 128 x 128 tile takes 
 the Infinity-Cache / HBM ingest rate of a CU (MI355X_MICROARCH.md, gather table), not MFMA (0.25 us) or LDS."""
 import importlib, os, sys, torch
 sys.path.insert(0, "/root/repo")
-ops = importlib.import_module("cmpc-refseg_amd.ops"); importlib.import_module("cmpc-refseg_amd")._lib.load()
+ops = importlib.import_module("tests.opwrap"); importlib.import_module("cmpc-refseg_amd")._lib.load()
 dev = torch.device("cuda:0")
 def t(fn, n=20):
     for _ in range(3): fn()

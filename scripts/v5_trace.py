@@ -3,7 +3,7 @@
 usage: CMPC_LIB_PATH=build/libcmpc_trace.so python scripts/v5_trace.py M N K"""
 import ctypes, importlib, os, sys, numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-ops = importlib.import_module("cmpc-refseg_amd.ops"); lib = importlib.import_module("cmpc-refseg_amd")._lib.load()
+ops = importlib.import_module("tests.opwrap"); lib = importlib.import_module("cmpc-refseg_amd")._lib.load()
 dev = torch.device("cuda:0")
 M, N, K = (int(x) for x in sys.argv[1:4])
 A = torch.randn(M, K, device=dev).half(); Bt = (0.1 * torch.randn(N, K, device=dev)).half(); C = torch.empty(M, N, device=dev, dtype=torch.float16)

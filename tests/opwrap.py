@@ -1,6 +1,6 @@
-"""Op-level launch helpers over the C ABI (include/cmpc.h): thin ctypes wrappers of cmpc_gemm_nt / cmpc_gemm_tn /
-cmpc_cast / cmpc_act_bwd on torch device tensors.  They exist for the kernel-level parity tests and micro-benchmarks
-(tests/test_gpu_parity.py, scripts/gemm_bench.py) and for backbone.py; the product path does not go through them:
+"""TEST / BENCH SCAFFOLDING (not product code): op-level launch helpers over the C ABI (include/cmpc.h) -- thin ctypes wrappers of
+cmpc_gemm_nt / cmpc_gemm_tn / cmpc_cast / cmpc_act_bwd on torch device tensors, for the kernel-level parity tests and the
+micro-benchmarks under scripts/.  The product path does not go through them:
 LSTM_model drives the whole head through ONE handle (cmpc_create / cmpc_forward / cmpc_backward / cmpc_optimizer_step,
 csrc/engine.hip), which chains the stage kernels in C++.
 """
@@ -11,8 +11,11 @@ from typing import List, Optional, Sequence, Tuple
 
 import torch
 
-from . import _lib
-from ._lib import ACT_NONE, DT_BF16, DT_F16, DT_F32, GemmNtArgs, GemmTnArgs
+import importlib
+
+_lib = importlib.import_module("cmpc-refseg_amd")._lib
+ACT_NONE, DT_BF16, DT_F16, DT_F32, GemmNtArgs, GemmTnArgs = (_lib.ACT_NONE, _lib.DT_BF16, _lib.DT_F16, _lib.DT_F32, _lib.GemmNtArgs,
+                                                             _lib.GemmTnArgs)
 
 F32 = DT_F32
 
@@ -155,18 +158,3 @@ def colsum(dt, dy, R, stride, ld, C, db=None, y=None, dpre=None, act=ACT_NONE, d
                   (_p(dpre) + c0 * e) if dpre is not None else None, act, R, stride, w, cv,
                   (_p(db) + 4 * c0) if db is not None else None, (_p(dsb) + 4 * c0) if dsb is not None else None,
                   ld_dsb, rows_per_sample, _st())
-
-
-def spatial_grid_padded(h: int, w: int) -> torch.Tensor:
-    """generate_spatial_batch (util/processing_tools.py:5-17) for one image as an [h*w, 64] fp32 matrix: the 8 coordinate
-    channels [xmin, ymin, xmax, ymax, xctr, yctr, 1/w, 1/h] (computed in float64, stored float32 like the reference's
-    np.float32 array), zero padded to the 64-wide K tile of the GEMMs that consume it."""
-    sp = torch.zeros(h * w, 64, dtype=torch.float32)
-    ys = torch.arange(h, dtype=torch.float64).view(h, 1).expand(h, w)
-    xs = torch.arange(w, dtype=torch.float64).view(1, w).expand(h, w)
-    xmin, xmax = xs / w * 2 - 1, (xs + 1) / w * 2 - 1
-    ymin, ymax = ys / h * 2 - 1, (ys + 1) / h * 2 - 1
-    grid = torch.stack([xmin, ymin, xmax, ymax, (xmin + xmax) / 2, (ymin + ymax) / 2,
-                        torch.full_like(xs, 1 / w), torch.full_like(xs, 1 / h)], -1)
-    sp[:, :8] = grid.reshape(h * w, 8).float()
-    return sp

@@ -38,8 +38,10 @@ def test_library_exports_every_declared_symbol(pkg):
         assert sig is not None, f"{name} missing from the ctypes binding"
         assert len(sig) == nargs, f"{name}: header has {nargs} args, binding {len(sig)}"
     assert set(pkg._lib.SIGNATURES) | set(pkg._lib.COUNTS) <= set(protos)
-    assert lib.cmpc_abi_version() == 1
+    assert lib.cmpc_abi_version() == pkg._lib.ABI_VERSION == 2
     assert isinstance(lib.cmpc_last_error(), bytes)
+    hdr = open(os.path.join(ROOT, "include", "cmpc.h")).read()
+    assert int(re.search(r"#define CMPC_ABI_VERSION (\d+)", hdr).group(1)) == pkg._lib.ABI_VERSION     # the binding refuses any other library
 
 
 def test_bad_arguments_are_rejected_without_a_gpu(pkg):

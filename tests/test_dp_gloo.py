@@ -41,7 +41,8 @@ def _worker(rank, world, port, q):
     _, grads, _ = O.grads_of(hp, feats, words, sl, tgt, cfg)
     gflat = torch.cat([grads[n].reshape(-1) for n in names])
     local = gflat.clone()
-    scale = D.allreduce_grads_(gflat)
+    dist.all_reduce(gflat, op=dist.ReduceOp.SUM)
+    scale = 1.0 / D.world_size()
     assert scale == 1.0 / world
     opt = O.TFAdam(hp)
     off = 0
@@ -103,7 +104,7 @@ def test_product_data_parallel_two_ranks_one_gpu(tmp_path):
     for r in range(2):
         env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(r), WORLD_SIZE="2", LOCAL_RANK="0",
                    HSA_ENABLE_IPC_MODE_LEGACY="0")
-        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "dp_worker.py"), str(tmp_path / f"rank{r}.npz")], env=env, cwd=ROOT))
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "dp_worker.py"), str(tmp_path / f"rank{r}.npz"), "gloo", "tiny_f32"], env=env, cwd=ROOT))
     for p in procs:
         assert p.wait(timeout=600) == 0
     a, b = (np.load(tmp_path / f"rank{r}.npz") for r in range(2))
@@ -136,3 +137,68 @@ def test_product_data_parallel_two_ranks_one_gpu(tmp_path):
             continue          # exact-zero gradient here vs Adam-amplified rounding noise in the oracle
         d = float(np.abs(a[n.replace("/", "|")] - ref.numpy()).max())
         assert d <= 0.35 * lr, (n, d)
+
+
+def _run_workers(tmp_path, world, backend, case, timeout=1200):
+    import subprocess
+    port = _free_port()
+    procs = []
+    for r in range(world):
+        env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(r), WORLD_SIZE=str(world), LOCAL_RANK="0",
+                   HSA_ENABLE_IPC_MODE_LEGACY="0", CMPC_DP_SINGLE="1")
+        out = tmp_path / f"{backend}_{case}_rank{r}.npz"
+        procs.append((subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "dp_worker.py"), str(out), backend, case], env=env, cwd=ROOT), out))
+    for p, _ in procs:
+        assert p.wait(timeout=timeout) == 0
+    import numpy as np
+    return [np.load(o) for _, o in procs]
+
+
+@pytest.mark.gpu
+def test_rccl_world_of_one_equals_no_process_group(tmp_path):
+    """RCCL readiness that one GPU can prove: a `nccl` (= RCCL) process group of ONE rank in a fresh child process, enable_data_parallel()
+    + 3 train steps with every gradient bucket all-reduced IN PLACE on the engine-owned hipMalloc buffer (views through
+    __cuda_array_interface__), on the communication stream, behind cmpc_grad_bucket_wait -- the memory, stream and event pattern RCCL
+    meets at N = 8.  Parameters and losses must equal the run without any process group bit for bit (sum over one rank, gscale = 1).
+    Scaling itself stays UNMEASURED until an 8-GPU record exists."""
+    import numpy as np
+    (a,) = _run_workers(tmp_path, 1, "nccl", "tiny_f32")
+    (b,) = _run_workers(tmp_path, 1, "none", "tiny_f32")
+    assert np.array_equal(a["losses"], b["losses"])
+    for k in a.files:
+        assert np.array_equal(a[k], b[k]), k
+    (c,) = _run_workers(tmp_path, 1, "nccl", "full_f16")
+    (d,) = _run_workers(tmp_path, 1, "none", "full_f16")
+    assert np.array_equal(c["losses"], d["losses"]) and np.array_equal(c["params"], d["params"]) and int(c["nonfinite"].sum()) == 0
+
+
+@pytest.mark.gpu
+def test_product_data_parallel_two_ranks_full_size_f16(tmp_path):
+    """The 2-rank product path at BASELINE config 2's per-GPU shard (B = 8, 320x320, L = 20, f16 storage: 304 MB of fp32 gradients in
+    five buckets, chunked all-reduces) -- two processes on the test box's one GPU over gloo.  Replicas end bit-identical; the per-step
+    losses of each rank follow the oracle's emulation (both shards' gradients averaged, TF-Adam) -- step 2 and 3 only match if the
+    exchanged update was the right one."""
+    import numpy as np
+    a, b = _run_workers(tmp_path, 2, "gloo", "full_f16", timeout=1500)
+    assert np.array_equal(a["params"], b["params"]) and int(a["nonfinite"].sum()) == 0 and int(b["nonfinite"].sum()) == 0
+    sys.path.insert(0, ROOT)
+    from tests.util import O
+    from bench import synth_batch
+    torch.set_num_threads(16)
+    cfg = O.Cfg(batch_size=8)
+    hp, bp = O.init_head_params(cfg, seed=100), O.init_backbone_params(cfg)
+    opt = O.TFAdam(hp)
+    shards = []
+    for r in range(2):
+        w, im, sl, tg = map(torch.from_numpy, synth_batch(8, 20, 320, 320, cfg.vocab_size, 40 + r))
+        with torch.no_grad():
+            shards.append((O.backbone_forward(bp, im, cfg), w, sl, tg))
+    for step in range(3):
+        gs = []
+        for r, (feats, w, sl, tg) in enumerate(shards):
+            scal, grads, _ = O.grads_of(hp, feats, w, sl, tg, cfg)
+            gs.append(grads)
+            got = float((a, b)[r]["losses"][step])
+            assert abs(scal["loss_all"] - got) <= 1e-2 * abs(scal["loss_all"]), (step, r, scal["loss_all"], got)
+        with torch.no_grad():
+            opt.step(hp, {n: (gs[0][n] + gs[1][n]) / 2 for n in hp}, O.poly_lr(step, cfg))

@@ -1,8 +1,9 @@
 """GPU parity tests (run on the MI355X box with -m gpu): the HIP path, called through the C ABI,
 against the oracle on identical seeded inputs.  Tolerances: fp32 mode (exact-fp32 MFMA) 2e-5
-relative on every tap and 2e-4 on parameter gradients (fp32 atomics reorder sums); f16 storage 6e-3 and
-bf16 storage 4e-2 on taps; mean-IoU delta <= 1e-4 (BASELINE.json) asserted in fp32 AND f16 mode at B = 2, 4 and 8
-(bf16 storage misses the bar on some inputs: measured up to 1.6e-4, bounded at 3e-4)."""
+relative on every tap and 2e-4 on parameter gradients (fp32 sums in a different, fixed order); f16 storage 6e-3 and
+bf16 storage 4e-2 on taps; mean-IoU delta <= 1e-4 (BASELINE.json) asserted in fp32 AND f16 mode (the shipped default) at B = 2, 4 and 8
+and over 16 seeds at B = 8.  bf16 storage is a DIAGNOSTIC mode (LSTM_model warns): it misses the bar on some inputs (measured up to
+1.6e-4); its delta is printed, never asserted as parity."""
 import importlib
 import os
 
@@ -18,7 +19,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 
 
 def _ops():
-    return importlib.import_module("cmpc-refseg_amd.ops")
+    return importlib.import_module("tests.opwrap")
 
 
 @pytest.fixture(scope="module")
@@ -49,7 +50,7 @@ def _ref_grad(case, n):
 def test_library_is_the_compute_path():
     P = U.pkg()
     assert os.path.exists(P._lib.LIB_PATH)
-    assert P._lib.load().cmpc_abi_version() == 1
+    assert P._lib.load().cmpc_abi_version() == P._lib.ABI_VERSION
 
 
 @pytest.mark.parametrize("dt,tdt,tol", [(0, torch.float32, 5e-6), (1, torch.bfloat16, 2e-2), (2, torch.float16, 3e-3)])
@@ -430,7 +431,7 @@ def test_train_steps_do_not_leak(case):
     """Device memory is flat across train steps: the handle's workspace is static, torch only holds the feeds of the steps
     in flight and the two backbone graphs' buffers (captured during steps 2 and 3)."""
     import gc
-    m = _model(case, "bf16")
+    m = _model(case, "f16")
     used = []
     for step in range(9):
         m.train_step(case["words"], case["im"], case["tgt"], case["sl"])
@@ -486,7 +487,8 @@ def test_full_size_properties():
     """B=2 at the real sizes (320x320, C=1000, M=500, T=20): size-independent invariants of the path."""
     P = U.pkg()
     from bench import synth_batch
-    m = P.LSTM_model(batch_size=2, mode="train", dtype="bf16")
+    m = P.LSTM_model(batch_size=2, mode="train")                                   # the shipped default: f16 storage
+    assert m.dt == P._lib.DT_F16
     w, im, sl, tg = synth_batch(2, 20, 320, 320, m.cfg.vocab_size, 3)
     feats = m.features(torch.from_numpy(im))
     o = m.loss_and_grads(feats, torch.from_numpy(w), torch.from_numpy(tg), torch.from_numpy(sl))
@@ -513,8 +515,8 @@ def test_full_size_properties():
 def test_full_size_mean_iou_delta_vs_oracle():
     """BASELINE.json's parity bar at the benchmark's sizes (320x320, L=20, C=1000, M=500, ResNet-101):
     |mean-IoU(HIP) - mean-IoU(oracle)| <= 1e-4 on identical inputs and weights.  fp32 and f16 storage must meet
-    it; bf16 storage is measured (1.6e-4 on this seed: ~150 of 204,800 mask pixels flip, all with |logit| below the
-    8-bit rounding of the 1000-channel sums) and bounded at 3e-4.  B=2 keeps the CPU oracle to ~15 s."""
+    it; bf16 storage is a diagnostic mode that does NOT (1.6e-4 on this seed: ~150 of 204,800 mask pixels flip, all with |logit|
+    below the 8-bit rounding of the 1000-channel sums): its delta is printed and only sanity-bounded.  B=2 keeps the CPU oracle to ~15 s."""
     from bench import synth_batch
     torch.set_num_threads(16)
     B = 2
@@ -541,7 +543,7 @@ def test_full_size_mean_iou_delta_vs_oracle():
     print("full-size parity:", {k: f"dIoU={v[0]:.2e} flipped_px={v[1]} up_rel_err={v[2]:.2e}" for k, v in res.items()}, "oracle mIoU", float(ref["mIoU"]))
     assert res["f32"][0] <= 1e-4 and res["f32"][2] < 1e-3
     assert res["f16"][0] <= 1e-4 and res["f16"][2] < 5e-3
-    assert res["bf16"][0] <= 3e-4
+    assert res["bf16"][0] < 1e-2 and res["bf16"][2] < 5e-2          # diagnostic mode: sane, not a parity claim (known above the 1e-4 bar here)
 
 
 def test_full_size_gradients_vs_oracle():
@@ -592,7 +594,7 @@ def test_benchmark_configurations_vs_oracle(B, seed):
     """BASELINE.json configs 2 (B=8: what bench.py times) and 1 (B=4) at full size, on bench.py's own synthetic batch:
     the batch matters here -- l2_normalize(gv_lang) couples the samples of a batch (CMPC_model.py:241) and the GEMM dispatch
     switches tile shapes with B.  fp32 mode: `up` within 1e-3 of the oracle and the SAME mean IoU; f16 storage: mean-IoU delta
-    <= 1e-4 (the north_star bar); bf16 storage: reported, bounded at 3e-4.  Plus the size-independent properties, and at B=8 a
+    <= 1e-4 (the north_star bar); bf16 storage (diagnostic mode): reported only.  Plus the size-independent properties, and at B=8 a
     gradient of five stage families against the oracle's (fp32 mode)."""
     from bench import synth_batch
     torch.set_num_threads(16)
@@ -643,4 +645,60 @@ def test_benchmark_configurations_vs_oracle(B, seed):
     print(f"B={B} parity:", {k: f"dIoU={v[0]:.2e} flipped_px={v[1]} up_rel_err={v[2]:.2e}" for k, v in res.items()}, "oracle mIoU", ref_miou)
     assert res["f32"][0] <= 1e-4 and res["f32"][2] < 1e-3
     assert res["f16"][0] <= 1e-4
-    assert res["bf16"][0] <= 3e-4
+    assert res["bf16"][0] < 1e-2                                    # diagnostic mode: reported above, not a parity claim
+
+
+def test_f16_mean_iou_delta_over_16_seeds():
+    """The evidence behind shipping f16 storage as the default: BASELINE config 2 (B=8, 320x320, L=20) on 16 different synthetic
+    batches, each against the oracle's forward on identical inputs and weights -- every one must meet the 1e-4 mean-IoU bar
+    (CMPC_model.py:486-490: mean over the batch of per-image I/U at up > 0); max and mean are printed."""
+    from bench import synth_batch
+    torch.set_num_threads(16)
+    B = 8
+    cfg = O.Cfg(batch_size=B)
+    hp, bp = O.init_head_params(cfg), O.init_backbone_params(cfg)
+    P = U.pkg()
+    m = P.LSTM_model(batch_size=B, mode="train", head_params=hp, backbone_params=bp)
+    assert m.dt == P._lib.DT_F16
+    deltas, flips = [], []
+    for seed in range(100, 116):
+        w, im, sl, tg = map(torch.from_numpy, synth_batch(B, 20, 320, 320, cfg.vocab_size, seed))
+        with torch.no_grad():
+            taps = O.head_forward(hp, O.backbone_forward(bp, im, cfg), w, sl, cfg)
+            ref = float(O.losses(hp, taps, tg, cfg)["mIoU"])
+            o = m.head(m.features(im), w, sl, tg)
+        torch.cuda.synchronize()
+        deltas.append(abs(float(o["mIoU"]) - ref))
+        flips.append(int(((o["up"].float().cpu() > 0) != (taps["up"] > 0)).sum()))
+    print("f16, B=8, 16 seeds: mean-IoU delta max %.2e mean %.2e; flipped mask pixels max %d of %d" %
+          (max(deltas), sum(deltas) / len(deltas), max(flips), B * 320 * 320))
+    assert max(deltas) <= 1e-4, deltas
+
+
+def test_nonfinite_gradient_is_skipped_and_counted(case):
+    """f16 storage saturates to inf; an inf / nan gradient element must not reach the Adam state.  Inject inf and nan into the final
+    gradient buffer between cmpc_backward and the optimizer: those elements keep parameter, m and v bit for bit, every other element is
+    updated as without the injection, and the handle's `grad_nonfinite` tap counts them in the right bucket."""
+    runs = []
+    for inject in (False, True):
+        m = _model(case, "f16")
+        m.loss_and_grads([f.to(m.device) for f in case["feats"]], case["words"], case["tgt"], case["sl"])
+        torch.cuda.synchronize()
+        offs = [m.eng.index["text_objseg/fusion_c5/DW"][0] + 3, m.eng.index["text_objseg/rnn/lstm_cell/kernel"][0] + 17]
+        p0 = m.eng.params.clone()
+        if inject:
+            m.eng.grads[offs[0]] = float("inf")
+            m.eng.grads[offs[1]] = float("nan")
+        m.eng.optimizer_step()
+        torch.cuda.synchronize()
+        runs.append((m.eng.params.clone(), m.eng.m.clone(), m.eng.v.clone(), m.eng.tap("grad_nonfinite").cpu().clone(), p0, offs))
+    (pa, ma, va, na, _, _), (pb, mb, vb, nb, p0, offs) = runs
+    assert int(na.sum()) == 0 and int(nb.sum()) == 2
+    # bucket of fusion_c5 = level c5 (1), of the LSTM kernel = text encoder (4)
+    assert int(nb[1]) == 1 and int(nb[4]) == 1
+    for o in offs:
+        assert pb[o] == p0[o] and mb[o] == 0 and vb[o] == 0                      # untouched
+    keep = torch.ones_like(pa, dtype=torch.bool)
+    keep[offs] = False
+    assert torch.equal(pa[keep], pb[keep]) and torch.equal(ma[keep], mb[keep]) and torch.equal(va[keep], vb[keep])
+    assert torch.isfinite(pb).all() and torch.isfinite(mb).all() and torch.isfinite(vb).all()

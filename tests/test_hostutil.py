@@ -84,15 +84,19 @@ def test_saver_rotation_and_names(tmp_path):
             eng.step = step
             paths.append(sv.save(model, str(tmp_path / "snap")))
         assert [os.path.basename(p) for p in paths] == ["snap-5.npz", "snap-10.npz", "snap-15.npz"]
-        assert sorted(os.listdir(tmp_path)) == ["snap-10.npz", "snap-15.npz"] and CK.latest_checkpoint(str(tmp_path / "snap")).endswith("snap-15.npz")
+        assert sorted(os.listdir(tmp_path)) == ["checkpoint", "snap-10.npz", "snap-15.npz"] and CK.latest_checkpoint(str(tmp_path / "snap")).endswith("snap-15.npz")
         z = np.load(paths[-1], allow_pickle=False)
         keys = {k.replace("|", "/") for k in z.files}
-        assert {"text_objseg/c5_lateral/DW", "text_objseg/c5_lateral/DW/Adam", "text_objseg/c5_lateral/biases/Adam_1", "global_step", "beta1_power",
-                "beta2_power", "conv1/weights", "bn_conv1/gamma"} <= keys
-        assert int(z["global_step"]) == 15 and z["text_objseg|c5_lateral|DW"].shape == (1, 1, 2, 3)
-        assert float(z["beta1_power"]) == pytest.approx(0.9 ** 16, rel=1e-6)
+        assert {"text_objseg/c5_lateral/DW", "text_objseg/text_objseg/c5_lateral/DW/Adam", "text_objseg/text_objseg/c5_lateral/biases/Adam_1",
+                "text_objseg/Variable_1", "text_objseg/beta1_power", "text_objseg/beta2_power", "conv1/weights", "bn_conv1/gamma"} <= keys
+        assert int(z["text_objseg|Variable_1"]) == 15 and z["text_objseg|Variable_1"].dtype == np.int32 and z["text_objseg|c5_lateral|DW"].shape == (1, 1, 2, 3)
+        assert float(z["text_objseg|beta1_power"]) == pytest.approx(0.9 ** 16, rel=1e-6)
+        # save ORDER, not step number, decides rotation and `latest`: a resumed run that reset its step counter
+        eng.step = 3
+        p3 = sv.save(model, str(tmp_path / "snap"))
+        assert sorted(os.listdir(tmp_path)) == ["checkpoint", "snap-15.npz", "snap-3.npz"] and CK.latest_checkpoint(str(tmp_path / "snap")) == p3
         assert np.array_equal(z["text_objseg|c5_lateral|biases"], np.arange(8.0, 11.0, dtype=np.float32))
-        only_bb = CK.Saver(var_filter=CK.is_backbone_var).save(model, str(tmp_path / "bb"), global_step=0)
+        only_bb = CK.Saver(var_filter=CK.is_backbone_var).save(model, str(tmp_path / "bb" / "bb"), global_step=0)
         assert {k.replace("|", "/") for k in np.load(only_bb).files} == {"conv1/weights", "bn_conv1/gamma"}
     finally:
         torch.cuda.synchronize = orig

@@ -33,14 +33,21 @@ def test_oracle_spatial_grid_is_the_references(key):
     assert np.array_equal(NP.spatial_grid(n, h, w).astype(np.float32), ref)
 
 
+@pytest.mark.gpu
 @pytest.mark.parametrize("key", GRIDS)
-def test_product_spatial_grid_is_the_references(key):
-    """ops.spatial_grid_padded is what Ctx.spatial (the K-segment every Mutan / fusion GEMM reads) is built from."""
+def test_engine_spatial_grid_is_the_references(key):
+    """The grid the PRODUCT uses: the K-segment every Mutan / fusion GEMM reads is built inside cmpc_create (csrc/engine.hip) and exposed as
+    cmpc_tap("spatial") -- f32 mode, a handle per fixture size, compared bit for bit with the reference's generate_spatial_batch."""
     n, h, w = _nhw(key)
-    ops = importlib.import_module("cmpc-refseg_amd.ops")
-    sp = ops.spatial_grid_padded(h, w)
-    assert tuple(sp.shape) == (h * w, 64) and torch.all(sp[:, 8:] == 0)
-    assert np.array_equal(sp[:, :8].reshape(h, w, 8).numpy(), G["grid/" + key][0])     # bit-exact
+    P = U.pkg()
+    E = importlib.import_module("cmpc-refseg_amd.engine")
+    cfg = P.HeadCfg(batch_size=n, num_steps=4, vf_h=h, vf_w=w, H=h * 8, W=w * 8, vf_dim=64, c4_dim=64, c3_dim=64, vocab_size=10,
+                    v_emb_dim=16, mlp_dim=8, rnn_size=16, glove_dim=4, parse_dim=4)
+    eng = E.Engine(cfg, P._lib.DT_F32, torch.device("cuda:0"))
+    sp = eng.tap("spatial").cpu()
+    assert tuple(sp.shape) == (n * h * w, 64) and sp.dtype == torch.float32 and torch.all(sp[:, 8:] == 0)
+    assert np.array_equal(sp[:, :8].reshape(n, h, w, 8).numpy(), G["grid/" + key])      # bit-exact, every sample of the batch
+    eng.close()
 
 
 def test_oracle_and_host_metrics_are_the_references():
@@ -75,8 +82,8 @@ def test_product_iu_counters_are_the_references():
     """cmpc_upsample_fwd's intersection / union counters (what LSTM_model reports as mean_IOU) on the reference's
     inputs: with h = H the legacy bilinear resize is the identity, so `up` is the fixture's score map itself."""
     P = U.pkg()
-    ops = importlib.import_module("cmpc-refseg_amd.ops")
     P._lib.load()
+    ops = importlib.import_module("tests.opwrap")
     dev = torch.device("cuda:0")
     up_in, tg = torch.from_numpy(G["batch/up"]).to(dev), torch.from_numpy(G["batch/target"]).to(dev)
     B, H, W, _ = up_in.shape

@@ -127,12 +127,32 @@ def test_saver_writes_and_reads_tensorflow_checkpoints(tmp_path):
         assert CK.latest_checkpoint(str(tmp_path / "snap")) == paths[-1]
         assert TB.read_checkpoint_state(str(tmp_path)) == paths[-1]
         lv = TB.list_variables(paths[-1])
-        assert lv["text_objseg/c5_lateral/DW"] == (np.dtype(np.float32), (1, 1, 2, 3)) and lv["global_step"] == (np.dtype(np.int64), ())
-        assert {"text_objseg/c5_lateral/DW/Adam", "text_objseg/c5_lateral/biases/Adam_1", "beta1_power", "beta2_power", "conv1/weights"} <= set(lv)
+        # the names tf.global_variables() has in the reference graph (checkpoint.py header; parity-unpinned: no TF-written file to compare)
+        assert lv["text_objseg/c5_lateral/DW"] == (np.dtype(np.float32), (1, 1, 2, 3)) and lv["text_objseg/Variable_1"] == (np.dtype(np.int32), ())
+        assert {"text_objseg/text_objseg/c5_lateral/DW/Adam", "text_objseg/text_objseg/c5_lateral/biases/Adam_1", "text_objseg/beta1_power",
+                "text_objseg/beta2_power", "conv1/weights"} <= set(lv)
+        assert not {"global_step", "beta1_power", "text_objseg/c5_lateral/DW/Adam"} & set(lv)
         eng.params, eng.m, eng.v, eng.step = torch.zeros(12), torch.zeros(12), torch.zeros(12), 0
         CK.Saver().restore(model, paths[-1])
         live = torch.tensor([0, 1, 2, 3, 4, 5, 8, 9, 10])                      # the elements the two variables cover
         assert torch.equal(eng.params[live], torch.arange(12.0)[live]) and torch.equal(eng.m[live], torch.ones(9)) and torch.equal(eng.v[live], torch.full((9,), 2.0))
         assert eng.step == 15 and float(eng.params[6]) == 0.0
+        # rounds 1-2 wrote `<var>/Adam`, `global_step`: still accepted on restore
+        old = {"text_objseg/c5_lateral/DW": np.full((1, 1, 2, 3), 7, np.float32), "text_objseg/c5_lateral/biases": np.zeros(3, np.float32),
+               "text_objseg/c5_lateral/DW/Adam": np.full((1, 1, 2, 3), 3, np.float32), "text_objseg/c5_lateral/DW/Adam_1": np.full((1, 1, 2, 3), 4, np.float32),
+               "text_objseg/c5_lateral/biases/Adam": np.zeros(3, np.float32), "text_objseg/c5_lateral/biases/Adam_1": np.zeros(3, np.float32),
+               "global_step": np.asarray(42, np.int64), "conv1/weights": np.zeros((7, 7, 3, 4), np.float32)}
+        CK.restore_variables(model, old)
+        assert eng.step == 42 and float(eng.params[0]) == 7 and float(eng.m[0]) == 3 and float(eng.v[5]) == 4
+        # a weights-only file restores but says so; a file missing a selected variable raises, with or without a filter
+        weights_only = {k: v for k, v in old.items() if "Adam" not in k and k != "global_step"}
+        with pytest.warns(UserWarning, match="weights only"):
+            CK.restore_variables(model, weights_only)
+        with pytest.raises(KeyError):
+            CK.restore_variables(model, {k: v for k, v in old.items() if k != "text_objseg/c5_lateral/biases"})
+        with pytest.raises(KeyError):
+            CK.restore_variables(model, {"bn_conv1/gamma": np.ones(4, np.float32)}, var_filter=CK.is_backbone_var)    # lacks conv1/weights
+        CK.restore_variables(model, {"conv1/weights": np.ones((7, 7, 3, 4), np.float32)}, var_filter=CK.is_backbone_var)
+        assert float(model.backbone_vars["conv1/weights"].sum()) == 7 * 7 * 3 * 4
     finally:
         torch.cuda.synchronize, torch.cuda.device = orig, orig_dev
