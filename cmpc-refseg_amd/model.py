@@ -278,11 +278,14 @@ class LSTM_model(object):
         scal = {k: sv[i] for i, k in enumerate(self._SCALARS)}
         scal["mean_IOU"] = scal.pop("mIoU")
         scal["learning_rate"] = lr
-        # int32[n_buckets] device tensor, valid once the step has finished: gradient elements whose update was skipped because they were
-        # inf / nan (f16 storage overflow).  Non-zero = lower cmpc_cfg.loss_scale; the Adam state of those elements is untouched.
-        scal["grad_nonfinite"] = self.eng.tap("grad_nonfinite")
         self.last = scal
         return self.eng.step, scal
+
+    def grad_nonfinite(self) -> int:
+        """Gradient elements the LAST optimizer step skipped because they were inf / nan (f16 storage overflow; synchronises).  Non-zero =
+        lower the loss scale; parameter and Adam moments of those elements were left untouched (cmpc_adam_step)."""
+        torch.cuda.synchronize(self.device)
+        return int(self.eng.tap("grad_nonfinite").sum())
 
     # ------------------------------------------------------------------------------------------
     def state_dict(self):

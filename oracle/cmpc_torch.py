@@ -254,9 +254,10 @@ def _bn(x, p, name, relu):
     return F.relu(y) if relu else y
 
 
-def backbone_forward(bp: Dict[str, torch.Tensor], im_nhwc: torch.Tensor, cfg: Cfg):
+def backbone_forward(bp: Dict[str, torch.Tensor], im_nhwc: torch.Tensor, cfg: Cfg, extra_taps=()):
     """im [B,H,W,3] (BGR, mean-subtracted) -> (c3, c4, c5) NHWC.
-    Taps res3b3_relu / res4b22_relu / res5c_relu (CMPC_model.py:73-76) = outputs of stages 3/4/5."""
+    Taps res3b3_relu / res4b22_relu / res5c_relu (CMPC_model.py:73-76) = outputs of stages 3/4/5.
+    extra_taps: block names ("2b" = res2b_relu, CMPCv5_BiLSTM_model.py:88) appended to the result in the order given."""
     _, blocks = backbone_layout(cfg)
     x = im_nhwc.permute(0, 3, 1, 2)
     x = _bn(tf_conv2d(x, bp["conv1/weights"], stride=2), bp, "bn_conv1", True)   # model.py:20-21
@@ -276,7 +277,8 @@ def backbone_forward(bp: Dict[str, torch.Tensor], im_nhwc: torch.Tensor, cfg: Cf
         y = _bn(tf_conv2d(y, bp[f"res{p}_branch2c/weights"]), bp, f"bn{p}_branch2c", False)
         x = F.relu(sc + y)
         taps[stage] = x
-    return tuple(taps[s].permute(0, 2, 3, 1).contiguous() for s in (3, 4, 5))
+        taps[p] = x
+    return tuple(taps[s].permute(0, 2, 3, 1).contiguous() for s in (3, 4, 5) + tuple(extra_taps))
 
 
 # ----------------------------------------------------------------------------------------
