@@ -13,6 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libcmpc_hip.so")
 
 DT_F32, DT_BF16, DT_F16 = 0, 1, 2
+MODEL_CMPC, MODEL_V5_BILSTM = 0, 1
 ABI_VERSION = 2          # CMPC_ABI_VERSION of include/cmpc.h this binding was written against
 ACT_NONE, ACT_RELU, ACT_TANH, ACT_SIGMOID = 0, 1, 2, 3
 
@@ -57,6 +58,7 @@ class GemmTnArgs(C.Structure):
         ("nb", C.c_int), ("a_off", C.c_int64 * 8), ("d_off", C.c_int64 * 8), ("o_off", C.c_int64 * 8),
         ("nb2", C.c_int), ("a_bs", C.c_int64), ("d_bs", C.c_int64), ("o_bs", C.c_int64),
         ("rsplit", C.c_int), ("alpha", C.c_float), ("zeros", C.c_void_p),
+        ("conv_H", C.c_int), ("conv_W", C.c_int), ("conv_dy", C.c_int), ("conv_dx", C.c_int),
     ]
 
 
@@ -101,13 +103,15 @@ class EngineCfg(C.Structure):
         ("start_lr", C.c_double), ("end_lr", C.c_double), ("lr_power", C.c_double), ("lr_decay_step", C.c_int),
         ("weight_decay", C.c_float), ("loss_w", C.c_float * 4),
         ("dtype", C.c_int), ("loss_scale", C.c_float), ("n_lanes", C.c_int), ("device", C.c_int),
+        ("model", C.c_int), ("hsv", C.c_int), ("bn_train", C.c_int), ("bn_decay", C.c_float),
+        ("c2_dim", C.c_int), ("c2_h", C.c_int), ("c2_w", C.c_int), ("aspp_depth", C.c_int), ("low_dim", C.c_int), ("aspp_rates", C.c_int * 3),
     ]
 
 
 class Feeds(C.Structure):
     """cmpc_feeds"""
     _fields_ = [("words", C.c_void_p), ("seq_len", C.c_void_p), ("c3", C.c_void_p), ("c4", C.c_void_p), ("c5", C.c_void_p),
-                ("target_fine", C.c_void_p), ("feats_ready", C.c_void_p)]
+                ("target_fine", C.c_void_p), ("feats_ready", C.c_void_p), ("c2", C.c_void_p), ("im", C.c_void_p)]
 
 
 class Fetches(C.Structure):
@@ -138,7 +142,7 @@ SIGNATURES = {
     "cmpc_lowrank_nn": [_I, _P, _I, _L, _P, _I, _L, _P, _I, _L, _I, _I, _I, _I, _I, _F, _I, _P],
     "cmpc_mutan_fwd": [_I, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     "cmpc_mutan_bwd": [_I, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
-    "cmpc_graph_softmax_fwd": [_I, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
+    "cmpc_graph_softmax_fwd": [_I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
     "cmpc_graph_softmax_bwd": [_I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
     "cmpc_gconv_pre_fwd": [_I, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
     "cmpc_gconv_pre_bwd": [_I, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _I, _I, _I, _I, _P],
@@ -168,11 +172,28 @@ SIGNATURES = {
     "cmpc_parse_softmax_bwd": [_P, _P, _P, _P, _I, _I, _P],
     "cmpc_lang_pool_fwd": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     "cmpc_lang_pool_bwd": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
+    "cmpc_bn_stats": [_I, _P, _I, _I, _I, _I, _F, _P, _P, _P],
+    "cmpc_bn_from_moving": [_P, _P, _I, _I, _F, _P, _P],
+    "cmpc_bn_update_moving": [_P, _I, _F, _P, _P, _I, _I, _P],
+    "cmpc_bn_apply_fwd": [_I, _P, _I, _P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _P],
+    "cmpc_bn_bwd": [_I, _P, _I, _P, _I, _P, _I, _P, _I, _P, _P, _I, _P, _P, _P, _I, _I, _I, _P],
+    "cmpc_resize_bilinear_fwd": [_I, _P, _I, _P, _I, _I, _I, _I, _I, _I, _I, _P],
+    "cmpc_resize_bilinear_bwd": [_I, _P, _I, _P, _I, _I, _I, _I, _I, _I, _I, _P],
+    "cmpc_hsv_map": [_I, _P, _P, _I, _I, _I, _I, _I, _I, _P],
+    "cmpc_reverse_sequence": [_P, _P, _P, _I, _I, _I, _P],
+    "cmpc_reverse_words_tb": [_P, _P, _P, _I, _I, _P],
+    "cmpc_rows_nonzero2": [_P, _P, _P, _I, _I, _I, _P],
+    "cmpc_conv_to1_fwd": [_I, _P, _I, _P, _P, _P, _I, _I, _P],
+    "cmpc_conv_to1_bwd": [_I, _P, _P, _I, _P, _P, _P, _P, _I, _I, _P],
     "cmpc_pack_weights": [_P, _P, _P, _P, _I, _I, _P],
     "cmpc_pack_weights_range": [_P, _P, _P, _P, _P, _I, _I, _I, _P],
     "cmpc_adam_step": [_P, _P, _P, _P, _P, _I, _F, _F, _F, _F, _F, _P, _P],
     # whole-path entry points (handle = void*)
     "cmpc_default_cfg": [C.POINTER(EngineCfg)],
+    "cmpc_default_cfg_model": [C.POINTER(EngineCfg), _I, _I],
+    "cmpc_state_info": [_P, _I, C.POINTER(C.c_char_p), C.POINTER(_L)],
+    "cmpc_get_state": [_P, C.c_char_p, _P, _L],
+    "cmpc_set_state": [_P, C.c_char_p, _P, _L],
     "cmpc_create": [C.POINTER(EngineCfg), _PP],
     "cmpc_destroy": [_P],
     "cmpc_get_cfg": [_P, C.POINTER(EngineCfg)],
@@ -202,7 +223,7 @@ SIGNATURES = {
     "cmpc_operand_info": [_P, C.c_char_p, C.POINTER(_L), C.POINTER(_I), C.POINTER(_I), C.POINTER(_I)],
 }
 # entry points that return a count, not a status
-COUNTS = {"cmpc_param_count": [_P], "cmpc_tap_count": [_P], "cmpc_grad_bucket_count": [_P]}
+COUNTS = {"cmpc_param_count": [_P], "cmpc_tap_count": [_P], "cmpc_grad_bucket_count": [_P], "cmpc_state_count": [_P]}
 
 _lib = None
 

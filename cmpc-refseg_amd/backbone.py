@@ -187,6 +187,8 @@ class DeepLabResNet(nn.Module):
             blk.b.load(p, f"res{n}_branch2b", f"bn{n}_branch2b")
             blk.c.load(p, f"res{n}_branch2c", f"bn{n}_branch2c")
 
+    taps_wanted = (3, 4, 5)     # stages (int) or block names ("2b" = res2b_relu, CMPCv5_BiLSTM_model.py:88) returned by forward, in this order
+
     @torch.no_grad()
     def forward(self, im_nhwc):
         x = im_nhwc.permute(0, 3, 1, 2).to(self.stem.weight.dtype).contiguous(memory_format=torch.channels_last)
@@ -195,8 +197,9 @@ class DeepLabResNet(nn.Module):
         pl, pr = _same_pad(x.shape[3], 3, 2, 1)
         x = F.max_pool2d(F.pad(x, (pl, pr, pt, pb), value=float("-inf")), 3, 2)
         taps = {}
-        for blk, (stage, *_r) in zip(self.blocks, self.layout):
+        for blk, (stage, suf, *_r) in zip(self.blocks, self.layout):
             x = blk(x)
             taps[stage] = x
+            taps[f"{stage}{suf}"] = x
         # NCHW(channels_last) -> NHWC views are free: permute gives a contiguous NHWC tensor
-        return tuple(taps[s].permute(0, 2, 3, 1).contiguous() for s in (3, 4, 5))
+        return tuple(taps[s].permute(0, 2, 3, 1).contiguous() for s in self.taps_wanted)

@@ -134,6 +134,7 @@ struct Bump {
 struct LevelBuf {          // one pyramid level (c5 / c4 / c3), forward then backward
     int cin;
     const void* feat;
+    void* X0t;             // model V5_BILSTM: tanh(lateral) before the l2-normalisation (kept for the backward pass)
     void *X0, *P, *X1, *PT, *PTt, *gw_w_t, *gw_v_t, *Zt, *Y, *G, *U, *X2, *F;
     float *lat_rstd, *g, *mut_rstd, *Wd, *PTf, *k0s, *A0, *pr, *gw_w, *gw_v, *gsc, *Ztf, *rrow, *sb;
     double *sums1, *sums2;
@@ -150,6 +151,16 @@ struct ExgBuf {            // one gated_exchange_module
     float *dg[2], *dgv, *dgvpre, *dpooled, *dnec, *dattn, *dlog, *dkq, *dq;
 };
 struct ClstmStep { void *Yg, *c_pre, *c_new, *h_new, *dYg, *dc_prev, *dx, *dh; double* sums; };
+// one direction of the text encoder (CMPC_model: the only one; CMPCv5_BiLSTM: fw and bw)
+struct LstmDir {
+    std::string key, pk, pb;            // operand key ("lstm" / "lstm_fw" / "lstm_bw"), kernel / bias parameter names
+    int* words_tb; float *emb, *xg, *gates, *h_all, *c_all, *outs, *douts, *dh, *dc, *dgt, *demb, *demb_parts;
+};
+// one slim conv2d + batch_norm + relu layer (CMPCv5_BiLSTM_model.py:190-251): the convolution's output, its statistics, the backward scratch
+struct BnLayer {
+    std::string scope; int C, Cpad, R, dt, ldpre;
+    void *pre, *dpre; double* sums; float *mr, *means, *mm, *mv;      // mm / mv: moving statistics (device, inside e->bn_state)
+};
 
 }  // namespace
 
@@ -179,12 +190,23 @@ struct cmpc_engine_s {
     hipEvent_t ev_opt0 = nullptr, ev_opt1 = nullptr; bool opt_pending = false;
     // buffers
     void* spatial = nullptr;
-    int* words_tb; float *emb, *xg, *gates, *h_all, *c_all, *outs, *wf, *wf_rstd, *mask;
-    float *douts, *dh, *dc, *dgt, *demb, *demb_parts;
+    float *wf, *wf_rstd, *mask;
     float *h1, *lg, *parse, *dlg, *dh1;
     float *vl, *vl_rstd, *nec, *nec_rstd, *dparse, *dwf, *dvl, *dnec;
+    // model variant (cfg.model): CMPC_model = 3 levels (c5, c4, c3), 3 exchange modules per round, 3 ConvLSTM steps; CMPCv5_BiLSTM = 2 / 2 / 2
+    bool v5 = false; int nlev = 3, nex = 3, ncl = 3;
+    LstmDir ldir[2]; int ndir = 1;
+    float *outs_bw = nullptr, *douts_bw = nullptr, *wft = nullptr, *dwft = nullptr;     // v5: un-reversed backward outputs / their gradient; tanh(words_feat conv)
+    void* hsv = nullptr;                                               // v5 hsv: [R, 64] map (3 channels)
+    // v5: ASPP + decoder (CMPCv5_BiLSTM_model.py:190-251)
+    int D = 0, Dp = 0, LOW = 0, CATp = 0, C2 = 0, h2 = 0, w2 = 0, R2 = 0;
+    BnLayer bn[9];                  // aspp 1x1, 3x3 x3, image level, concat; decoder low level, 3x3 x2  (bn_scopes order)
+    float* bn_state = nullptr; std::vector<std::pair<std::string, int64_t>> state_specs; std::unordered_map<std::string, int64_t> state_off; int64_t state_total = 0;
+    const void* c2_feed = nullptr; const float* im_feed = nullptr;
+    void *cat4, *enc, *deccat, *net1, *net2, *dcat4, *denc, *ddeccat, *dnet1, *dnet2;
+    float *pooled, *img, *catsb, *dcatsb, *dimg, *dpooled, *ones_n, *zbias, *dpred, *zeros_bt = nullptr;
     LevelBuf lv[3];                 // c5, c4, c3
-    ExgBuf ex[6];                   // c3, c4, c5, c3_2, c4_2, c5_2
+    ExgBuf ex[6];                   // c3, c4, c5, c3_2, c4_2, c5_2  (v5: c4, c5, c4_2, c5_2)
     void* de1[3];                   // gradients of the round-1 outputs (c3, c4, c5)
     ClstmStep cl[3]; void* cl_scr; double* cl_bs;
     float *score, *up, *sigm, *loss; int* iu; float *dscore; void* dfused;
@@ -224,8 +246,17 @@ struct cmpc_engine_s {
 
 namespace {
 typedef cmpc_engine_s E;
-const char* LEVELS[3] = {"c5", "c4", "c3"};
-const char* EXG[6] = {"c3", "c4", "c5", "c3_2", "c4_2", "c5_2"};
+// level / exchange-module names in build order: CMPC_model.py:120-125,271-283; CMPCv5_BiLSTM_model.py:134-137,364-375
+const char* LEVELS_V1[3] = {"c5", "c4", "c3"};
+const char* EXG_V1[6] = {"c3", "c4", "c5", "c3_2", "c4_2", "c5_2"};
+const char* EXG_V5[6] = {"c4", "c5", "c4_2", "c5_2", "", ""};
+inline const char* lvn(const cmpc_engine_s* e, int i) { return LEVELS_V1[i]; }                       // v5 uses the first two
+inline const char* exn(const cmpc_engine_s* e, int i) { return e->v5 ? EXG_V5[i] : EXG_V1[i]; }      // i < 2 * e->nex
+// slim conv2d + BatchNorm scopes in creation order (v5:234-249 then :196-204)
+const char* BN_SCOPES[9] = {"aspp/conv_1x1", "aspp/conv_3x3_1", "aspp/conv_3x3_2", "aspp/conv_3x3_3", "aspp/image_level_features/conv_1x1",
+                            "aspp/conv_1x1_concat", "decoder/low_level_features/conv_1x1", "decoder/upsampling_logits/conv_3x3_1",
+                            "decoder/upsampling_logits/conv_3x3_2"};
+enum { BN_A0 = 0, BN_A1 = 1, BN_A2 = 2, BN_A3 = 3, BN_IMG = 4, BN_CAT = 5, BN_LOW = 6, BN_D1 = 7, BN_D2 = 8 };
 
 std::string fmt(const char* f, ...) {
     char buf[256]; va_list ap; va_start(ap, f); vsnprintf(buf, sizeof(buf), f, ap); va_end(ap); return buf;
@@ -254,15 +285,25 @@ void add_ln(E* e, const std::string& scope, int dim) {
 }
 void build_manifest(E* e) {
     const int C = e->C, M = e->M, R = e->RNN;
+    const int hx = (e->v5 && e->cfg.hsv) ? 3 : 0;
     add_param(e, "Variable", {e->V, e->G}, 0.f, 1.f);
-    add_param(e, "rnn/lstm_cell/kernel", {e->G + R, 4 * R}, 0.f, 1.f);
-    add_param(e, "rnn/lstm_cell/bias", {4 * R}, 0.f, 1.f);
-    add_conv(e, "c5_lateral", 1, e->cfg.vf_dim, C);
-    add_conv(e, "c4_lateral", 1, e->cfg.c4_dim, C);
-    add_conv(e, "c3_lateral", 1, e->cfg.c3_dim, C);
+    if (!e->v5) {
+        add_param(e, "rnn/lstm_cell/kernel", {e->G + R, 4 * R}, 0.f, 1.f);
+        add_param(e, "rnn/lstm_cell/bias", {4 * R}, 0.f, 1.f);
+    } else {                                                                       // BiLSTM(), v5:159-187
+        for (const char* d : {"fw", "bw"}) {
+            add_param(e, fmt("bidirectional_rnn/%s/lstm_cell/kernel", d), {e->G + R, 4 * R}, 0.f, 1.f);
+            add_param(e, fmt("bidirectional_rnn/%s/lstm_cell/bias", d), {4 * R}, 0.f, 1.f);
+        }
+        add_conv(e, "words_feat", 1, 2 * R, R);
+    }
+    add_conv(e, "c5_lateral", 1, e->cfg.vf_dim + hx, C);
+    add_conv(e, "c4_lateral", 1, e->cfg.c4_dim + hx, C);
+    if (!e->v5) add_conv(e, "c3_lateral", 1, e->cfg.c3_dim, C);
     add_conv(e, "words_parse_1", 1, R, e->P);
     add_conv(e, "words_parse_2", 1, e->P, 4);
-    for (const char* lv : LEVELS) {
+    for (int li = 0; li < e->nlev; ++li) {
+        const char* lv = lvn(e, li);
         for (int hd = 1; hd <= 5; ++hd) {
             add_conv(e, fmt("vis_trans_%s_head%d", lv, hd), 1, C + 8, C);
             add_conv(e, fmt("lang_trans_%s_head%d", lv, hd), 1, R, C);
@@ -274,15 +315,18 @@ void build_manifest(E* e) {
         add_ln(e, fmt("gconv_update_ln_spa_graph_%s", lv), C);
         add_conv(e, fmt("fusion_%s", lv), 1, 2 * C + R + 8, M);
     }
-    for (const char* lv : LEVELS) add_conv(e, fmt("score_%s", lv), 3, M, 1);
-    for (const char* x : EXG) {
+    for (int li = 0; li < e->nlev; ++li) add_conv(e, fmt("score_%s", lvn(e, li)), 3, M, 1);
+    for (int xi = 0; xi < 2 * e->nex; ++xi) {
+        const char* x = exn(e, xi);
         add_conv(e, fmt("spa_graph_key_%sgv_f1", x), 1, M, M);
         add_conv(e, fmt("lang_query_%sgv_f1", x), 1, R, M);
         add_conv(e, fmt("gv_lang_%sgv_f1", x), 1, M + R, M);
         add_conv(e, fmt("lang_feat_%s_f1", x), 1, M, M);
         add_conv(e, fmt("trans_feat_%s_f1", x), 1, M, M);
-        add_conv(e, fmt("lang_feat_%s_f2", x), 1, M, M);
-        add_conv(e, fmt("trans_feat_%s_f2", x), 1, M, M);
+        if (!e->v5) {
+            add_conv(e, fmt("lang_feat_%s_f2", x), 1, M, M);
+            add_conv(e, fmt("trans_feat_%s_f2", x), 1, M, M);
+        }
     }
     const std::string pre = "rnn/conv_lstm_cell";
     add_param(e, pre + "/kernel", {1, 1, 2 * M, 4 * M}, 0.f, 1.f);
@@ -294,7 +338,20 @@ void build_manifest(E* e) {
     add_param(e, pre + "/W_co", {e->h, e->w, M}, 0.f, 1.f);
     add_ln(e, pre + "/LayerNorm_3", M);
     add_ln(e, pre + "/LayerNorm_4", M);
-    add_conv(e, "score", 3, M, 1);
+    if (!e->v5) { add_conv(e, "score", 3, M, 1); return; }
+    // atrous_spatial_pyramid_pooling + decoder (v5:190-251): slim conv2d `weights` (in reg_var_list: name ends in 'weights', v5:530) +
+    // BatchNorm beta / gamma; the moving statistics are non-trainable state (cmpc_state_*)
+    const int D = e->D, ksz[9] = {1, 3, 3, 3, 1, 1, 1, 3, 3}, cin[9] = {M, M, M, M, M, 5 * D, e->C2, D + e->LOW, D}, cout[9] = {D, D, D, D, D, D, e->LOW, D, D};
+    for (int i = 0; i < 9; ++i) {
+        add_param(e, std::string(BN_SCOPES[i]) + "/weights", {ksz[i], ksz[i], cin[i], cout[i]}, e->cfg.weight_decay, 1.f);
+        add_ln(e, std::string(BN_SCOPES[i]) + "/BatchNorm", cout[i]);
+        for (const char* sfx : {"moving_mean", "moving_variance"}) {
+            const std::string n = std::string("text_objseg/") + BN_SCOPES[i] + "/BatchNorm/" + sfx;
+            e->state_off[n] = e->state_total; e->state_specs.push_back({n, cout[i]}); e->state_total += (cout[i] + 3) / 4 * 4;
+        }
+    }
+    add_param(e, "decoder/upsampling_logits/conv_1x1/weights", {1, 1, D, 1}, e->cfg.weight_decay, 1.f);      // v5:205
+    add_param(e, "decoder/upsampling_logits/conv_1x1/biases", {1}, 0.f, 2.f);
 }
 
 inline const ParamSpec& spec(const E* e, const std::string& name) { return e->specs[e->pindex.at("text_objseg/" + name)]; }
@@ -315,10 +372,10 @@ Operand& new_operand(E* e, const std::string& key, int dt, int rows, int ld) {
     return e->ops[key] = op;
 }
 void add_desc(E* e, const Operand& op, const std::string& pname, int ld_src, int transpose, int row0, int col0, int rows, int cols,
-              const Segs& ks, const Segs& ns) {
+              const Segs& ks, const Segs& ns, int64_t src_elem_off = 0) {
     const int esz = op.dt == DT_F32 ? 4 : 2;
     cmpc_pack_desc d; memset(&d, 0, sizeof(d));
-    d.src_off = poff(e, pname); d.ld_src = ld_src;
+    d.src_off = poff(e, pname) + src_elem_off; d.ld_src = ld_src;
     d.dst_off = (int64_t)op.off + ((int64_t)row0 * op.ld + col0) * esz;
     d.dst_dt = op.dt; d.transpose = transpose;
     d.rows = rows; d.cols = cols; d.ld_dst = op.ld;
@@ -337,19 +394,42 @@ void linear(E* e, const std::string& key, const std::string& pname, int dt, int 
     if (fwd) { Operand& op = new_operand(e, key + ".t", dt, Np, Kp); add_desc(e, op, pname, ld_src, 1, 0, 0, Np, Kp, ks, ns); }
     if (bwd) { Operand& op = new_operand(e, key + ".n", dt, Kp, Np); add_desc(e, op, pname, ld_src, 0, 0, 0, Kp, Np, ks, ns); }
 }
+// a 3x3 convolution's HWIO weights [3, 3, cin, cout] as implicit-GEMM operands (cmpc_conv_nhwc): '<key>.t' = [Np][9 * Kp], tap-major
+// K (forward); '<key>.n' = [Kp][9 * Np] with the taps REVERSED (the input gradient is the same convolution of dY with the flipped,
+// transposed kernel: dX[p] = sum_t dY[p - off_t] W_t^T, and -off_t = off_{8 - t})
+void conv3(E* e, const std::string& key, const std::string& pname, int dt, int cin, int cout, int Kp, int Np, Segs ks = {}) {
+    if (ks.empty()) ks = {{0, cin, 0}};
+    Operand opt = new_operand(e, key + ".t", dt, Np, 9 * Kp);
+    Operand opn = new_operand(e, key + ".n", dt, Kp, 9 * Np);
+    for (int t = 0; t < 9; ++t) {
+        add_desc(e, opt, pname, cout, 1, 0, t * Kp, Np, Kp, ks, {{0, cout, 0}}, (int64_t)t * cin * cout);
+        add_desc(e, opn, pname, cout, 0, 0, (8 - t) * Np, Kp, Np, ks, {{0, cout, 0}}, (int64_t)t * cin * cout);
+    }
+}
 void plan_operands(E* e) {
     const int C = e->C, M = e->M, R = e->RNN, G = e->G, P = e->P, Cp = e->Cp, Mp = e->Mp, Gp = e->Gp, Pp = e->Pp;
     const int V = e->dt, L = DT_F32;
-    // text LSTM: kernel [G+R, 4R], gates i,j,f,o -> padded gate blocks of Cp
+    // text LSTM(s): kernel [G+R, 4R], gates i,j,f,o -> padded gate blocks of Cp
     Segs gate_ns; for (int g = 0; g < 4; ++g) gate_ns.push_back({g * R, R, g * Cp});
-    linear(e, "lstm", "rnn/lstm_cell/kernel", L, G + R, 4 * R, Gp + Cp, 4 * Cp, true, true, {{0, G, 0}, {G, R, Gp}}, gate_ns);
-    { Operand& ob = new_operand(e, "lstm.b", L, 1, 4 * Cp); add_desc(e, ob, "rnn/lstm_cell/bias", 4 * R, 0, 0, 0, 1, 4 * Cp, {{0, 1, 0}}, gate_ns); }
+    for (int d = 0; d < e->ndir; ++d) {
+        const LstmDir& D = e->ldir[d];
+        linear(e, D.key, D.pk, L, G + R, 4 * R, Gp + Cp, 4 * Cp, true, true, {{0, G, 0}, {G, R, Gp}}, gate_ns);
+        Operand& ob = new_operand(e, D.key + ".b", L, 1, 4 * Cp); add_desc(e, ob, D.pb, 4 * R, 0, 0, 0, 1, 4 * Cp, {{0, 1, 0}}, gate_ns);
+    }
+    if (e->v5) linear(e, "wfeat", "words_feat/DW", L, 2 * R, R, 2 * Cp, Cp, true, true, {{0, R, 0}, {R, R, Cp}});      // [fw | bw] -> R (v5:182)
     linear(e, "parse1", "words_parse_1/DW", L, R, P, Cp, Pp);
     linear(e, "parse2", "words_parse_2/DW", L, P, 4, Pp, 64);
     e->stage0_ndesc = (int)e->descs.size();       // what the text encoder + parser read: packed (and published) first
     const int cins[3] = {e->cfg.vf_dim, e->cfg.c4_dim, e->cfg.c3_dim};
-    for (int i = 0; i < 3; ++i) linear(e, fmt("lat_%s", LEVELS[i]), fmt("%s_lateral/DW", LEVELS[i]), V, cins[i], C, pad64(cins[i]), Cp, true, false);
-    for (const char* lv : LEVELS) {
+    for (int i = 0; i < e->nlev; ++i) {
+        // hsv: the three HSV channels are a K-segment of their own (rows cin .. cin+2 of the weight -> k = pad64(cin) ..), read from e->hsv
+        Segs ks = {{0, cins[i], 0}};
+        const bool hx = e->v5 && e->cfg.hsv;
+        if (hx) ks.push_back({cins[i], 3, pad64(cins[i])});
+        linear(e, fmt("lat_%s", lvn(e, i)), fmt("%s_lateral/DW", lvn(e, i)), V, cins[i] + (hx ? 3 : 0), C, pad64(cins[i]) + (hx ? 64 : 0), Cp, true, false, ks);
+    }
+    for (int li = 0; li < e->nlev; ++li) {
+        const char* lv = lvn(e, li);
         // mutan: five heads side by side; forward operand [5Cp][Cp+64] (k: C visual rows, then the 8 spatial rows)
         Operand opt = new_operand(e, fmt("mutan_%s.t", lv), V, 5 * Cp, Cp + 64);
         Operand opn = new_operand(e, fmt("mutan_%s.n", lv), V, Cp, 5 * Cp);
@@ -373,17 +453,34 @@ void plan_operands(E* e) {
         linear(e, fmt("fus_%s", lv), fus, V, 2 * C + R + 8, M, 2 * Cp + 64, Mp, true, true, {{0, C, 0}, {C, C, Cp}, {2 * C + R, 8, 2 * Cp}});
         linear(e, fmt("fusl_%s", lv), fus, L, R, M, Cp, Mp, true, true, {{2 * C, R, 0}});
     }
-    for (const char* x : EXG) {
+    for (int xi = 0; xi < 2 * e->nex; ++xi) {
+        const char* x = exn(e, xi);
         linear(e, fmt("key_%s", x), fmt("spa_graph_key_%sgv_f1/DW", x), L, M, M, Mp, Mp);
         linear(e, fmt("query_%s", x), fmt("lang_query_%sgv_f1/DW", x), L, R, M, Cp, Mp);
         linear(e, fmt("gv_%s", x), fmt("gv_lang_%sgv_f1/DW", x), L, M + R, M, Mp + Cp, Mp, true, true, {{0, M, 0}, {M, R, Mp}});
         for (const char* f : {"f1", "f2"}) {
+            if (e->v5 && f[1] == '2') continue;
             linear(e, fmt("lfeat_%s_%s", x, f), fmt("lang_feat_%s_%s/DW", x, f), L, M, M, Mp, Mp);
             linear(e, fmt("tfeat_%s_%s", x, f), fmt("trans_feat_%s_%s/DW", x, f), V, M, M, Mp, Mp);
         }
     }
     Segs cl_ns; for (int g = 0; g < 4; ++g) cl_ns.push_back({g * M, M, g * Mp});
     linear(e, "clstm", "rnn/conv_lstm_cell/kernel", V, 2 * M, 4 * M, 2 * Mp, 4 * Mp, true, true, {{0, M, 0}, {M, M, Mp}}, cl_ns);
+    if (!e->v5) return;
+    // ASPP + decoder (v5:190-251)
+    const int D = e->D, Dp = e->Dp, LOW = e->LOW, CATp = e->CATp, C2 = e->C2;
+    auto w = [&](int i) { return std::string(BN_SCOPES[i]) + "/weights"; };
+    linear(e, "aspp0", w(BN_A0), V, M, D, Mp, Dp);
+    for (int k = 1; k <= 3; ++k) conv3(e, fmt("aspp%d", k), w(BN_A0 + k), V, M, D, Mp, Dp);
+    linear(e, "aspp_img", w(BN_IMG), L, M, D, Mp, Dp);
+    {   // conv_1x1_concat: K = [four branches | image level]; the image-level part is a per-sample bias (its input is constant over the map)
+        Segs ks; for (int k = 0; k < 4; ++k) ks.push_back({k * D, D, k * Dp});
+        linear(e, "aspp_cat", w(BN_CAT), V, 5 * D, D, 4 * Dp, Dp, true, true, ks);
+        linear(e, "aspp_catl", w(BN_CAT), L, D, D, Dp, Dp, true, true, {{4 * D, D, 0}});
+    }
+    linear(e, "dec_low", w(BN_LOW), V, C2, LOW, pad64(C2), 64, true, false);
+    conv3(e, "dec1", w(BN_D1), V, D + LOW, D, CATp, Dp, {{0, D, 0}, {D, LOW, Dp}});      // K = [upsampled encoder output | low-level features]
+    conv3(e, "dec2", w(BN_D2), V, D, D, Dp, Dp);
 }
 inline const void* opp(const E* e, const std::string& key, int row = 0, int col = 0) {
     const Operand& o = e->ops.at(key);
@@ -439,21 +536,31 @@ void plan_workspace(E* e, Bump& zf, Bump& zb, Bump& g) {
     e->zero_page = zf.take(256);
     e->spatial = g.take((size_t)R * 64 * es);
     // ---- text encoder / parser / language pools
-    e->words_tb = (int*)g.take((size_t)T * B * 4);
-    e->emb = (float*)g.take((size_t)T * B * Gp * F);
-    e->xg = (float*)g.take((size_t)T * B * 4 * Cp * F);
-    e->gates = (float*)g.take((size_t)T * B * 4 * Cp * F);
-    e->h_all = (float*)zf.take((size_t)(T + 1) * B * Cp * F);
-    e->c_all = (float*)zf.take((size_t)(T + 1) * B * Cp * F);
-    e->outs = (float*)g.take((size_t)B * T * Cp * F);
+    for (int d = 0; d < e->ndir; ++d) {
+        LstmDir& D = e->ldir[d];
+        D.words_tb = (int*)g.take((size_t)T * B * 4);
+        D.emb = (float*)g.take((size_t)T * B * Gp * F);
+        D.xg = (float*)g.take((size_t)T * B * 4 * Cp * F);
+        D.gates = (float*)g.take((size_t)T * B * 4 * Cp * F);
+        D.h_all = (float*)zf.take((size_t)(T + 1) * B * Cp * F);
+        D.c_all = (float*)zf.take((size_t)(T + 1) * B * Cp * F);
+        D.outs = (float*)g.take((size_t)B * T * Cp * F);
+        D.douts = (float*)g.take((size_t)B * T * Cp * F);
+        D.dh = (float*)zb.take((size_t)B * Cp * F);
+        D.dc = (float*)zb.take((size_t)B * Cp * F);
+        D.dgt = (float*)g.take((size_t)T * B * 4 * Cp * F);
+        D.demb = (float*)g.take((size_t)T * B * Gp * F); D.demb_parts = (float*)g.take((size_t)8 * T * B * Gp * F);
+    }
+    if (e->v5) {
+        e->outs_bw = (float*)g.take((size_t)B * T * Cp * F); e->douts_bw = (float*)g.take((size_t)B * T * Cp * F);
+        e->wft = (float*)g.take((size_t)B * T * Cp * F); e->dwft = (float*)g.take((size_t)B * T * Cp * F);
+        if (e->cfg.hsv) e->hsv = g.take((size_t)R * 64 * es);
+        tap(e, "bilstm_fw", e->ldir[0].outs, 0, {B * T, Cp}); tap(e, "bilstm_bw", e->outs_bw, 0, {B * T, Cp});
+        if (e->cfg.hsv) tap(e, "hsv", e->hsv, vd, {R, 64});
+    }
     e->wf = (float*)g.take((size_t)B * T * Cp * F);
     e->wf_rstd = (float*)g.take((size_t)B * T * F);
     e->mask = (float*)g.take((size_t)B * T * F);
-    e->douts = (float*)g.take((size_t)B * T * Cp * F);
-    e->dh = (float*)zb.take((size_t)B * Cp * F);
-    e->dc = (float*)zb.take((size_t)B * Cp * F);
-    e->dgt = (float*)g.take((size_t)T * B * 4 * Cp * F);
-    e->demb = (float*)g.take((size_t)T * B * Gp * F); e->demb_parts = (float*)g.take((size_t)8 * T * B * Gp * F);
     e->h1 = (float*)g.take((size_t)B * T * Pp * F);
     e->lg = (float*)g.take((size_t)B * T * 64 * F);
     e->parse = (float*)g.take((size_t)B * T * 4 * F);
@@ -470,10 +577,11 @@ void plan_workspace(E* e, Bump& zf, Bump& zb, Bump& g) {
     // ---- pyramid levels
     const int cins[3] = {e->cfg.vf_dim, e->cfg.c4_dim, e->cfg.c3_dim};
     const int nch = (N + 63) / 64;
-    for (int i = 0; i < 3; ++i) {
-        LevelBuf& L = e->lv[i]; const char* n = LEVELS[i];
+    for (int i = 0; i < e->nlev; ++i) {
+        LevelBuf& L = e->lv[i]; const char* n = lvn(e, i);
         L.cin = cins[i];
         L.X0 = g.take((size_t)R * Cp * es); L.lat_rstd = (float*)g.take((size_t)R * F);
+        L.X0t = e->v5 ? g.take((size_t)R * Cp * es) : nullptr;
         L.g = (float*)g.take((size_t)B * 5 * Cp * F); L.P = g.take((size_t)R * 5 * Cp * es);
         L.X1 = g.take((size_t)R * Cp * es); L.mut_rstd = (float*)g.take((size_t)R * F);
         L.Wd = (float*)zf.take((size_t)B * Tp * Cp * F);
@@ -515,7 +623,7 @@ void plan_workspace(E* e, Bump& zf, Bump& zb, Bump& g) {
         tap(e, fmt("loss_vec_%s", n), L.loss, 0, {B});
     }
     // ---- gated exchange
-    for (int i = 0; i < 6; ++i) {
+    for (int i = 0; i < 2 * e->nex; ++i) {
         ExgBuf& X = e->ex[i];
         X.q = (float*)g.take((size_t)B * Mp * F); X.kq = (float*)g.take((size_t)B * Mp * F);
         X.logits = (float*)g.take((size_t)B * N * F); X.attn = (float*)g.take((size_t)B * N * F);
@@ -532,11 +640,11 @@ void plan_workspace(E* e, Bump& zf, Bump& zb, Bump& g) {
         X.dpooled = (float*)g.take((size_t)B * Mp * F); X.dnec = (float*)g.take((size_t)B * Cp * F);
         X.dattn = (float*)g.take((size_t)B * N * F); X.dlog = (float*)g.take((size_t)B * N * F);
         X.dkq = (float*)zb.take((size_t)B * Mp * F); X.dq = (float*)g.take((size_t)B * Mp * F);
-        tap(e, fmt("exg_%s", EXG[i]), X.out, vd, {R, Mp});
+        tap(e, fmt("exg_%s", exn(e, i)), X.out, vd, {R, Mp});
     }
-    for (int i = 0; i < 3; ++i) e->de1[i] = g.take((size_t)R * Mp * es);
+    for (int i = 0; i < e->nex; ++i) e->de1[i] = g.take((size_t)R * Mp * es);
     // ---- ConvLSTM + final score
-    for (int s = 0; s < 3; ++s) {
+    for (int s = 0; s < e->ncl; ++s) {
         ClstmStep& S = e->cl[s];
         S.Yg = g.take((size_t)R * 4 * Mp * es); S.sums = (double*)g.take((size_t)5 * B * STAT_PARTS * 2 * D);
         S.c_pre = g.take((size_t)R * Mp * es); S.c_new = g.take((size_t)R * Mp * es); S.h_new = g.take((size_t)R * Mp * es);
@@ -544,10 +652,36 @@ void plan_workspace(E* e, Bump& zf, Bump& zb, Bump& g) {
         S.dx = g.take((size_t)R * Mp * es); S.dh = g.take((size_t)R * Mp * es);
     }
     e->cl_scr = g.take((size_t)R * Mp * es); e->cl_bs = (double*)g.take((size_t)5 * B * STAT_PARTS * 2 * D);
-    e->score = (float*)g.take((size_t)B * e->h * e->w * F); e->up = (float*)g.take((size_t)B * H * W * F);
+    const int ph = e->v5 ? e->h2 : e->h, pw = e->v5 ? e->w2 : e->w;        // the map `pred` lives on (v5: the decoder's, H/4 x W/4)
+    e->score = (float*)g.take((size_t)B * ph * pw * F); e->up = (float*)g.take((size_t)B * H * W * F);
     e->sigm = (float*)g.take((size_t)B * H * W * F);
     e->loss = (float*)zf.take((size_t)B * F); e->iu = (int*)zf.take((size_t)2 * B * 4);
-    e->dscore = (float*)g.take((size_t)B * e->h * e->w * F); e->dfused = g.take((size_t)R * Mp * es);
+    e->dscore = (float*)g.take((size_t)B * ph * pw * F); e->dfused = g.take((size_t)R * Mp * es);
+    if (e->v5) {
+        // ---- ASPP + decoder (v5:190-251)
+        const int Dp = e->Dp, CATp = e->CATp, R2 = e->R2;
+        const int rows[9] = {R, R, R, R, B, R, R2, R2, R2}, cpad[9] = {Dp, Dp, Dp, Dp, Dp, Dp, 64, Dp, Dp}, cval[9] = {e->D, e->D, e->D, e->D, e->D, e->D, e->LOW, e->D, e->D};
+        for (int i = 0; i < 9; ++i) {
+            BnLayer& L = e->bn[i];
+            L.scope = BN_SCOPES[i]; L.C = cval[i]; L.Cpad = cpad[i]; L.R = rows[i]; L.dt = i == BN_IMG ? DT_F32 : vd; L.ldpre = cpad[i];
+            const size_t esz_i = i == BN_IMG ? F : es;
+            L.pre = g.take((size_t)rows[i] * cpad[i] * esz_i); L.dpre = g.take((size_t)rows[i] * cpad[i] * esz_i);
+            L.sums = (double*)g.take((size_t)2 * cpad[i] * D); L.mr = (float*)g.take((size_t)2 * cpad[i] * F); L.means = (float*)g.take((size_t)2 * cpad[i] * F);
+            L.mm = e->bn_state ? e->bn_state + e->state_off.at(std::string("text_objseg/") + BN_SCOPES[i] + "/BatchNorm/moving_mean") : nullptr;
+            L.mv = e->bn_state ? e->bn_state + e->state_off.at(std::string("text_objseg/") + BN_SCOPES[i] + "/BatchNorm/moving_variance") : nullptr;
+        }
+        e->cat4 = g.take((size_t)R * 4 * Dp * es); e->enc = g.take((size_t)R * Dp * es);
+        e->deccat = g.take((size_t)R2 * CATp * es); e->net1 = g.take((size_t)R2 * Dp * es); e->net2 = g.take((size_t)R2 * Dp * es);
+        e->dcat4 = g.take((size_t)R * 4 * Dp * es); e->denc = g.take((size_t)R * Dp * es);
+        e->ddeccat = g.take((size_t)R2 * CATp * es); e->dnet1 = g.take((size_t)R2 * Dp * es); e->dnet2 = g.take((size_t)R2 * Dp * es);
+        e->pooled = (float*)zf.take((size_t)B * Mp * F); e->img = (float*)g.take((size_t)B * Dp * F); e->catsb = (float*)g.take((size_t)B * Dp * F);
+        e->dcatsb = (float*)zb.take((size_t)B * Dp * F); e->dimg = (float*)g.take((size_t)B * Dp * F); e->dpooled = (float*)g.take((size_t)B * Mp * F);
+        e->ones_n = (float*)g.take((size_t)B * N * F);              // 1/N per node: the global average pooling as an attention pool (filled once, at create)
+        e->zbias = (float*)g.take((size_t)2048 * F);
+        e->zeros_bt = (float*)g.take((size_t)std::max(B * T, 64) * F);      // never written: the absent third level's d(parse_R) and loss vector                // zero bias vector of the batch-normed convolutions (never written)
+        tap(e, "aspp_branches", e->cat4, vd, {R, 4 * Dp}); tap(e, "aspp_image", e->img, 0, {B, Dp}); tap(e, "aspp", e->enc, vd, {R, Dp});
+        tap(e, "dec_cat", e->deccat, vd, {R2, CATp}); tap(e, "dec_net2", e->net2, vd, {R2, Dp});
+    }
     e->scalars = (float*)g.take(256);
     e->nonfinite = (int*)zb.take(256);
     e->tn_table_bytes = (size_t)128 << 10;
@@ -555,13 +689,13 @@ void plan_workspace(E* e, Bump& zf, Bump& zb, Bump& g) {
     // partial rows of the deferred folds (~2 MB each, ~110 per step at B*N = 12800, Cp = 1024) and the per-part slabs of the split dW
     // reductions: both scale with the rows x widest map of the plan; 2 GiB at the benchmark's sizes, 32 MiB floor for tiny handles.  A
     // request that does not fit is served from the per-stream scratch and folded at once (cmpc_ws / cmpc_reduce_parts_f32): same bits.
-    e->fold.cap = up256(((size_t)32 << 20) + (size_t)(2147483648.0 * ((double)R * Cp / (12800.0 * 1024.0))));
+    e->fold.cap = up256(((size_t)32 << 20) + (size_t)(2147483648.0 * (((double)R * Cp + (e->v5 ? 4.0 * e->R2 * e->Dp : 0.0)) / (12800.0 * 1024.0))));
     e->fold.arena = (char*)g.take(e->fold.cap);
     e->fold.table_cap = 1024;
     for (int a = 0; a < E::NBK; ++a) e->fold_table[a] = (cmpc_fold_desc*)g.take(sizeof(cmpc_fold_desc) * e->fold.table_cap);
     e->fold.table_dev = e->fold_table[E::NBK - 1];
-    tap(e, "fused", e->cl[2].h_new, vd, {R, Mp});
-    tap(e, "pred", e->score, 0, {B, e->h, e->w, 1}); tap(e, "up", e->up, 0, {B, H, W, 1}); tap(e, "sigm", e->sigm, 0, {B, H, W, 1});
+    tap(e, "fused", e->cl[e->ncl - 1].h_new, vd, {R, Mp});
+    tap(e, "pred", e->score, 0, {B, ph, pw, 1}); tap(e, "up", e->up, 0, {B, H, W, 1}); tap(e, "sigm", e->sigm, 0, {B, H, W, 1});
     tap(e, "iu", e->iu, 3, {2, B}); tap(e, "loss_vec", e->loss, 0, {B}); tap(e, "scalars", e->scalars, 0, {6});
     tap(e, "grad_nonfinite", e->nonfinite, 3, {E::NBK});
 }
@@ -737,60 +871,128 @@ int add_n(hipStream_t st, int dt, void* dst, std::initializer_list<const void*> 
 // ------------------------------------------------------------------------------------------
 // stage: text encoder -- lstm(), CMPC_model.py:144-164
 // ------------------------------------------------------------------------------------------
-int text_fwd(E* e, hipStream_t st, const int32_t* words, const int32_t* seq_len) {
+// one LSTM direction over its (already gathered) word ids: x-side product for all steps, then the recurrence
+int lstm_dir_fwd(E* e, hipStream_t st, LstmDir& D, const int32_t* seq_len) {
     const int B = e->B, T = e->T, R = e->RNN, G = e->G, Cp = e->Cp, Gp = e->Gp, ldk = Gp + Cp;
-    hipLaunchKernelGGL(transpose_i32_kernel, dim3((B * T + 255) / 256), dim3(256), 0, st, words, e->words_tb, B, T);
-    CK(cmpc_check_launch("transpose_i32"));
-    CK(cmpc_embed_gather(pptr(e, "Variable"), e->words_tb, e->emb, T * B, G, Gp, e->V, st));
-    GemmOpt o; o.bias = (const float*)opp(e, "lstm.b");
-    CK(gemm_nt(st, DT_F32, {{e->emb, Gp, opp(e, "lstm.t"), ldk, Gp}}, e->xg, 4 * Cp, T * B, 4 * Cp, o));
-    const void* wh = opp(e, "lstm.t", 0, Gp);
+    CK(cmpc_embed_gather(pptr(e, "Variable"), D.words_tb, D.emb, T * B, G, Gp, e->V, st));
+    GemmOpt o; o.bias = (const float*)opp(e, D.key + ".b");
+    CK(gemm_nt(st, DT_F32, {{D.emb, Gp, opp(e, D.key + ".t"), ldk, Gp}}, D.xg, 4 * Cp, T * B, 4 * Cp, o));
+    const void* wh = opp(e, D.key + ".t", 0, Gp);
     for (int t = 0; t < T; ++t) {
-        float* gt = e->gates + (size_t)t * B * 4 * Cp;
-        float *hp = e->h_all + (size_t)t * B * Cp, *cp = e->c_all + (size_t)t * B * Cp;
-        GemmOpt s; s.sbias = e->xg + (size_t)t * B * 4 * Cp; s.ld_sbias = 4 * Cp; s.rows_per_sample = 1;
+        float* gt = D.gates + (size_t)t * B * 4 * Cp;
+        float *hp = D.h_all + (size_t)t * B * Cp, *cp = D.c_all + (size_t)t * B * Cp;
+        GemmOpt s; s.sbias = D.xg + (size_t)t * B * 4 * Cp; s.ld_sbias = 4 * Cp; s.rows_per_sample = 1;
         CK(gemm_nt(st, DT_F32, {{hp, Cp, wh, ldk, Cp}}, gt, 4 * Cp, B, 4 * Cp, s));
-        CK(cmpc_lstm_cell_fwd(gt, cp, hp, seq_len, t, cp + (size_t)B * Cp, hp + (size_t)B * Cp, e->outs + (size_t)t * Cp, T * Cp, B, Cp, R, st));
+        CK(cmpc_lstm_cell_fwd(gt, cp, hp, seq_len, t, cp + (size_t)B * Cp, hp + (size_t)B * Cp, D.outs + (size_t)t * Cp, T * Cp, B, Cp, R, st));
     }
-    return cmpc_l2norm_rows_fwd(DT_F32, e->outs, e->wf, e->wf_rstd, e->mask, B * T, Cp, R, st);
+    return CMPC_OK;
 }
-int text_bwd(E* e, hipStream_t st, const int32_t* seq_len) {
+// in: D.douts (gradient of the direction's outputs [B, T, Cp]); out: kernel / bias gradients (deferred), D.demb (not yet scattered)
+int lstm_dir_bwd(E* e, hipStream_t st, LstmDir& D, const int32_t* seq_len) {
     const int B = e->B, T = e->T, R = e->RNN, G = e->G, Cp = e->Cp, Gp = e->Gp;
-    CK(cmpc_l2norm_rows_bwd(DT_F32, e->dwf, e->wf, e->wf_rstd, e->douts, B * T, Cp, R, 0, st));
-    auto gat = [&](int t) { return e->gates + (size_t)t * B * 4 * Cp; };
-    auto call = [&](int t) { return e->c_all + (size_t)t * B * Cp; };
-    auto dgt = [&](int t) { return e->dgt + (size_t)t * B * 4 * Cp; };
+    auto gat = [&](int t) { return D.gates + (size_t)t * B * 4 * Cp; };
+    auto call = [&](int t) { return D.c_all + (size_t)t * B * Cp; };
+    auto dgt = [&](int t) { return D.dgt + (size_t)t * B * 4 * Cp; };
     if (B <= 8) {
         // one launch per step: dh += dg[t] . W_h^T fused with the cell backward of step t-1
-        CK(cmpc_lstm_cell_bwd(gat(T - 1), call(T - 1), call(T), seq_len, T - 1, e->douts + (size_t)(T - 1) * Cp, T * Cp, e->dh, e->dc, dgt(T - 1), B, Cp, R, st));
-        const float* wn = (const float*)opp(e, "lstm.n", Gp, 0);
+        CK(cmpc_lstm_cell_bwd(gat(T - 1), call(T - 1), call(T), seq_len, T - 1, D.douts + (size_t)(T - 1) * Cp, T * Cp, D.dh, D.dc, dgt(T - 1), B, Cp, R, st));
+        const float* wn = (const float*)opp(e, D.key + ".n", Gp, 0);
         for (int t = T - 1; t > 0; --t)
-            CK(cmpc_lstm_bwd_step(dgt(t), wn, 4 * Cp, gat(t - 1), call(t - 1), call(t), seq_len, t - 1, e->douts + (size_t)(t - 1) * Cp, T * Cp,
-                                  e->dh, e->dc, dgt(t - 1), B, Cp, R, st));
+            CK(cmpc_lstm_bwd_step(dgt(t), wn, 4 * Cp, gat(t - 1), call(t - 1), call(t), seq_len, t - 1, D.douts + (size_t)(t - 1) * Cp, T * Cp,
+                                  D.dh, D.dc, dgt(t - 1), B, Cp, R, st));
     } else {
         for (int t = T - 1; t >= 0; --t) {
-            CK(cmpc_lstm_cell_bwd(gat(t), call(t), call(t + 1), seq_len, t, e->douts + (size_t)t * Cp, T * Cp, e->dh, e->dc, dgt(t), B, Cp, R, st));
+            CK(cmpc_lstm_cell_bwd(gat(t), call(t), call(t + 1), seq_len, t, D.douts + (size_t)t * Cp, T * Cp, D.dh, D.dc, dgt(t), B, Cp, R, st));
             GemmOpt o; o.n_valid = R; o.accumulate = 1;
-            CK(gemm_nt(st, DT_F32, {{dgt(t), 4 * Cp, opp(e, "lstm.n", Gp, 0), 4 * Cp, 4 * Cp}}, e->dh, Cp, B, Cp, o));
+            CK(gemm_nt(st, DT_F32, {{dgt(t), 4 * Cp, opp(e, D.key + ".n", Gp, 0), 4 * Cp, 4 * Cp}}, D.dh, Cp, B, Cp, o));
         }
     }
-    float* gk = gptr(e, "rnn/lstm_cell/kernel");
+    float* gk = gptr(e, D.pk);
     Offs o0, o1;
     for (int g = 0; g < 4; ++g) { o0.push_back({0, (int64_t)g * Cp, (int64_t)g * R}); o1.push_back({0, (int64_t)g * Cp, (int64_t)G * 4 * R + (int64_t)g * R}); }
     TnOpt d; d.defer = true;
-    CK(gemm_tn(e, st, DT_F32, e->emb, Gp, Gp, e->dgt, 4 * Cp, Cp, gk, 4 * R, T * B, G, R, o0, d));
-    CK(gemm_tn(e, st, DT_F32, e->h_all, Cp, Cp, e->dgt, 4 * Cp, Cp, gk, 4 * R, T * B, R, R, o1, d));
-    float* gb = gptr(e, "rnn/lstm_cell/bias");
-    for (int g = 0; g < 4; ++g) CK(colsum(st, DT_F32, e->dgt + (size_t)g * Cp, T * B, 4 * Cp, Cp, R, gb + (size_t)g * R));
+    CK(gemm_tn(e, st, DT_F32, D.emb, Gp, Gp, D.dgt, 4 * Cp, Cp, gk, 4 * R, T * B, G, R, o0, d));
+    CK(gemm_tn(e, st, DT_F32, D.h_all, Cp, Cp, D.dgt, 4 * Cp, Cp, gk, 4 * R, T * B, R, R, o1, d));
+    float* gb = gptr(e, D.pb);
+    for (int g = 0; g < 4; ++g) CK(colsum(st, DT_F32, D.dgt + (size_t)g * Cp, T * B, 4 * Cp, Cp, R, gb + (size_t)g * R));
     {   // demb = dg . W_x^T: a small output ([T*B, G]) over a long reduction (4 Cp) -> split-K as a batched product + one sum
         const int ks = (4 * Cp) % (8 * 32) == 0 ? 8 : 1, kc = 4 * Cp / ks;
         GemmOpt o; o.n_valid = G; o.batch = ks; o.sC = (int64_t)T * B * Gp;
-        CK(gemm_nt(st, DT_F32, {{e->dgt, 4 * Cp, opp(e, "lstm.n"), 4 * Cp, kc, (int64_t)kc, (int64_t)kc}}, e->demb_parts, Gp, T * B, Gp, o));
-        const float* p = e->demb_parts; const size_t sl = (size_t)T * B * Gp;
-        if (ks == 8) CK(add_n(st, DT_F32, e->demb, {p, p + sl, p + 2 * sl, p + 3 * sl, p + 4 * sl, p + 5 * sl, p + 6 * sl, p + 7 * sl}, false, (long)sl));
-        else CK(add_n(st, DT_F32, e->demb, {p}, false, (long)sl));
+        CK(gemm_nt(st, DT_F32, {{D.dgt, 4 * Cp, opp(e, D.key + ".n"), 4 * Cp, kc, (int64_t)kc, (int64_t)kc}}, D.demb_parts, Gp, T * B, Gp, o));
+        const float* p = D.demb_parts; const size_t sl = (size_t)T * B * Gp;
+        if (ks == 8) CK(add_n(st, DT_F32, D.demb, {p, p + sl, p + 2 * sl, p + 3 * sl, p + 4 * sl, p + 5 * sl, p + 6 * sl, p + 7 * sl}, false, (long)sl));
+        else CK(add_n(st, DT_F32, D.demb, {p}, false, (long)sl));
     }
-    return cmpc_embed_scatter(e->demb, Gp, e->words_tb, gptr(e, "Variable"), T * B, G, e->V, st);
+    return CMPC_OK;
+}
+
+// lstm(), CMPC_model.py:144-164 -- or BiLSTM(), CMPCv5_BiLSTM_model.py:159-187 (the backward direction on lane 1 beside the forward one)
+int text_fwd(E* e, hipStream_t st, const int32_t* words, const int32_t* seq_len) {
+    const int B = e->B, T = e->T, R = e->RNN, Cp = e->Cp;
+    LstmDir& F = e->ldir[0];
+    hipLaunchKernelGGL(transpose_i32_kernel, dim3((B * T + 255) / 256), dim3(256), 0, st, words, F.words_tb, B, T);
+    CK(cmpc_check_launch("transpose_i32"));
+    if (!e->v5) {
+        CK(lstm_dir_fwd(e, st, F, seq_len));
+        return cmpc_l2norm_rows_fwd(DT_F32, F.outs, e->wf, e->wf_rstd, e->mask, B * T, Cp, R, st);
+    }
+    LstmDir& W = e->ldir[1];
+    hipStream_t sb = st;
+    hipEvent_t back = nullptr;
+    if (e->cfg.n_lanes > 1) {
+        hipEvent_t ev = next_event(e);
+        HCK(hipEventRecord(ev, st));
+        sb = e->lane[1];
+        HCK(hipStreamWaitEvent(sb, ev, 0));
+    }
+    // bidirectional_dynamic_rnn: the backward cell reads reverse_sequence(inputs) and its outputs are reversed back (v5:170-174)
+    CK(cmpc_reverse_words_tb(words, seq_len, W.words_tb, B, T, sb));
+    CK(lstm_dir_fwd(e, sb, W, seq_len));
+    CK(cmpc_reverse_sequence(W.outs, e->outs_bw, seq_len, B, T, Cp, sb));
+    if (sb != st) { back = next_event(e); HCK(hipEventRecord(back, sb)); }
+    CK(lstm_dir_fwd(e, st, F, seq_len));
+    if (back) HCK(hipStreamWaitEvent(st, back, 0));
+    CK(cmpc_rows_nonzero2(F.outs, e->outs_bw, e->mask, B * T, Cp, R, st));                 // seq_mask (v5:181)
+    GemmOpt o; o.n_valid = R; o.bias = pptr(e, "words_feat/biases"); o.act = ACT_TANH;     // words_feat conv + tanh (v5:182-183)
+    CK(gemm_nt(st, DT_F32, {{F.outs, Cp, opp(e, "wfeat.t"), 2 * Cp, Cp}, {e->outs_bw, Cp, opp(e, "wfeat.t", 0, Cp), 2 * Cp, Cp}}, e->wft, Cp, B * T, Cp, o));
+    return cmpc_l2norm_rows_fwd(DT_F32, e->wft, e->wf, e->wf_rstd, nullptr, B * T, Cp, R, st);          // v5:185
+}
+int text_bwd(E* e, hipStream_t st, const int32_t* seq_len) {
+    const int B = e->B, T = e->T, R = e->RNN, G = e->G, Cp = e->Cp, Gp = e->Gp;
+    LstmDir& F = e->ldir[0];
+    if (!e->v5) {
+        CK(cmpc_l2norm_rows_bwd(DT_F32, e->dwf, e->wf, e->wf_rstd, F.douts, B * T, Cp, R, 0, st));
+        CK(lstm_dir_bwd(e, st, F, seq_len));
+        return cmpc_embed_scatter(F.demb, Gp, F.words_tb, gptr(e, "Variable"), T * B, G, e->V, st);
+    }
+    LstmDir& W = e->ldir[1];
+    TnOpt d; d.defer = true;
+    // words_feat = l2norm(tanh([fw | bw] . W + b)) (v5:182-185); dpre is read again by the deferred weight-gradient products
+    float* dpre = e->dwft;
+    CK(cmpc_l2norm_rows_bwd(DT_F32, e->dwf, e->wf, e->wf_rstd, dpre, B * T, Cp, R, 0, st));
+    CK(colsum(st, DT_F32, dpre, B * T, Cp, Cp, R, gptr(e, "words_feat/biases"), e->wft, dpre, ACT_TANH));
+    float* gw = gptr(e, "words_feat/DW");
+    CK(gemm_tn(e, st, DT_F32, F.outs, Cp, Cp, dpre, Cp, Cp, gw, R, B * T, R, R, OFF0, d));
+    CK(gemm_tn(e, st, DT_F32, e->outs_bw, Cp, Cp, dpre, Cp, Cp, gw + (size_t)R * R, R, B * T, R, R, OFF0, d));
+    GemmOpt o; o.n_valid = R;
+    CK(gemm_nt(st, DT_F32, {{dpre, Cp, opp(e, "wfeat.n"), Cp, Cp}}, F.douts, Cp, B * T, Cp, o));
+    CK(gemm_nt(st, DT_F32, {{dpre, Cp, opp(e, "wfeat.n", Cp, 0), Cp, Cp}}, e->douts_bw, Cp, B * T, Cp, o));
+    hipStream_t sb = st;
+    hipEvent_t back = nullptr;
+    if (e->cfg.n_lanes > 1) {
+        hipEvent_t ev = next_event(e);
+        HCK(hipEventRecord(ev, st));
+        sb = e->lane[1];
+        HCK(hipStreamWaitEvent(sb, ev, 0));
+    }
+    CK(cmpc_reverse_sequence(e->douts_bw, W.douts, seq_len, B, T, Cp, sb));
+    CK(lstm_dir_bwd(e, sb, W, seq_len));
+    if (sb != st) { back = next_event(e); HCK(hipEventRecord(back, sb)); }
+    CK(lstm_dir_bwd(e, st, F, seq_len));
+    if (back) HCK(hipStreamWaitEvent(st, back, 0));
+    // both directions add into the one embedding table: two scatters in a fixed order on one stream (one writer per row each)
+    CK(cmpc_embed_scatter(F.demb, Gp, F.words_tb, gptr(e, "Variable"), T * B, G, e->V, st));
+    return cmpc_embed_scatter(W.demb, Gp, W.words_tb, gptr(e, "Variable"), T * B, G, e->V, st);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -826,7 +1028,7 @@ int parser_bwd(E* e, hipStream_t st) {
 // operands of build_spa_graph, the tiled-language share of the fusion conv): ~8 small fp32 launches that run while the backbone
 // is still producing the visual features.
 int level_lang_fwd(E* e, hipStream_t st, int li) {
-    LevelBuf& L = e->lv[li]; const char* lv = LEVELS[li];
+    LevelBuf& L = e->lv[li]; const char* lv = lvn(e, li);
     const int B = e->B, T = e->T, C = e->C, Cp = e->Cp, Tp = e->Tp, M = e->M, Mp = e->Mp, dt = e->dt;
     { GemmOpt o; o.bias = (const float*)opp(e, fmt("mlang_%s.b", lv)); o.act = ACT_TANH;
       CK(gemm_nt(st, DT_F32, {{e->vl, Cp, opp(e, fmt("mlang_%s.t", lv)), Cp, Cp}}, L.g, 5 * Cp, B, 5 * Cp, o)); }
@@ -848,12 +1050,22 @@ int level_lang_fwd(E* e, hipStream_t st, int li) {
 
 // the visual side (after level_lang_fwd, once the backbone taps are complete)
 int level_fwd(E* e, hipStream_t st, int li, const float* target) {
-    LevelBuf& L = e->lv[li]; const char* lv = LEVELS[li];
+    LevelBuf& L = e->lv[li]; const char* lv = lvn(e, li);
     const int B = e->B, N = e->N, T = e->T, R = e->R, C = e->C, Cp = e->Cp, Tp = e->Tp, M = e->M, Mp = e->Mp, dt = e->dt;
-    // -- lateral 1x1 conv + l2_normalize (CMPC_model.py:108-113)
-    { GemmOpt o; o.n_valid = C; o.bias = pptr(e, fmt("%s_lateral/biases", lv));
+    // -- lateral 1x1 conv + l2_normalize (CMPC_model.py:108-113); CMPCv5_BiLSTM: tanh in between (v5:120-125), HSV channels as a K-segment (hsv:128-134)
+    if (!e->v5) {
+      GemmOpt o; o.n_valid = C; o.bias = pptr(e, fmt("%s_lateral/biases", lv));
       CK(gemm_nt(st, dt, {{L.feat, L.cin, opp(e, fmt("lat_%s.t", lv)), L.cin, L.cin}}, L.X0, Cp, R, Cp, o));
-      CK(cmpc_l2norm_rows_fwd(dt, L.X0, L.X0, L.lat_rstd, nullptr, R, Cp, C, st)); }
+      CK(cmpc_l2norm_rows_fwd(dt, L.X0, L.X0, L.lat_rstd, nullptr, R, Cp, C, st));
+    } else {
+      GemmOpt o; o.n_valid = C; o.bias = pptr(e, fmt("%s_lateral/biases", lv)); o.act = ACT_TANH;
+      const std::string k = fmt("lat_%s.t", lv);
+      if (e->cfg.hsv) {
+          const int ldk = L.cin + 64;
+          CK(gemm_nt(st, dt, {{L.feat, L.cin, opp(e, k), ldk, L.cin}, {e->hsv, 64, opp(e, k, 0, L.cin), ldk, 64}}, L.X0t, Cp, R, Cp, o));
+      } else CK(gemm_nt(st, dt, {{L.feat, L.cin, opp(e, k), L.cin, L.cin}}, L.X0t, Cp, R, Cp, o));
+      CK(cmpc_l2norm_rows_fwd(dt, L.X0t, L.X0, L.lat_rstd, nullptr, R, Cp, C, st));
+    }
     // -- mutan_fusion (:295-328)
     { const int ldk = Cp + 64; const std::string k = fmt("mutan_%s.t", lv);
       GemmOpt p; p.bias = (const float*)opp(e, fmt("mutan_%s.b", lv)); if (e->mutan_epilogue) p.act = ACT_TANH;
@@ -863,7 +1075,7 @@ int level_fwd(E* e, hipStream_t st, int li, const float* target) {
     { const float scale = 1.0f / sqrtf((float)C);
       GemmOpt c; c.batch = B; c.sC = (int64_t)N * Tp; c.c_f32 = 1; c.alpha = scale; c.sbias = L.k0s; c.ld_sbias = Tp; c.rows_per_sample = N;
       CK(gemm_nt(st, dt, {{L.X1, Cp, L.PT, Cp, Cp, (int64_t)N * Cp, (int64_t)Tp * Cp}}, L.A0, Tp, N, Tp, c));
-      CK(cmpc_graph_softmax_fwd(dt, L.A0, L.pr, e->mask, L.gw_w, L.gw_v, L.gw_w_t, L.gw_v_t, L.gsc, B, N, T, Tp, st));
+      CK(cmpc_graph_softmax_fwd(dt, e->v5 ? 1 : 0, L.A0, L.pr, e->mask, L.gw_w, L.gw_v, L.gw_w_t, L.gw_v_t, L.gsc, B, N, T, Tp, st));
       if (e->lowrank) {      // Z = gw_v^T . X1 [T, C] k-major (kept for the backward pass), Y = gw_w . Z as a stream of Y
           TnOpt zt; zt.nb2 = B; zt.a_bs = (int64_t)N * Tp; zt.d_bs = (int64_t)N * Cp; zt.o_bs = (int64_t)Tp * Cp;
           CK(gemm_tn(e, st, dt, L.gw_v_t, Tp, Tp, L.X1, Cp, Cp, L.Zf, Cp, N, T, C, OFF0, zt));
@@ -895,7 +1107,7 @@ int level_fwd(E* e, hipStream_t st, int li, const float* target) {
 
 // dfus (the level's fusion-output gradient from the exchange modules) must already hold the sum of its consumers
 int level_bwd(E* e, hipStream_t st, int li, const float* target) {
-    LevelBuf& L = e->lv[li]; const char* lv = LEVELS[li];
+    LevelBuf& L = e->lv[li]; const char* lv = lvn(e, li);
     const int B = e->B, N = e->N, T = e->T, R = e->R, C = e->C, Cp = e->Cp, Tp = e->Tp, M = e->M, Mp = e->Mp, dt = e->dt, Rr = e->RNN;
     const int es = e->esz;
     TnOpt d; d.defer = true;
@@ -993,8 +1205,11 @@ int level_bwd(E* e, hipStream_t st, int li, const float* target) {
       CK(gemm_nt(st, DT_F32, {{L.dg, 5 * Cp, opp(e, fmt("mlang_%s.n", lv)), 5 * Cp, 5 * Cp}}, L.dvl, Cp, B, Cp, v)); }
     // -- lateral
     CK(cmpc_l2norm_rows_bwd(dt, L.dX0, L.X0, L.lat_rstd, L.dV, R, Cp, C, 0, st));
-    CK(colsum(st, dt, L.dV, R, Cp, Cp, C, gptr(e, fmt("%s_lateral/biases", lv))));
-    return gemm_tn(e, st, dt, L.feat, L.cin, L.cin, L.dV, Cp, Cp, gptr(e, fmt("%s_lateral/DW", lv)), C, R, L.cin, C, OFF0, d);
+    if (!e->v5) CK(colsum(st, dt, L.dV, R, Cp, Cp, C, gptr(e, fmt("%s_lateral/biases", lv))));
+    else CK(colsum(st, dt, L.dV, R, Cp, Cp, C, gptr(e, fmt("%s_lateral/biases", lv)), L.X0t, L.dV, ACT_TANH));
+    float* glw = gptr(e, fmt("%s_lateral/DW", lv));
+    if (e->v5 && e->cfg.hsv) CK(gemm_tn(e, st, dt, e->hsv, 64, 64, L.dV, Cp, Cp, glw + (size_t)L.cin * C, C, R, 3, C, OFF0, d));
+    return gemm_tn(e, st, dt, L.feat, L.cin, L.cin, L.dV, Cp, Cp, glw, C, R, L.cin, C, OFF0, d);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1002,58 +1217,64 @@ int level_bwd(E* e, hipStream_t st, int li, const float* target) {
 // ------------------------------------------------------------------------------------------
 // the language side of an exchange module (query and folded key: functions of nec_lang only), run before the visual features exist
 int exchange_lang_fwd(E* e, hipStream_t st, int xi) {
-    ExgBuf& X = e->ex[xi]; const char* lv = EXG[xi];
+    ExgBuf& X = e->ex[xi]; const char* lv = exn(e, xi);
     const int B = e->B, Cp = e->Cp, M = e->M, Mp = e->Mp;
     GemmOpt q; q.n_valid = M; q.bias = pptr(e, fmt("lang_query_%sgv_f1/biases", lv));
     CK(gemm_nt(st, DT_F32, {{e->nec, Cp, opp(e, fmt("query_%s.t", lv)), Cp, Cp}}, X.q, Mp, B, Mp, q));
     GemmOpt k; k.n_valid = M;
     return gemm_nt(st, DT_F32, {{X.q, Mp, opp(e, fmt("key_%s.n", lv)), Mp, Mp}}, X.kq, Mp, B, Mp, k);
 }
+// f2 == nullptr: one gated branch (CMPCv5_BiLSTM_model.py:343-346), and tanh before the all-dims l2_normalize of gv_lang (v5:328-329)
 int exchange_fwd(E* e, hipStream_t st, int xi, const void* feat, const void* f1, const void* f2) {
-    ExgBuf& X = e->ex[xi]; const char* lv = EXG[xi];
+    ExgBuf& X = e->ex[xi]; const char* lv = exn(e, xi);
     const int B = e->B, N = e->N, R = e->R, Cp = e->Cp, M = e->M, Mp = e->Mp, dt = e->dt;
     const float s = 1.0f / sqrtf((float)M);
+    const int nbr = f2 ? 2 : 1;
     CK(cmpc_rowdot1(dt, feat, X.kq, Mp, X.logits, B, N, Mp, M, s, st));
     CK(cmpc_softmax_n_fwd(X.logits, X.attn, B, N, st));
     CK(cmpc_wcolsum(dt, feat, X.attn, X.pooled, Mp, B, N, Mp, M, 1.0f, st));
     const int ldk = Mp + Cp; const std::string gvk = fmt("gv_%s.t", lv);
-    GemmOpt g; g.n_valid = M; g.bias = pptr(e, fmt("gv_lang_%sgv_f1/biases", lv));
+    GemmOpt g; g.n_valid = M; g.bias = pptr(e, fmt("gv_lang_%sgv_f1/biases", lv)); if (e->v5) g.act = ACT_TANH;
     CK(gemm_nt(st, DT_F32, {{X.pooled, Mp, opp(e, gvk), ldk, Mp}, {e->nec, Cp, opp(e, gvk, 0, Mp), ldk, Cp}}, X.gvpre, Mp, B, Mp, g));
     CK(cmpc_l2norm_all_fwd(X.gvpre, X.gv, X.rs1, B * Mp, st));
     const void* fx[2] = {f1, f2}; const char* fn[2] = {"f1", "f2"};
     NtJob tj[2];
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < nbr; ++i) {
         GemmOpt a; a.n_valid = M; a.bias = pptr(e, fmt("lang_feat_%s_%s/biases", lv, fn[i])); a.act = ACT_SIGMOID;
         CK(gemm_nt(st, DT_F32, {{X.gv, Mp, opp(e, fmt("lfeat_%s_%s.t", lv, fn[i])), Mp, Mp}}, X.g[i], Mp, B, Mp, a));
         GemmOpt b; b.n_valid = M; b.bias = pptr(e, fmt("trans_feat_%s_%s/biases", lv, fn[i])); b.act = ACT_RELU;
         tj[i] = NtJob{Seg{fx[i], Mp, opp(e, fmt("tfeat_%s_%s.t", lv, fn[i])), Mp, Mp}, X.r[i], Mp, b};
     }
-    CK(gemm_nt_pair(st, dt, tj[0], tj[1], R, Mp));         // the two trans_feat 1x1 convs: one launch
-    return cmpc_exchange_combine_fwd(dt, feat, X.r[0], X.r[1], X.g[0], X.g[1], Mp, X.out, X.rstd, B, N, Mp, M, st);
+    if (nbr == 2) CK(gemm_nt_pair(st, dt, tj[0], tj[1], R, Mp));         // the two trans_feat 1x1 convs: one launch
+    else CK(gemm_nt(st, dt, {tj[0].seg}, tj[0].C, tj[0].ldc, R, Mp, tj[0].o));
+    return cmpc_exchange_combine_fwd(dt, feat, X.r[0], nbr == 2 ? X.r[1] : nullptr, X.g[0], nbr == 2 ? X.g[1] : nullptr, Mp, X.out, X.rstd, B, N, Mp, M, st);
 }
 // outputs: X.dfeat, X.dfs[0] (d f1), X.dfs[1] (d f2), X.dnec
 int exchange_bwd(E* e, hipStream_t st, int xi, const void* dout, const void* feat, const void* f1, const void* f2) {
-    ExgBuf& X = e->ex[xi]; const char* lv = EXG[xi];
+    ExgBuf& X = e->ex[xi]; const char* lv = exn(e, xi);
     const int B = e->B, N = e->N, R = e->R, Cp = e->Cp, M = e->M, Mp = e->Mp, dt = e->dt, Rr = e->RNN;
     const float s = 1.0f / sqrtf((float)M);
+    const int nbr = f2 ? 2 : 1;
     TnOpt d; d.defer = true;
-    CK(cmpc_exchange_combine_bwd(dt, dout, X.out, X.rstd, X.r[0], X.r[1], X.g[0], X.g[1], Mp, X.dfeat, 0, X.dp[0], X.dp[1], X.dg[0], X.dg[1],
-                                 B, N, Mp, M, st));
+    CK(cmpc_exchange_combine_bwd(dt, dout, X.out, X.rstd, X.r[0], nbr == 2 ? X.r[1] : nullptr, X.g[0], nbr == 2 ? X.g[1] : nullptr, Mp, X.dfeat, 0,
+                                 X.dp[0], nbr == 2 ? X.dp[1] : nullptr, X.dg[0], nbr == 2 ? X.dg[1] : nullptr, B, N, Mp, M, st));
     const void* fx[2] = {f1, f2}; const char* fn[2] = {"f1", "f2"};
     NtJob dj[2];
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < nbr; ++i) {
         CK(colsum(st, dt, X.dp[i], R, Mp, Mp, M, gptr(e, fmt("trans_feat_%s_%s/biases", lv, fn[i]))));
         CK(gemm_tn(e, st, dt, fx[i], Mp, Mp, X.dp[i], Mp, Mp, gptr(e, fmt("trans_feat_%s_%s/DW", lv, fn[i])), M, R, M, M, OFF0, d));
         GemmOpt o; o.n_valid = M;
         dj[i] = NtJob{Seg{X.dp[i], Mp, opp(e, fmt("tfeat_%s_%s.n", lv, fn[i])), Mp, Mp}, X.dfs[i], Mp, o};
-        if (i == 1) CK(gemm_nt_pair(st, dt, dj[0], dj[1], R, Mp));       // d f1 and d f2: one launch
+        if (nbr == 2 && i == 1) CK(gemm_nt_pair(st, dt, dj[0], dj[1], R, Mp));       // d f1 and d f2: one launch
+        if (nbr == 1) CK(gemm_nt(st, dt, {dj[0].seg}, dj[0].C, dj[0].ldc, R, Mp, dj[0].o));
         CK(colsum(st, DT_F32, X.dg[i], B, Mp, Mp, M, gptr(e, fmt("lang_feat_%s_%s/biases", lv, fn[i])), X.g[i], X.dg[i], ACT_SIGMOID));
         CK(gemm_tn(e, st, DT_F32, X.gv, Mp, Mp, X.dg[i], Mp, Mp, gptr(e, fmt("lang_feat_%s_%s/DW", lv, fn[i])), M, B, M, M, OFF0, d));
         GemmOpt a; a.n_valid = M; a.accumulate = i == 1;
         CK(gemm_nt(st, DT_F32, {{X.dg[i], Mp, opp(e, fmt("lfeat_%s_%s.n", lv, fn[i])), Mp, Mp}}, X.dgv, Mp, B, Mp, a));
     }
     CK(cmpc_l2norm_all_bwd(X.dgv, X.gv, X.rs1, X.dgvpre, B * Mp, st));
-    CK(colsum(st, DT_F32, X.dgvpre, B, Mp, Mp, M, gptr(e, fmt("gv_lang_%sgv_f1/biases", lv))));
+    if (!e->v5) CK(colsum(st, DT_F32, X.dgvpre, B, Mp, Mp, M, gptr(e, fmt("gv_lang_%sgv_f1/biases", lv))));
+    else CK(colsum(st, DT_F32, X.dgvpre, B, Mp, Mp, M, gptr(e, fmt("gv_lang_%sgv_f1/biases", lv)), X.gvpre, X.dgvpre, ACT_TANH));     // X.gvpre holds tanh(...)
     float* gwg = gptr(e, fmt("gv_lang_%sgv_f1/DW", lv));
     CK(gemm_tn(e, st, DT_F32, X.pooled, Mp, Mp, X.dgvpre, Mp, Mp, gwg, M, B, M, M, OFF0, d));
     CK(gemm_tn(e, st, DT_F32, e->nec, Cp, Cp, X.dgvpre, Mp, Mp, gwg + (size_t)M * M, M, B, Rr, M, OFF0, d));
@@ -1089,9 +1310,9 @@ int clstm_fwd(E* e, hipStream_t st, hipEvent_t* x_ready) {
     const int B = e->B, N = e->N, R = e->R, M = e->M, Mp = e->Mp, dt = e->dt;
     cmpc_convlstm_ln ln; cmpc_convlstm_dln dln; clstm_ln(e, ln, dln);
     const std::string pre = "rnn/conv_lstm_cell/";
-    const void* xs[3] = {e->ex[3].out, e->ex[4].out, e->ex[5].out};
+    const void* xs[3] = {e->ex[e->nex].out, e->ex[e->nex + 1].out, e->nex > 2 ? e->ex[e->nex + 2].out : nullptr};
     const void *hcur = nullptr, *ccur = nullptr;
-    for (int s = 0; s < 3; ++s) {
+    for (int s = 0; s < e->ncl; ++s) {
         ClstmStep& S = e->cl[s];
         if (x_ready && x_ready[s]) HCK(hipStreamWaitEvent(st, x_ready[s], 0));
         if (s == 0) CK(gemm_nt(st, dt, {{xs[s], Mp, opp(e, "clstm.t"), 2 * Mp, Mp}}, S.Yg, 4 * Mp, R, 4 * Mp));
@@ -1108,11 +1329,11 @@ int clstm_bwd(E* e, hipStream_t st, hipEvent_t* dx_ready) {
     const int B = e->B, N = e->N, R = e->R, M = e->M, Mp = e->Mp, dt = e->dt;
     cmpc_convlstm_ln ln; cmpc_convlstm_dln dln; clstm_ln(e, ln, dln);
     const std::string pre = "rnn/conv_lstm_cell/";
-    const void* xs[3] = {e->ex[3].out, e->ex[4].out, e->ex[5].out};
+    const void* xs[3] = {e->ex[e->nex].out, e->ex[e->nex + 1].out, e->nex > 2 ? e->ex[e->nex + 2].out : nullptr};
     float* gk = gptr(e, pre + "kernel");
     TnOpt d; d.defer = true;
     const void* dh = e->dfused; const void* dc = nullptr;
-    for (int s = 2; s >= 0; --s) {
+    for (int s = e->ncl - 1; s >= 0; --s) {
         ClstmStep& S = e->cl[s];
         const void* h_prev = s > 0 ? e->cl[s - 1].h_new : nullptr;
         const void* c_prev = s > 0 ? e->cl[s - 1].c_new : nullptr;
@@ -1141,6 +1362,145 @@ int clstm_bwd(E* e, hipStream_t st, hipEvent_t* dx_ready) {
         if (dx_ready && dx_ready[s]) HCK(hipEventRecord(dx_ready[s], xst));
     }
     return CMPC_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// stage: atrous_spatial_pyramid_pooling + decoder, CMPCv5_BiLSTM_model.py:190-251 (slim conv2d = convolution without bias +
+// batch_norm(eps 1e-5) + relu under resnet_v2.resnet_arg_scope)
+// ------------------------------------------------------------------------------------------
+const float BN_EPS = 1e-5f;
+int bn_fwd(E* e, hipStream_t st, BnLayer& L, void* y, int ldy, int Cy) {
+    const std::string p = L.scope + "/BatchNorm";
+    if (e->cfg.bn_train) CK(cmpc_bn_stats(L.dt, L.pre, L.ldpre, L.R, L.C, L.Cpad, BN_EPS, L.sums, L.mr, st));
+    else CK(cmpc_bn_from_moving(L.mm, L.mv, L.C, L.Cpad, BN_EPS, L.mr, st));
+    return cmpc_bn_apply_fwd(L.dt, L.pre, L.ldpre, L.mr, L.Cpad, pptr(e, p + "/gamma"), pptr(e, p + "/beta"), y, ldy, Cy, L.R, L.C, 1, st);
+}
+// dy / y: gradient wrt and value of the layer's (relu) output, possibly column blocks of wider maps; result in L.dpre
+int bn_bwd(E* e, hipStream_t st, BnLayer& L, const void* dy, int lddy, const void* y, int ldy) {
+    const std::string p = L.scope + "/BatchNorm";
+    return cmpc_bn_bwd(L.dt, dy, lddy, y, ldy, L.pre, L.ldpre, L.mr, L.Cpad, pptr(e, p + "/gamma"), L.dpre, L.ldpre, gptr(e, p + "/gamma"), gptr(e, p + "/beta"),
+                       L.means, L.R, L.C, 1, st);
+}
+// 3x3 'SAME' convolution with rate `dil` on [B, H, W] maps through the implicit-GEMM kernel; res: optional map added to the result (in place allowed)
+int conv3x3(E* e, hipStream_t st, const void* X, int ldx, const void* Wt, int ldw, void* Y, int ldy, const void* res, int H, int W, int Cin, int Cout, int dil) {
+    cmpc_conv_args a; memset(&a, 0, sizeof(a));
+    a.dtype = e->dt; a.X = X; a.ldx = ldx; a.Wt = Wt; a.ldw = ldw; a.bias = e->zbias; a.res = res; a.Y = Y; a.ldy = ldy;
+    a.B = e->B; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout; a.ksize = 3; a.stride = 1; a.dil = dil; a.relu = 0; a.zeros = e->zero_page;
+    return cmpc_conv_nhwc(&a, st);
+}
+// weight gradient of a 3x3 convolution: nine products out[t] += X(shifted by tap t)^T . dY, each a deferred gemm_tn with conv addressing.
+// X [rows, ldx] with the input channels in `nseg` column segments (a_col, out_row, len); out = HWIO gradient [9][cin][cout]
+int conv3x3_wgrad(E* e, hipStream_t st, const void* X, int ldx, int Ka, const void* dY, int lddy, int Nd, float* gw, int cin, int cout, int H, int W, int dil,
+                  std::initializer_list<std::array<int, 3>> segs) {
+    const int es = e->esz;
+    for (int t = 0; t < 9; ++t) {
+        for (const auto& sg : segs) {
+            cmpc_gemm_tn_args a; memset(&a, 0, sizeof(a));
+            a.dtype = e->dt; a.A = (const char*)X + (size_t)sg[0] * es; a.lda = ldx; a.Ka = Ka - sg[0];
+            a.D = dY; a.ldd = lddy; a.Nd = Nd;
+            a.out = gw + ((size_t)t * cin + sg[1]) * cout; a.ldo = cout;
+            a.R = e->B * H * W; a.Kv = sg[2]; a.Nv = cout; a.nb = 1; a.nb2 = 1; a.rsplit = 1; a.alpha = 1.f; a.zeros = e->zero_page;
+            a.conv_H = H; a.conv_W = W; a.conv_dy = (t / 3 - 1) * dil; a.conv_dx = (t % 3 - 1) * dil;
+            e->deferred[bucket_of(e, a.out)].push_back(a);
+        }
+    }
+    (void)st;
+    return CMPC_OK;
+}
+
+// in: fused = last ConvLSTM output; out: e->score (= pred on the decoder's map), e->up, e->sigm, loss / IoU counters
+int aspp_decoder_fwd(E* e, hipStream_t main, const float* target) {
+    const int B = e->B, N = e->N, R = e->R, M = e->M, Mp = e->Mp, D = e->D, Dp = e->Dp, CATp = e->CATp, R2 = e->R2, dt = e->dt, es = e->esz;
+    const void* X = e->cl[e->ncl - 1].h_new;
+    hipStream_t st[3];
+    CK(fork_lanes(e, main, st));
+    // (a) 1x1 branch and the image-level features on main, the three atrous branches on the lanes (v5:234-246)
+    for (int k = 1; k <= 3; ++k) {
+        BnLayer& L = e->bn[BN_A0 + k];
+        CK(conv3x3(e, st[k - 1], X, Mp, opp(e, fmt("aspp%d.t", k)), 9 * Mp, L.pre, Dp, nullptr, e->h, e->w, Mp, Dp, e->cfg.aspp_rates[k - 1]));
+        CK(bn_fwd(e, st[k - 1], L, (char*)e->cat4 + (size_t)k * Dp * es, 4 * Dp, Dp));
+    }
+    { GemmOpt o; o.n_valid = D;
+      CK(gemm_nt(main, dt, {{X, Mp, opp(e, "aspp0.t"), Mp, Mp}}, e->bn[BN_A0].pre, Dp, R, Dp, o));
+      CK(bn_fwd(e, main, e->bn[BN_A0], e->cat4, 4 * Dp, Dp));
+      CK(cmpc_wcolsum(dt, X, e->ones_n, e->pooled, Mp, B, N, Mp, M, 1.0f, main));                       // global average pooling (v5:242)
+      CK(gemm_nt(main, DT_F32, {{e->pooled, Mp, opp(e, "aspp_img.t"), Mp, Mp}}, e->bn[BN_IMG].pre, Dp, B, Dp, o));
+      CK(bn_fwd(e, main, e->bn[BN_IMG], e->img, Dp, Dp));
+      // its bilinear upsampling from 1x1 is a constant map (v5:246): its share of conv_1x1_concat is a per-sample bias
+      CK(gemm_nt(main, DT_F32, {{e->img, Dp, opp(e, "aspp_catl.t"), Dp, Dp}}, e->catsb, Dp, B, Dp, o)); }
+    CK(join_lanes(e, main));
+    { GemmOpt o; o.n_valid = D; o.sbias = e->catsb; o.ld_sbias = Dp; o.rows_per_sample = N;
+      CK(gemm_nt(main, dt, {{e->cat4, 4 * Dp, opp(e, "aspp_cat.t"), 4 * Dp, 4 * Dp}}, e->bn[BN_CAT].pre, Dp, R, Dp, o));
+      CK(bn_fwd(e, main, e->bn[BN_CAT], e->enc, Dp, Dp)); }
+    CK(mark(e, "fwd:aspp_done", main));
+    // decoder (v5:190-206): [upsampled encoder output | low-level features] -> 3x3 -> 3x3 -> 1x1 to one channel
+    CK(cmpc_resize_bilinear_fwd(dt, e->enc, Dp, e->deccat, CATp, B, e->h, e->w, e->h2, e->w2, Dp, main));
+    BnLayer &L1 = e->bn[BN_D1], &L2 = e->bn[BN_D2];
+    CK(conv3x3(e, main, e->deccat, CATp, opp(e, "dec1.t"), 9 * CATp, L1.pre, Dp, nullptr, e->h2, e->w2, CATp, Dp, 1));
+    CK(bn_fwd(e, main, L1, e->net1, Dp, Dp));
+    CK(conv3x3(e, main, e->net1, Dp, opp(e, "dec2.t"), 9 * Dp, L2.pre, Dp, nullptr, e->h2, e->w2, Dp, Dp, 1));
+    CK(bn_fwd(e, main, L2, e->net2, Dp, Dp));
+    CK(cmpc_conv_to1_fwd(dt, e->net2, Dp, pptr(e, "decoder/upsampling_logits/conv_1x1/weights"), pptr(e, "decoder/upsampling_logits/conv_1x1/biases"),
+                         e->score, R2, D, main));
+    return cmpc_upsample_fwd(e->score, e->up, e->sigm, target, e->loss, e->iu, e->iu + B, B, e->h2, e->w2, e->H, e->W, main);
+}
+// the low-level branch of the decoder depends on the backbone only (v5:195-197): issued as soon as the taps are complete
+int decoder_low_fwd(E* e, hipStream_t st) {
+    BnLayer& L = e->bn[BN_LOW];
+    GemmOpt o; o.n_valid = e->LOW;
+    CK(gemm_nt(st, e->dt, {{e->c2_feed, e->C2, opp(e, "dec_low.t"), pad64(e->C2), e->C2}}, L.pre, 64, e->R2, 64, o));
+    return bn_fwd(e, st, L, (char*)e->deccat + (size_t)e->Dp * e->esz, e->CATp, 64);
+}
+// out: e->dfused (gradient of the last ConvLSTM output) and every ASPP / decoder parameter gradient
+int aspp_decoder_bwd(E* e, hipStream_t main, const float* target) {
+    const int B = e->B, N = e->N, R = e->R, M = e->M, Mp = e->Mp, D = e->D, Dp = e->Dp, LOW = e->LOW, CATp = e->CATp, R2 = e->R2, dt = e->dt, es = e->esz;
+    const void* X = e->cl[e->ncl - 1].h_new;
+    TnOpt d; d.defer = true;
+    auto gw = [&](int i) { return gptr(e, std::string(BN_SCOPES[i]) + "/weights"); };
+    BnLayer &L1 = e->bn[BN_D1], &L2 = e->bn[BN_D2], &LL = e->bn[BN_LOW], &LC = e->bn[BN_CAT], &LI = e->bn[BN_IMG];
+    CK(cmpc_upsample_loss_bwd(e->up, target, e->dscore, e->cfg.loss_w[0] * e->cfg.loss_scale / B, B, e->h2, e->w2, e->H, e->W, main));
+    CK(cmpc_conv_to1_bwd(dt, e->dscore, e->net2, Dp, pptr(e, "decoder/upsampling_logits/conv_1x1/weights"), e->dnet2,
+                         gptr(e, "decoder/upsampling_logits/conv_1x1/weights"), gptr(e, "decoder/upsampling_logits/conv_1x1/biases"), R2, D, main));
+    CK(bn_bwd(e, main, L2, e->dnet2, Dp, e->net2, Dp));
+    CK(conv3x3_wgrad(e, main, e->net1, Dp, Dp, L2.dpre, Dp, Dp, gw(BN_D2), D, D, e->h2, e->w2, 1, {{0, 0, D}}));
+    CK(conv3x3(e, main, L2.dpre, Dp, opp(e, "dec2.n"), 9 * Dp, e->dnet1, Dp, nullptr, e->h2, e->w2, Dp, Dp, 1));
+    CK(bn_bwd(e, main, L1, e->dnet1, Dp, e->net1, Dp));
+    if (D == Dp) CK(conv3x3_wgrad(e, main, e->deccat, CATp, CATp, L1.dpre, Dp, Dp, gw(BN_D1), D + LOW, D, e->h2, e->w2, 1, {{0, 0, D + LOW}}));
+    else CK(conv3x3_wgrad(e, main, e->deccat, CATp, CATp, L1.dpre, Dp, Dp, gw(BN_D1), D + LOW, D, e->h2, e->w2, 1, {{0, 0, D}, {Dp, D, LOW}}));
+    CK(conv3x3(e, main, L1.dpre, Dp, opp(e, "dec1.n"), 9 * Dp, e->ddeccat, CATp, nullptr, e->h2, e->w2, Dp, CATp, 1));
+    // low-level branch: only its weights (res2b_relu belongs to the frozen backbone)
+    CK(bn_bwd(e, main, LL, (const char*)e->ddeccat + (size_t)Dp * es, CATp, (const char*)e->deccat + (size_t)Dp * es, CATp));
+    CK(gemm_tn(e, main, dt, e->c2_feed, e->C2, e->C2, LL.dpre, 64, 64, gw(BN_LOW), LOW, R2, e->C2, LOW, OFF0, d));
+    // encoder output
+    CK(cmpc_resize_bilinear_bwd(dt, e->ddeccat, CATp, e->denc, Dp, B, e->h, e->w, e->h2, e->w2, Dp, main));
+    CK(mark(e, "bwd:decoder_done", main));
+    CK(bn_bwd(e, main, LC, e->denc, Dp, e->enc, Dp));
+    CK(colsum(main, dt, LC.dpre, R, Dp, Dp, D, nullptr, nullptr, nullptr, ACT_NONE, e->dcatsb, Dp, N));           // gradient of the per-sample bias
+    { Offs oc; for (int k = 0; k < 4; ++k) oc.push_back({(int64_t)k * Dp, 0, (int64_t)k * D * D});
+      CK(gemm_tn(e, main, dt, e->cat4, 4 * Dp, Dp, LC.dpre, Dp, Dp, gw(BN_CAT), D, R, D, D, oc, d)); }
+    CK(gemm_tn(e, main, DT_F32, e->img, Dp, Dp, e->dcatsb, Dp, Dp, gw(BN_CAT) + (size_t)4 * D * D, D, B, D, D, OFF0, d));
+    { GemmOpt o; o.n_valid = D;
+      CK(gemm_nt(main, DT_F32, {{e->dcatsb, Dp, opp(e, "aspp_catl.n"), Dp, Dp}}, e->dimg, Dp, B, Dp, o)); }
+    CK(bn_bwd(e, main, LI, e->dimg, Dp, e->img, Dp));
+    CK(gemm_tn(e, main, DT_F32, e->pooled, Mp, Mp, LI.dpre, Dp, Dp, gw(BN_IMG), D, B, M, D, OFF0, d));
+    { GemmOpt o; o.n_valid = M;
+      CK(gemm_nt(main, DT_F32, {{LI.dpre, Dp, opp(e, "aspp_img.n"), Dp, Dp}}, e->dpooled, Mp, B, Mp, o)); }
+    CK(gemm_nt(main, dt, {{LC.dpre, Dp, opp(e, "aspp_cat.n"), Dp, Dp}}, e->dcat4, 4 * Dp, R, 4 * Dp));
+    // branches: gradients of the four maps that read `fused` are summed into e->dfused (1x1 first, each atrous branch adds through the
+    // convolution's residual input, the pooled path through a rank-1 update): a fixed order on one stream
+    BnLayer& L0 = e->bn[BN_A0];
+    CK(bn_bwd(e, main, L0, e->dcat4, 4 * Dp, e->cat4, 4 * Dp));
+    CK(gemm_tn(e, main, dt, X, Mp, Mp, L0.dpre, Dp, Dp, gw(BN_A0), D, R, M, D, OFF0, d));
+    { GemmOpt o; o.n_valid = M;
+      CK(gemm_nt(main, dt, {{L0.dpre, Dp, opp(e, "aspp0.n"), Dp, Dp}}, e->dfused, Mp, R, Mp, o)); }
+    for (int k = 1; k <= 3; ++k) {
+        BnLayer& L = e->bn[BN_A0 + k];
+        const int rate = e->cfg.aspp_rates[k - 1];
+        CK(bn_bwd(e, main, L, (const char*)e->dcat4 + (size_t)k * Dp * es, 4 * Dp, (const char*)e->cat4 + (size_t)k * Dp * es, 4 * Dp));
+        CK(conv3x3_wgrad(e, main, X, Mp, Mp, L.dpre, Dp, Dp, gw(BN_A0 + k), M, D, e->h, e->w, rate, {{0, 0, M}}));
+        CK(conv3x3(e, main, L.dpre, Dp, opp(e, fmt("aspp%d.n", k)), 9 * Dp, e->dfused, Mp, e->dfused, e->h, e->w, Dp, Mp, rate));
+    }
+    return cmpc_rank1_update(dt, e->dfused, e->ones_n, e->dpooled, nullptr, nullptr, Mp, 1.0f, 0.0f, B, N, Mp, M, main);
 }
 
 // bucket b is complete: its deferred weight-gradient products in one grouped launch, its deferred bias / LayerNorm / peephole folds in
@@ -1189,6 +1549,19 @@ extern "C" int cmpc_default_cfg(cmpc_cfg* c) {
     c->start_lr = 0.00025; c->end_lr = 0.00001; c->lr_power = 0.9; c->lr_decay_step = 800000; c->weight_decay = 0.0005f;
     c->loss_w[0] = 0.7f; c->loss_w[1] = c->loss_w[2] = c->loss_w[3] = 0.1f;
     c->dtype = DT_F16; c->n_lanes = 3; c->device = 0; c->loss_scale = 0.f;
+    c->model = CMPC_MODEL_CMPC; c->hsv = 0; c->bn_train = 0; c->bn_decay = 0.9997f;
+    c->c2_dim = 256; c->c2_h = c->H / 4; c->c2_w = c->W / 4; c->aspp_depth = 256; c->low_dim = 48;
+    c->aspp_rates[0] = 6; c->aspp_rates[1] = 12; c->aspp_rates[2] = 18;
+    return CMPC_OK;
+}
+// the caller's graph-shaping fields (batch_size, num_steps, vf_h, vf_w, H, W, ...) are kept; only the model-specific ones are set
+extern "C" int cmpc_default_cfg_model(cmpc_cfg* c, int model, int hsv) {
+    if (!c || (model != CMPC_MODEL_CMPC && model != CMPC_MODEL_V5_BILSTM)) { cmpc_set_error("default_cfg_model: bad argument"); return CMPC_EINVAL; }
+    c->model = model; c->hsv = (model == CMPC_MODEL_V5_BILSTM && hsv) ? 1 : 0;
+    c->bn_decay = 0.9997f; c->c2_dim = 256; c->c2_h = c->H / 4; c->c2_w = c->W / 4; c->aspp_depth = 256; c->low_dim = 48;
+    c->aspp_rates[0] = 6; c->aspp_rates[1] = 12; c->aspp_rates[2] = 18;
+    if (model == CMPC_MODEL_V5_BILSTM) { c->loss_w[0] = 0.8f; c->loss_w[1] = 0.1f; c->loss_w[2] = 0.1f; c->loss_w[3] = 0.f; c->bn_train = 1; }     // v5:541-542
+    else { c->loss_w[0] = 0.7f; c->loss_w[1] = c->loss_w[2] = c->loss_w[3] = 0.1f; c->bn_train = 0; }
     return CMPC_OK;
 }
 
@@ -1198,7 +1571,7 @@ extern "C" int cmpc_destroy(cmpc_handle e) {
     (void)hipSetDevice(e->cfg.device);
     (void)hipDeviceSynchronize();
     for (void* p : {(void*)e->params, (void*)e->grads, (void*)e->adam_m, (void*)e->adam_v, (void*)e->arena, (void*)e->descs_dev,
-                    (void*)e->tile_prefix_dev, (void*)e->tile_desc_dev, (void*)e->segs_dev, (void*)e->ws})
+                    (void*)e->tile_prefix_dev, (void*)e->tile_desc_dev, (void*)e->segs_dev, (void*)e->ws, (void*)e->bn_state})
         if (p) (void)hipFree(p);
     for (hipStream_t s : e->lane) if (s) (void)hipStreamDestroy(s);
     for (hipEvent_t ev : e->evpool) (void)hipEventDestroy(ev);
@@ -1224,6 +1597,15 @@ extern "C" int cmpc_create(const cmpc_cfg* c, cmpc_handle* out) {
     }
     if (pad64(c->v_emb_dim) > 2048 || pad64(c->mlp_dim) > 2048) { cmpc_set_error("create: v_emb_dim, mlp_dim <= 2048 (per-column registers of the map kernels)"); return CMPC_EINVAL; }
     if (c->n_lanes != 1 && c->n_lanes != 3) { cmpc_set_error("create: n_lanes must be 1 or 3"); return CMPC_EINVAL; }
+    if (c->model != CMPC_MODEL_CMPC && c->model != CMPC_MODEL_V5_BILSTM) { cmpc_set_error("create: model must be CMPC_MODEL_CMPC (0) or CMPC_MODEL_V5_BILSTM (1)"); return CMPC_EINVAL; }
+    if (c->model == CMPC_MODEL_V5_BILSTM) {
+        if (c->c2_dim < 64 || c->c2_dim % 64 || c->c2_h < c->vf_h || c->c2_w < c->vf_w || c->aspp_depth < 8 || c->aspp_depth % 4 || pad64(c->aspp_depth) > 512 ||
+            c->low_dim < 4 || c->low_dim % 4 || c->low_dim > 64 || c->aspp_rates[0] < 1 || c->aspp_rates[1] < 1 || c->aspp_rates[2] < 1 || c->mlp_dim % 4 ||
+            !(c->bn_decay >= 0.f && c->bn_decay <= 1.f)) {
+            cmpc_set_error("create (CMPCv5_BiLSTM): need c2_dim a multiple of 64, c2_h >= vf_h, c2_w >= vf_w, aspp_depth a multiple of 4 with pad64 <= 512, "
+                           "low_dim a multiple of 4 and <= 64, rates >= 1, mlp_dim a multiple of 4, 0 <= bn_decay <= 1"); return CMPC_EINVAL;
+        }
+    }
     const bool plan_only = c->device == -1;      // host-side planning only (manifest, operand plan, workspace size): no GPU needed
     if (!plan_only) {
         int ndev = 0;
@@ -1249,6 +1631,15 @@ extern "C" int cmpc_create(const cmpc_cfg* c, cmpc_handle* out) {
     e->H = c->H; e->W = c->W; e->V = c->vocab_size;
     e->C = c->v_emb_dim; e->Cp = pad64(e->C); e->M = c->mlp_dim; e->Mp = pad64(e->M); e->G = c->glove_dim; e->Gp = pad64(e->G);
     e->P = c->parse_dim; e->Pp = pad64(e->P); e->Tp = 64; e->RNN = c->rnn_size; e->dt = c->dtype; e->esz = c->dtype == DT_F32 ? 4 : 2;
+    e->v5 = c->model == CMPC_MODEL_V5_BILSTM;
+    if (e->v5) {
+        e->nlev = 2; e->nex = 2; e->ncl = 2; e->ndir = 2;
+        e->D = c->aspp_depth; e->Dp = pad64(e->D); e->LOW = c->low_dim; e->CATp = e->Dp + 64; e->C2 = c->c2_dim; e->h2 = c->c2_h; e->w2 = c->c2_w; e->R2 = e->B * e->h2 * e->w2;
+        const char* dn[2] = {"fw", "bw"};
+        for (int d = 0; d < 2; ++d) {
+            e->ldir[d].key = fmt("lstm_%s", dn[d]); e->ldir[d].pk = fmt("bidirectional_rnn/%s/lstm_cell/kernel", dn[d]); e->ldir[d].pb = fmt("bidirectional_rnn/%s/lstm_cell/bias", dn[d]);
+        }
+    } else { e->ldir[0].key = "lstm"; e->ldir[0].pk = "rnn/lstm_cell/kernel"; e->ldir[0].pb = "rnn/lstm_cell/bias"; }
     // the graph's T-deep products as streaming kernels (cmpc_lowrank_nn); decided before the workspace is planned (Z moves to the forward pass)
     e->lowrank = e->dt != DT_F32 && e->T <= 24 && e->Cp <= 1024 && ((e->Cp / 4) & (e->Cp / 4 - 1)) == 0;
     if (const char* v = getenv("CMPC_LOWRANK")) e->lowrank = e->lowrank && atoi(v) != 0;          // read once, at create
@@ -1267,6 +1658,14 @@ extern "C" int cmpc_create(const cmpc_cfg* c, cmpc_handle* out) {
     ECK(hipMalloc(&e->params, pbytes)); ECK(hipMalloc(&e->grads, pbytes)); ECK(hipMalloc(&e->adam_m, pbytes)); ECK(hipMalloc(&e->adam_v, pbytes));
     ECK(hipMemset(e->params, 0, pbytes)); ECK(hipMemset(e->grads, 0, pbytes)); ECK(hipMemset(e->adam_m, 0, pbytes)); ECK(hipMemset(e->adam_v, 0, pbytes));
     ECK(hipMalloc(&e->arena, e->arena_bytes)); ECK(hipMemset(e->arena, 0, e->arena_bytes));
+    if (e->state_total > 0) {       // batch-norm moving statistics: mean 0, variance 1 (slim's initialisers)
+        std::vector<float> init((size_t)e->state_total, 0.f);
+        for (const auto& sp : e->state_specs)
+            if (sp.first.size() > 15 && sp.first.compare(sp.first.size() - 15, 15, "moving_variance") == 0)
+                for (int64_t i = 0; i < sp.second; ++i) init[(size_t)e->state_off.at(sp.first) + i] = 1.f;
+        ECK(hipMalloc(&e->bn_state, (size_t)e->state_total * sizeof(float)));
+        ECK(hipMemcpy(e->bn_state, init.data(), init.size() * sizeof(float), hipMemcpyHostToDevice));
+    }
     if (upload_tables(e) != CMPC_OK) return fail(CMPC_EHIP);
     {   // workspace: measure, allocate, assign
         Bump zf, zb, g;
@@ -1294,6 +1693,10 @@ extern "C" int cmpc_create(const cmpc_cfg* c, cmpc_handle* out) {
         ECK(hipDeviceSynchronize());
         (void)hipFree(tmp);
     }
+    if (e->v5) {
+        std::vector<float> on((size_t)e->B * e->N, 1.0f / (float)e->N);       // tf.reduce_mean over the map (v5:242)
+        ECK(hipMemcpy(e->ones_n, on.data(), on.size() * sizeof(float), hipMemcpyHostToDevice));
+    }
     for (int i = 0; i < 3; ++i) ECK(hipStreamCreateWithFlags(&e->lane[i], hipStreamNonBlocking));
     e->evpool.resize(256);
     for (auto& ev : e->evpool) { ev = nullptr; ECK(hipEventCreateWithFlags(&ev, hipEventDisableTiming)); }
@@ -1307,13 +1710,25 @@ extern "C" int cmpc_create(const cmpc_cfg* c, cmpc_handle* out) {
     e->fold.descs = e->fold_descs.data(); e->fold.shadow = e->fold_shadow[E::NBK - 1].data();
     {   // bucket ranges from the manifest order (build_manifest)
         auto off = [&](const char* n) { return poff(e, n); };
-        const int64_t lat0 = off("c5_lateral/DW"), par0 = off("words_parse_1/DW"), l5 = off("vis_trans_c5_head1/DW"), l4 = off("vis_trans_c4_head1/DW"),
-                      l3 = off("vis_trans_c3_head1/DW"), ex0 = off("spa_graph_key_c3gv_f1/DW");
-        e->bucket[0] = {{ex0, e->total - ex0}};
-        e->bucket[1] = {{l5, l4 - l5}};
-        e->bucket[2] = {{l4, l3 - l4}};
-        e->bucket[3] = {{l3, ex0 - l3}, {lat0, par0 - lat0}};
-        e->bucket[4] = {{0, lat0}, {par0, l5 - par0}};
+        if (!e->v5) {
+            const int64_t lat0 = off("c5_lateral/DW"), par0 = off("words_parse_1/DW"), l5 = off("vis_trans_c5_head1/DW"), l4 = off("vis_trans_c4_head1/DW"),
+                          l3 = off("vis_trans_c3_head1/DW"), ex0 = off("spa_graph_key_c3gv_f1/DW");
+            e->bucket[0] = {{ex0, e->total - ex0}};
+            e->bucket[1] = {{l5, l4 - l5}};
+            e->bucket[2] = {{l4, l3 - l4}};
+            e->bucket[3] = {{l3, ex0 - l3}, {lat0, par0 - lat0}};
+            e->bucket[4] = {{0, lat0}, {par0, l5 - par0}};
+        } else {
+            // CMPCv5_BiLSTM: 0 = exchange modules + ConvLSTM + ASPP + decoder, 1 = level c5, 2 = level c4 + score_c5 / score_c4 + laterals,
+            // 3 = (empty), 4 = text encoder (both LSTMs, words_feat) + parser
+            const int64_t lat0 = off("c5_lateral/DW"), par0 = off("words_parse_1/DW"), l5 = off("vis_trans_c5_head1/DW"), l4 = off("vis_trans_c4_head1/DW"),
+                          ex0 = off("spa_graph_key_c4gv_f1/DW");
+            e->bucket[0] = {{ex0, e->total - ex0}};
+            e->bucket[1] = {{l5, l4 - l5}};
+            e->bucket[2] = {{l4, ex0 - l4}, {lat0, par0 - lat0}};
+            e->bucket[3] = {};
+            e->bucket[4] = {{0, lat0}, {par0, l5 - par0}};
+        }
         for (int b = 0; b < E::NBK; ++b) ECK(hipEventCreateWithFlags(&e->bucket_ev[b], hipEventDisableTiming));
         // the optimizer's work per bucket: runs of Adam segments and of pack tiles (both tables are in parameter / plan order)
         auto bucket_at = [&](int64_t o) { return bucket_of(e, e->grads + o); };
@@ -1381,6 +1796,37 @@ extern "C" int cmpc_pack(cmpc_handle e, void* stream) {
     CK(set_device(e));
     CK(params_ready(e, (hipStream_t)stream, 1));
     return cmpc_pack_weights_range(e->params, e->arena, e->descs_dev, e->tile_prefix_dev, e->tile_desc_dev, e->ndesc, 0, e->total_tiles, stream);
+}
+extern "C" int cmpc_state_count(cmpc_handle e) { return e ? (int)e->state_specs.size() : 0; }
+extern "C" int cmpc_state_info(cmpc_handle e, int i, const char** name, int64_t* count) {
+    if (!e || i < 0 || i >= (int)e->state_specs.size()) { cmpc_set_error("state_info: bad index"); return CMPC_EINVAL; }
+    if (name) *name = e->state_specs[i].first.c_str();
+    if (count) *count = e->state_specs[i].second;
+    return CMPC_OK;
+}
+static int find_state(cmpc_handle e, const char* name, int64_t count, int64_t* off) {
+    if (!e || !name) { cmpc_set_error("state: null argument"); return CMPC_EINVAL; }
+    auto it = e->state_off.find(name);
+    if (it == e->state_off.end()) { cmpc_set_error("state: no variable named %s", name); return CMPC_EINVAL; }
+    for (const auto& sp : e->state_specs) if (sp.first == name && sp.second != count) { cmpc_set_error("state: %s has %lld elements, got %lld", name, (long long)sp.second, (long long)count); return CMPC_EINVAL; }
+    *off = it->second;
+    return CMPC_OK;
+}
+extern "C" int cmpc_get_state(cmpc_handle e, const char* name, float* dst, int64_t count) {
+    int64_t off = 0;
+    CK(find_state(e, name, count, &off));
+    CK(set_device(e));
+    HCK(hipDeviceSynchronize());
+    HCK(hipMemcpy(dst, e->bn_state + off, (size_t)count * sizeof(float), hipMemcpyDeviceToHost));
+    return CMPC_OK;
+}
+extern "C" int cmpc_set_state(cmpc_handle e, const char* name, const float* src, int64_t count) {
+    int64_t off = 0;
+    CK(find_state(e, name, count, &off));
+    CK(set_device(e));
+    HCK(hipDeviceSynchronize());
+    HCK(hipMemcpy(e->bn_state + off, src, (size_t)count * sizeof(float), hipMemcpyHostToDevice));
+    return CMPC_OK;
 }
 extern "C" int cmpc_get_step(cmpc_handle e, int64_t* step) { if (!e || !step) return CMPC_EINVAL; *step = e->step; return CMPC_OK; }
 extern "C" int cmpc_set_step(cmpc_handle e, int64_t step) { if (!e || step < 0) return CMPC_EINVAL; e->step = step; return CMPC_OK; }
@@ -1525,13 +1971,16 @@ extern "C" int cmpc_launch_count(cmpc_handle e, int64_t* n) { if (!e || !n) retu
 
 // ------------------------------------------------------------------------------------------
 extern "C" int cmpc_forward(cmpc_handle e, const cmpc_feeds* f, const cmpc_fetches* fetch, void* stream) {
-    if (!e || !f || !f->words || !f->seq_len || !f->c3 || !f->c4 || !f->c5) { cmpc_set_error("forward: null handle / feed"); return CMPC_EINVAL; }
+    if (!e || !f || !f->words || !f->seq_len || !f->c4 || !f->c5) { cmpc_set_error("forward: null handle / feed"); return CMPC_EINVAL; }
+    if (!e->v5 && !f->c3) { cmpc_set_error("forward: CMPC_model needs the c3 tap"); return CMPC_EINVAL; }
+    if (e->v5 && (!f->c2 || (e->cfg.hsv && !f->im))) { cmpc_set_error("forward: CMPCv5_BiLSTM needs the c2 tap (and the image feed for the HSV variant)"); return CMPC_EINVAL; }
     CK(set_device(e));
     hipStream_t main = (hipStream_t)stream;
     t_cur = e;
     e->l0 = g_cmpc_launches;
     e->seq_len_feed = f->seq_len; e->target_feed = f->target_fine; e->last_main = main;
-    const int B = e->B, Cp = e->Cp;
+    e->c2_feed = f->c2; e->im_feed = f->im;
+    const int B = e->B, Cp = e->Cp, NL = e->nlev, NX = e->nex;
     e->have_target = f->target_fine != nullptr;
     for (auto& d : e->deferred) d.clear();
     e->lv[0].feat = f->c5; e->lv[1].feat = f->c4; e->lv[2].feat = f->c3;
@@ -1548,37 +1997,51 @@ extern "C" int cmpc_forward(cmpc_handle e, const cmpc_feeds* f, const cmpc_fetch
     // the lanes, while the backbone (caller's side stream) is still running; each lane then waits for the visual features itself.
     hipStream_t st[3];
     CK(fork_lanes(e, main, st));
-    for (int i = 0; i < 3; ++i) { CK(level_lang_fwd(e, st[i], i)); CK(exchange_lang_fwd(e, st[i], i)); CK(exchange_lang_fwd(e, st[i], 3 + i)); }
+    for (int i = 0; i < NL; ++i) { CK(level_lang_fwd(e, st[i], i)); CK(exchange_lang_fwd(e, st[i], i)); CK(exchange_lang_fwd(e, st[i], NX + i)); }
     if (f->feats_ready) for (int i = 0; i < (e->cfg.n_lanes > 1 ? 3 : 1); ++i) HCK(hipStreamWaitEvent(st[i], (hipEvent_t)f->feats_ready, 0));
     CK(mark(e, "fwd:feats_ready", st[0]));
+    if (e->v5) {
+        // hsv:120-126 (the image feed only) before the levels that read it; the decoder's low-level branch (backbone only) on the idle third lane
+        if (e->cfg.hsv) {
+            CK(cmpc_hsv_map(e->dt, f->im, e->hsv, 64, B, e->H, e->W, e->h, e->w, st[2]));
+            if (e->cfg.n_lanes > 1) { hipEvent_t ev = next_event(e); HCK(hipEventRecord(ev, st[2])); HCK(hipStreamWaitEvent(st[0], ev, 0)); HCK(hipStreamWaitEvent(st[1], ev, 0)); }
+        }
+        CK(decoder_low_fwd(e, st[2]));
+    }
     const char* lvm[3] = {"fwd:level_c5_done", "fwd:level_c4_done", "fwd:level_c3_done"};
-    for (int i = 0; i < 3; ++i) { CK(level_fwd(e, st[i], i, f->target_fine)); CK(mark(e, lvm[i], st[i])); }
+    for (int i = 0; i < NL; ++i) { CK(level_fwd(e, st[i], i, f->target_fine)); CK(mark(e, lvm[i], st[i])); }
     CK(join_lanes(e, main));
-    // gated_exchange_fusion_lstm_2times (:261-293): fusion maps in EXG order c3, c4, c5 = lv[2], lv[1], lv[0]
-    const void* fz[3] = {e->lv[2].F, e->lv[1].F, e->lv[0].F};
-    const int o1[3] = {1, 0, 0}, o2[3] = {2, 2, 1};                           // (c3: c4,c5) (c4: c3,c5) (c5: c3,c4)
+    // gated_exchange_fusion_lstm_2times (CMPC_model.py:261-293: modules c3, c4, c5 = lv[2], lv[1], lv[0], each reading the other two;
+    // CMPCv5_BiLSTM_model.py:349-388: modules c4, c5 = lv[1], lv[0], each reading the other one)
+    const void* fz[3] = {e->lv[NL - 1].F, e->lv[NL - 2].F, NL > 2 ? e->lv[0].F : nullptr};
+    const int o1[3] = {1, 0, 0}, o2[3] = {2, 2, 1};
     CK(fork_lanes(e, main, st));
-    for (int i = 0; i < 3; ++i) CK(exchange_fwd(e, st[i], i, fz[i], fz[o1[i]], fz[o2[i]]));
+    for (int i = 0; i < NX; ++i) CK(exchange_fwd(e, st[i], i, fz[i], fz[o1[i]], NX > 2 ? fz[o2[i]] : nullptr));
     CK(join_lanes(e, main));
     CK(mark(e, "fwd:exch1_done", main));
-    const void* ez[3] = {e->ex[0].out, e->ex[1].out, e->ex[2].out};
+    const void* ez[3] = {e->ex[0].out, e->ex[1].out, NX > 2 ? e->ex[2].out : nullptr};
     CK(fork_lanes(e, main, st));
     hipEvent_t ex2_done[3] = {nullptr, nullptr, nullptr};
-    for (int i = 0; i < 3; ++i) {
-        CK(exchange_fwd(e, st[i], 3 + i, ez[i], ez[o1[i]], ez[o2[i]]));
+    for (int i = 0; i < NX; ++i) {
+        CK(exchange_fwd(e, st[i], NX + i, ez[i], ez[o1[i]], NX > 2 ? ez[o2[i]] : nullptr));
         if (e->cfg.n_lanes > 1) { ex2_done[i] = next_event(e); HCK(hipEventRecord(ex2_done[i], st[i])); }
     }
+    if (e->v5 && e->cfg.n_lanes > 1) { hipEvent_t ev = next_event(e); HCK(hipEventRecord(ev, e->lane[2])); HCK(hipStreamWaitEvent(main, ev, 0)); }   // the low-level branch
     CK(clstm_fwd(e, main, ex2_done));            // ConvLSTM step s only waits for the round-2 module s that feeds it
     CK(mark(e, "fwd:clstm_done", main));
-    CK(cmpc_score_conv_fwd(e->dt, e->cl[2].h_new, pptr(e, "score/DW"), pptr(e, "score/biases"), e->score, B, e->h, e->w, e->Mp, e->M, main));
-    CK(cmpc_upsample_fwd(e->score, e->up, e->sigm, f->target_fine, e->loss, e->iu, e->iu + B, B, e->h, e->w, e->H, e->W, main));
+    const float* l5 = e->lv[0].loss; const float* l4 = e->lv[1].loss; const float* l3 = NL > 2 ? e->lv[2].loss : e->zeros_bt;
+    if (!e->v5) {
+        CK(cmpc_score_conv_fwd(e->dt, e->cl[2].h_new, pptr(e, "score/DW"), pptr(e, "score/biases"), e->score, B, e->h, e->w, e->Mp, e->M, main));
+        CK(cmpc_upsample_fwd(e->score, e->up, e->sigm, f->target_fine, e->loss, e->iu, e->iu + B, B, e->h, e->w, e->H, e->W, main));
+    } else CK(aspp_decoder_fwd(e, main, f->target_fine));
     if (e->have_target) {
-        hipLaunchKernelGGL(scalars_kernel, dim3(1), dim3(64), 0, main, e->loss, e->lv[0].loss, e->lv[1].loss, e->lv[2].loss, e->iu, e->iu + B, B,
-                           e->cfg.loss_w[0], e->cfg.loss_w[1], e->cfg.loss_w[2], e->cfg.loss_w[3], e->scalars);
+        hipLaunchKernelGGL(scalars_kernel, dim3(1), dim3(64), 0, main, e->loss, l5, l4, l3, e->iu, e->iu + B, B,
+                           e->cfg.loss_w[0], e->cfg.loss_w[1], e->cfg.loss_w[2], NL > 2 ? e->cfg.loss_w[3] : 0.f, e->scalars);
         CK(cmpc_check_launch("scalars"));
     }
     if (fetch) {
-        if (fetch->pred) HCK(hipMemcpyAsync(fetch->pred, e->score, (size_t)B * e->h * e->w * 4, hipMemcpyDeviceToDevice, main));
+        const int ph = e->v5 ? e->h2 : e->h, pw = e->v5 ? e->w2 : e->w;
+        if (fetch->pred) HCK(hipMemcpyAsync(fetch->pred, e->score, (size_t)B * ph * pw * 4, hipMemcpyDeviceToDevice, main));
         if (fetch->up) HCK(hipMemcpyAsync(fetch->up, e->up, (size_t)B * e->H * e->W * 4, hipMemcpyDeviceToDevice, main));
         if (fetch->sigm) HCK(hipMemcpyAsync(fetch->sigm, e->sigm, (size_t)B * e->H * e->W * 4, hipMemcpyDeviceToDevice, main));
     }
@@ -1599,10 +2062,11 @@ extern "C" int cmpc_backward(cmpc_handle e, void* stream) {
     static const bool hp = getenv("CMPC_HOST_PROFILE") != nullptr;
     double hp_t = host_now();
     if (!e->have_target || !e->seq_len_feed) { cmpc_set_error("backward: the last cmpc_forward had no target_fine"); return CMPC_EINVAL; }
+    if (e->v5 && !e->cfg.bn_train) { cmpc_set_error("backward: CMPCv5_BiLSTM trains with batch statistics (cfg.bn_train = 1, mode == 'train')"); return CMPC_EINVAL; }
     CK(set_device(e));
     hipStream_t main = (hipStream_t)stream;
     t_cur = e;
-    const int B = e->B, T = e->T, Cp = e->Cp, Mp = e->Mp, dt = e->dt;
+    const int B = e->B, T = e->T, Cp = e->Cp, Mp = e->Mp, dt = e->dt, NL = e->nlev, NX = e->nex;
     const long nmap = (long)e->R * Mp;
     const float* target = e->target_feed;
     CK(mark(e, "bwd:start", main));
@@ -1611,62 +2075,74 @@ extern "C" int cmpc_backward(cmpc_handle e, void* stream) {
     HOSTPROF("memsets");
     cmpc_fold_begin(&e->fold);
     struct FoldGuard { ~FoldGuard() { cmpc_fold_begin(nullptr); } } fold_guard;      // an early error return must not leave the collector on
-    // final score head + ConvLSTM
-    CK(cmpc_upsample_loss_bwd(e->up, target, e->dscore, e->cfg.loss_w[0] * e->cfg.loss_scale / B, B, e->h, e->w, e->H, e->W, main));
-    CK(cmpc_score_conv_bwd(dt, e->dscore, e->cl[2].h_new, pptr(e, "score/DW"), e->dfused, 0, gptr(e, "score/DW"), gptr(e, "score/biases"),
-                           B, e->h, e->w, Mp, e->M, main));
+    // final score head (CMPC_model) / ASPP + decoder (CMPCv5_BiLSTM), then the ConvLSTM
+    if (!e->v5) {
+        CK(cmpc_upsample_loss_bwd(e->up, target, e->dscore, e->cfg.loss_w[0] * e->cfg.loss_scale / B, B, e->h, e->w, e->H, e->W, main));
+        CK(cmpc_score_conv_bwd(dt, e->dscore, e->cl[2].h_new, pptr(e, "score/DW"), e->dfused, 0, gptr(e, "score/DW"), gptr(e, "score/biases"),
+                               B, e->h, e->w, Mp, e->M, main));
+    } else {
+        CK(aspp_decoder_bwd(e, main, target));
+        // UPDATE_OPS of the train step (v5:575-577): the moving statistics follow this step's batch statistics
+        for (BnLayer& L : e->bn) CK(cmpc_bn_update_moving(L.sums, L.R, e->cfg.bn_decay, L.mm, L.mv, L.C, L.Cpad, main));
+        CK(mark(e, "bwd:aspp_done", main));
+    }
     const int o1[3] = {1, 0, 0}, o2[3] = {2, 2, 1};
-    const void* fz[3] = {e->lv[2].F, e->lv[1].F, e->lv[0].F};
-    const void* ez[3] = {e->ex[0].out, e->ex[1].out, e->ex[2].out};
+    const void* fz[3] = {e->lv[NL - 1].F, e->lv[NL - 2].F, NL > 2 ? e->lv[0].F : nullptr};
+    const void* ez[3] = {e->ex[0].out, e->ex[1].out, NX > 2 ? e->ex[2].out : nullptr};
     hipStream_t st[3];
-    // ConvLSTM backward (steps 2, 1, 0 on main); the round-2 exchange module s starts on its lane as soon as step s has
+    // ConvLSTM backward (last step first, on main); the round-2 exchange module s starts on its lane as soon as step s has
     // produced its input gradient
     hipEvent_t dx_ready[3] = {nullptr, nullptr, nullptr};
-    if (e->cfg.n_lanes > 1) for (int i = 0; i < 3; ++i) dx_ready[i] = next_event(e);
+    if (e->cfg.n_lanes > 1) for (int i = 0; i < NX; ++i) dx_ready[i] = next_event(e);
     CK(clstm_bwd(e, main, dx_ready));
     CK(mark(e, "bwd:clstm_done", main));
     HOSTPROF("clstm");
-    for (int i = 0; i < 3; ++i) {
+    for (int i = 0; i < NX; ++i) {
         st[i] = e->cfg.n_lanes > 1 ? e->lane[i] : main;
         if (dx_ready[i]) HCK(hipStreamWaitEvent(st[i], dx_ready[i], 0));
-        CK(exchange_bwd(e, st[i], 3 + i, e->cl[i].dx, ez[i], ez[o1[i]], ez[o2[i]]));
+        CK(exchange_bwd(e, st[i], NX + i, e->cl[i].dx, ez[i], ez[o1[i]], NX > 2 ? ez[o2[i]] : nullptr));
     }
     CK(join_lanes(e, main));
     CK(mark(e, "bwd:exch2_done", main));
     HOSTPROF("exch2");
-    // gradient of input j of a round = dfeat of module j + the f1 / f2 gradients of the two modules that read it
+    // gradient of input j of a round = dfeat of module j + the f1 / f2 gradients of the modules that read it
     auto fan_in = [&](int base, int j, const void* (&src)[3]) {
         int n = 0;
         src[n++] = e->ex[base + j].dfeat;
-        for (int i = 0; i < 3; ++i) {
+        for (int i = 0; i < NX; ++i) {
             if (i == j) continue;
             if (o1[i] == j) src[n++] = e->ex[base + i].dfs[0];
-            if (o2[i] == j) src[n++] = e->ex[base + i].dfs[1];
+            if (NX > 2 && o2[i] == j) src[n++] = e->ex[base + i].dfs[1];
         }
         return n;
     };
+    auto add_fan = [&](hipStream_t s, void* dst, const void* (&src)[3], int n) {
+        return n == 3 ? add_n(s, dt, dst, {src[0], src[1], src[2]}, false, nmap) : add_n(s, dt, dst, {src[0], src[1]}, false, nmap);
+    };
     // exchange round 1
     CK(fork_lanes(e, main, st));
-    for (int j = 0; j < 3; ++j) {
+    for (int j = 0; j < NX; ++j) {
         const void* src[3];
-        if (fan_in(3, j, src) != 3) { cmpc_set_error("backward: exchange fan-in"); return CMPC_EINVAL; }
-        CK(add_n(st[j], dt, e->de1[j], {src[0], src[1], src[2]}, false, nmap));
-        CK(exchange_bwd(e, st[j], j, e->de1[j], fz[j], fz[o1[j]], fz[o2[j]]));
+        const int n = fan_in(NX, j, src);
+        if (n != NX) { cmpc_set_error("backward: exchange fan-in"); return CMPC_EINVAL; }
+        CK(add_fan(st[j], e->de1[j], src, n));
+        CK(exchange_bwd(e, st[j], j, e->de1[j], fz[j], fz[o1[j]], NX > 2 ? fz[o2[j]] : nullptr));
     }
     CK(join_lanes(e, main));
     CK(mark(e, "bwd:exch1_done", main));
     HOSTPROF("exch1");
-    // pyramid levels (lane i = level i = c5, c4, c3 = exchange input 2 - i); the language-side sums run on main meanwhile, and so do
-    // the weight-gradient products of the bucket that has just become final (exchange modules, ConvLSTM, final score): issued AFTER
-    // the fork, they run beside the levels instead of holding the three lanes back for their ~0.4 ms
+    // pyramid levels (lane i = level i = exchange input NL-1-i); the language-side sums run on main meanwhile, and so do
+    // the weight-gradient products of the bucket that has just become final (exchange modules, ConvLSTM, final score / ASPP + decoder):
+    // issued AFTER the fork, they run beside the levels instead of holding the lanes back
     CK(fork_lanes(e, main, st));
-    CK(add_n(main, DT_F32, e->dnec, {e->ex[0].dnec, e->ex[1].dnec, e->ex[2].dnec, e->ex[3].dnec, e->ex[4].dnec, e->ex[5].dnec}, false, (long)B * Cp));
+    if (NX > 2) CK(add_n(main, DT_F32, e->dnec, {e->ex[0].dnec, e->ex[1].dnec, e->ex[2].dnec, e->ex[3].dnec, e->ex[4].dnec, e->ex[5].dnec}, false, (long)B * Cp));
+    else CK(add_n(main, DT_F32, e->dnec, {e->ex[0].dnec, e->ex[1].dnec, e->ex[2].dnec, e->ex[3].dnec}, false, (long)B * Cp));
     CK(cmpc_lang_pool_bwd(e->dnec, e->nec, e->nec_rstd, e->parse, e->wf, e->dparse, e->dwf, B, T, Cp, e->RNN, 3, main));
     CK(flush_bucket(e, main, 0));
-    for (int i = 0; i < 3; ++i) {
+    for (int i = 0; i < NL; ++i) {
         const void* src[3];
-        fan_in(0, 2 - i, src);
-        CK(add_n(st[i], dt, e->lv[i].dfus, {src[0], src[1], src[2]}, false, nmap));
+        const int n = fan_in(0, NL - 1 - i, src);
+        CK(add_fan(st[i], e->lv[i].dfus, src, n));
         CK(level_bwd(e, st[i], i, target));
         const char* lvb[3] = {"bwd:level_c5_done", "bwd:level_c4_done", "bwd:level_c3_done"};
         CK(mark(e, lvb[i], st[i]));
@@ -1684,15 +2160,18 @@ extern "C" int cmpc_backward(cmpc_handle e, void* stream) {
         HCK(hipStreamWaitEvent(e->lane[0], ev, 0));
         wst = e->lane[0];
     }
-    for (int b = 1; b <= 3; ++b) CK(flush_bucket(e, wst, b));         // levels c5, c4, c3 (+ score_cX, laterals)
+    for (int b = 1; b <= 3; ++b) CK(flush_bucket(e, wst, b));         // levels (+ score_cX, laterals)
     CK(mark(e, "bwd:dW_main_done", wst));
     if (wst != main) { wg_done = next_event(e); HCK(hipEventRecord(wg_done, wst)); }
     HOSTPROF("dW main");
-    CK(add_n(main, DT_F32, e->dvl, {e->lv[0].dvl, e->lv[1].dvl, e->lv[2].dvl}, false, (long)B * Cp));
+    if (NL > 2) CK(add_n(main, DT_F32, e->dvl, {e->lv[0].dvl, e->lv[1].dvl, e->lv[2].dvl}, false, (long)B * Cp));
+    else CK(add_n(main, DT_F32, e->dvl, {e->lv[0].dvl, e->lv[1].dvl}, false, (long)B * Cp));
     CK(cmpc_lang_pool_bwd(e->dvl, e->vl, e->vl_rstd, e->parse, e->wf, e->dparse, e->dwf, B, T, Cp, e->RNN, 2, main));
-    hipLaunchKernelGGL(col_add3_kernel, dim3((B * T + 255) / 256), dim3(256), 0, main, e->dparse, 4, 2, e->lv[0].dpr, e->lv[1].dpr, e->lv[2].dpr, B * T);
+    const float* dpr3 = NL > 2 ? e->lv[2].dpr : e->zeros_bt;
+    hipLaunchKernelGGL(col_add3_kernel, dim3((B * T + 255) / 256), dim3(256), 0, main, e->dparse, 4, 2, e->lv[0].dpr, e->lv[1].dpr, dpr3, B * T);
     CK(cmpc_check_launch("col_add3"));
-    CK(add_n(main, DT_F32, e->dwf, {e->lv[0].dwf, e->lv[1].dwf, e->lv[2].dwf}, true, (long)B * T * Cp));
+    if (NL > 2) CK(add_n(main, DT_F32, e->dwf, {e->lv[0].dwf, e->lv[1].dwf, e->lv[2].dwf}, true, (long)B * T * Cp));
+    else CK(add_n(main, DT_F32, e->dwf, {e->lv[0].dwf, e->lv[1].dwf}, true, (long)B * T * Cp));
     CK(parser_bwd(e, main));
     CK(text_bwd(e, main, e->seq_len_feed));
     CK(mark(e, "bwd:text_done", main));

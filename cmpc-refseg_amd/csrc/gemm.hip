@@ -992,7 +992,15 @@ __device__ __forceinline__ void gemm_tn_body(const cmpc_gemm_tn_args& p, const i
             const int id = tid + 256 * i, row = id / CPR, c = id % CPR, gr = r0 + row;
             const int ka = k0 + c * EPC, nd = n0 + c * EPC;
             const bool rv = gr < rend;
-            ra[i] = (rv && ka < p.Ka) ? *reinterpret_cast<const uint4*>(A + (long)gr * p.lda + ka) : uint4{0u, 0u, 0u, 0u};
+            // weight gradient of a k x k (atrous) convolution, one tap: rows are pixels (b, y, x) of [*, conv_H, conv_W] maps and the A row of
+            // output pixel gr is the INPUT pixel (y + conv_dy, x + conv_dx) -- zero outside the image (TF 'SAME')
+            long ga = gr; bool av = rv;
+            if (p.conv_W > 0 && rv) {
+                const int xx = gr % p.conv_W + p.conv_dx, yy = (gr / p.conv_W) % p.conv_H + p.conv_dy;
+                av = yy >= 0 && yy < p.conv_H && xx >= 0 && xx < p.conv_W;
+                ga = (long)gr + (long)p.conv_dy * p.conv_W + p.conv_dx;
+            }
+            ra[i] = (av && ka < p.Ka) ? *reinterpret_cast<const uint4*>(A + ga * p.lda + ka) : uint4{0u, 0u, 0u, 0u};
             rd[i] = (rv && nd < p.Nd) ? *reinterpret_cast<const uint4*>(D + (long)gr * p.ldd + nd) : uint4{0u, 0u, 0u, 0u};
         }
     };
@@ -1123,6 +1131,7 @@ struct TnUploadArgs {
     int n, base;
     TnGroupDesc d[TN_UPLOAD];
 };
+static_assert(sizeof(TnUploadArgs) <= 4000, "descriptor batches travel through the kernel-argument segment (4 KB)");
 __global__ void tn_desc_upload_kernel(const TnUploadArgs ua, TnGroupDesc* table) {
     constexpr int W = (int)(sizeof(TnGroupDesc) / sizeof(int));
     const int* src = reinterpret_cast<const int*>(&ua.d[0]);

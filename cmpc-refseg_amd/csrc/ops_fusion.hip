@@ -201,7 +201,7 @@ constexpr int GS_ROWS = 64;     // node rows per workgroup
 template <typename T>
 __global__ __launch_bounds__(256) void graph_softmax_fwd1_kernel(const float* __restrict__ A0, const float* __restrict__ pr, const float* __restrict__ mask,
                                                                 float* __restrict__ gw_w, T* __restrict__ gw_w_t, float* __restrict__ cstat,
-                                                                int N, int Tn, int Tp) {
+                                                                int N, int Tn, int Tp, int mask_after) {
     __shared__ float cmax[4][64], csum[4][64];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, b = blockIdx.y, ch = blockIdx.x;
     const bool tv = lane < Tn;
@@ -212,11 +212,13 @@ __global__ __launch_bounds__(256) void graph_softmax_fwd1_kernel(const float* __
     const int n1 = min(N, (ch + 1) * GS_ROWS);
     for (int n = ch * GS_ROWS + w; n < n1; n += 4) {
         const float a = tv ? prt * A0[sb + (long)n * Tp + lane] : 0.f;
-        const float lg = tv ? (mk * a + (1.f - mk) * F32_MIN) : -INFINITY;
+        // CMPC_model.py:389-394: padded words leave the softmax (logit float32.min); CMPCv5_BiLSTM_model.py:486-487: they stay in it
+        // (with logit parse_R * affinity = 0) and the result is masked afterwards
+        const float lg = tv ? (mask_after ? a : (mk * a + (1.f - mk) * F32_MIN)) : -INFINITY;
         const float mx = wave_max(lg);
         const float ex = tv ? expf(lg - mx) : 0.f;
         const float sm = wave_sum(ex);
-        const float pz = ex / sm;
+        const float pz = mask_after ? mk * (ex / sm) : ex / sm;
         if (lane < Tp) {
             gw_w[sb + (long)n * Tp + lane] = pz;
             Elem<T>::st(gw_w_t + sb + (long)n * Tp + lane, pz);
@@ -375,11 +377,14 @@ __global__ __launch_bounds__(256) void exch_combine_fwd_kernel(const T* __restri
                                                               const float* __restrict__ g1, const float* __restrict__ g2, int ld_g,
                                                               T* __restrict__ out, float* __restrict__ rstd, int N, int ld, int C) {
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, b = blockIdx.y;
+    const bool two = r2 != nullptr;        // CMPCv5_BiLSTM_model.py:343-346 has ONE gated branch
     float gv1[MB][8], gv2[MB][8];
 #pragma unroll
     for (int k = 0; k < MB; ++k) {
         const int c0 = k * 512 + lane * 8;
-        if (c0 < ld) { ld8<float>(g1 + (long)b * ld_g + c0, gv1[k]); ld8<float>(g2 + (long)b * ld_g + c0, gv2[k]); }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) gv2[k][e] = 0.f;
+        if (c0 < ld) { ld8<float>(g1 + (long)b * ld_g + c0, gv1[k]); if (two) ld8<float>(g2 + (long)b * ld_g + c0, gv2[k]); }
     }
     for (int n = blockIdx.x * WPB + w; n < N; n += gridDim.x * WPB) {
         const long base = ((long)b * N + n) * ld;
@@ -389,8 +394,8 @@ __global__ __launch_bounds__(256) void exch_combine_fwd_kernel(const T* __restri
         for (int k = 0; k < MB; ++k) {
             const int c0 = k * 512 + lane * 8;
             if (c0 < ld) {
-                float f[8], a[8], c[8];
-                ld8<T>(feat + base + c0, f); ld8<T>(r1 + base + c0, a); ld8<T>(r2 + base + c0, c);
+                float f[8], a[8], c[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                ld8<T>(feat + base + c0, f); ld8<T>(r1 + base + c0, a); if (two) ld8<T>(r2 + base + c0, c);
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
                     const int cc = c0 + e;
@@ -423,13 +428,14 @@ __global__ __launch_bounds__(256) void exch_combine_bwd_kernel(const T* __restri
                                                               float* part, int N, int ld, int C) {
     extern __shared__ float lds[];     // [WPB][2*ld]
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, b = blockIdx.y;
+    const bool two = r2 != nullptr;
     float a1[MB][8], a2[MB][8], gv1[MB][8], gv2[MB][8];
 #pragma unroll
     for (int k = 0; k < MB; ++k) {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) { a1[k][e] = 0.f; a2[k][e] = 0.f; }
+        for (int e = 0; e < 8; ++e) { a1[k][e] = 0.f; a2[k][e] = 0.f; gv2[k][e] = 0.f; }
         const int c0 = k * 512 + lane * 8;
-        if (c0 < ld) { ld8<float>(g1 + (long)b * ld_g + c0, gv1[k]); ld8<float>(g2 + (long)b * ld_g + c0, gv2[k]); }
+        if (c0 < ld) { ld8<float>(g1 + (long)b * ld_g + c0, gv1[k]); if (two) ld8<float>(g2 + (long)b * ld_g + c0, gv2[k]); }
     }
     for (int n = blockIdx.x * WPB + w; n < N; n += gridDim.x * WPB) {
         const long base = ((long)b * N + n) * ld;
@@ -451,8 +457,8 @@ __global__ __launch_bounds__(256) void exch_combine_bwd_kernel(const T* __restri
         for (int k = 0; k < MB; ++k) {
             const int c0 = k * 512 + lane * 8;
             if (c0 < ld) {
-                float x1[8], x2[8], o1[8], o2[8], df[8];
-                ld8<T>(r1 + base + c0, x1); ld8<T>(r2 + base + c0, x2);
+                float x1[8], x2[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, o1[8], o2[8], df[8];
+                ld8<T>(r1 + base + c0, x1); if (two) ld8<T>(r2 + base + c0, x2);
                 if (accumulate) ld8<T>(dfeat + base + c0, df);
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
@@ -463,7 +469,7 @@ __global__ __launch_bounds__(256) void exch_combine_bwd_kernel(const T* __restri
                     o2[e] = (cc < C && x2[e] > 0.f) ? dE * gv2[k][e] : 0.f;
                     df[e] = accumulate ? df[e] + dE : dE;
                 }
-                st8<T>(dp1 + base + c0, o1); st8<T>(dp2 + base + c0, o2); st8<T>(dfeat + base + c0, df);
+                st8<T>(dp1 + base + c0, o1); if (two) st8<T>(dp2 + base + c0, o2); st8<T>(dfeat + base + c0, df);
             }
         }
     }
@@ -662,13 +668,13 @@ extern "C" int cmpc_mutan_bwd(int dt, void* Th, const float* g, const void* X1, 
     return cmpc_check_launch("mutan_bwd");
 }
 
-extern "C" int cmpc_graph_softmax_fwd(int dt, const float* A0, const float* pr, const float* mask, float* gw_w, float* gw_v,
+extern "C" int cmpc_graph_softmax_fwd(int dt, int mask_after, const float* A0, const float* pr, const float* mask, float* gw_w, float* gw_v,
                                       void* gw_w_t, void* gw_v_t, float* scratch, int B, int N, int T_, int Tp, void* stream) {
     if (T_ <= 0 || T_ > 64 || Tp < T_ || Tp > 64) { cmpc_set_error("graph_softmax: need 0 < T <= Tp <= 64"); return CMPC_EINVAL; }
     if (!scratch) { cmpc_set_error("graph_softmax: scratch (B*ceil(N/64)*128 floats) required"); return CMPC_EINVAL; }
     const int ch = (N + GS_ROWS - 1) / GS_ROWS;
     CMPC_DISPATCH_DT(dt, {
-        hipLaunchKernelGGL((graph_softmax_fwd1_kernel<T>), dim3(ch, B), dim3(256), 0, ST, A0, pr, mask, gw_w, (T*)gw_w_t, scratch, N, T_, Tp);
+        hipLaunchKernelGGL((graph_softmax_fwd1_kernel<T>), dim3(ch, B), dim3(256), 0, ST, A0, pr, mask, gw_w, (T*)gw_w_t, scratch, N, T_, Tp, mask_after);
         hipLaunchKernelGGL((graph_softmax_fwd2_kernel<T>), dim3(ch, B), dim3(256), 0, ST, A0, pr, mask, scratch, gw_v, (T*)gw_v_t, N, T_, Tp);
     });
     return cmpc_check_launch("graph_softmax_fwd");
@@ -724,6 +730,6 @@ extern "C" int cmpc_exchange_combine_bwd(int dt, const void* dout, const void* o
                                              (const T*)dout, (const T*)out, rstd, (const T*)r1, (const T*)r2, g1, g2, ld_g,
                                              (T*)dfeat, accumulate_dfeat, (T*)dp1, (T*)dp2, part, N, ld, C));
     if (cmpc_reduce_parts_f32(part, 2L * ld, B, gx, 1, ld, C, dg1, ld_g, 0, 1, ST)) return CMPC_EHIP;
-    if (cmpc_reduce_parts_f32(part + ld, 2L * ld, B, gx, 1, ld, C, dg2, ld_g, 0, 1, ST)) return CMPC_EHIP;
+    if (r2 && cmpc_reduce_parts_f32(part + ld, 2L * ld, B, gx, 1, ld, C, dg2, ld_g, 0, 1, ST)) return CMPC_EHIP;
     return cmpc_check_launch("exchange_combine_bwd");
 }

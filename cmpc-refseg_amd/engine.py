@@ -36,7 +36,7 @@ class Engine:
     """One cmpc_handle.  `store`-style accessors (params / grads views, state_dict, grad_dict, load_state) mirror what
     tf.train.Saver and tf.gradients give the reference's driver (trainval_model.py:46-63)."""
 
-    def __init__(self, cfg: HeadCfg, dt: int, device: torch.device, n_lanes: int = 3, loss_w=(0.7, 0.1, 0.1, 0.1)):
+    def __init__(self, cfg: HeadCfg, dt: int, device: torch.device, n_lanes: int = 3, loss_w=None):
         lib = _lib.load()
         self.lib, self.cfg, self.dt, self.device = lib, cfg, dt, torch.device(device)
         c = EngineCfg()
@@ -44,8 +44,15 @@ class Engine:
         for k in ("batch_size", "num_steps", "vf_h", "vf_w", "H", "W", "vf_dim", "c4_dim", "c3_dim", "vocab_size", "v_emb_dim",
                   "mlp_dim", "rnn_size", "glove_dim", "parse_dim", "start_lr", "end_lr", "lr_power", "lr_decay_step", "weight_decay"):
             setattr(c, k, getattr(cfg, k))
-        for i, w in enumerate(loss_w):
-            c.loss_w[i] = w
+        _lib.call("cmpc_default_cfg_model", C.byref(c), int(cfg.model), int(cfg.hsv))
+        if cfg.model == _lib.MODEL_V5_BILSTM:
+            for k in ("bn_train", "bn_decay", "c2_dim", "c2_h", "c2_w", "aspp_depth", "low_dim"):
+                setattr(c, k, getattr(cfg, k))
+            for i, r in enumerate(cfg.aspp_rates):
+                c.aspp_rates[i] = int(r)
+        if loss_w is not None:
+            for i, w in enumerate(loss_w):
+                c.loss_w[i] = w
         c.dtype, c.n_lanes = dt, n_lanes
         c.device = self.device.index if self.device.index is not None else torch.cuda.current_device()
         self.ccfg = c
@@ -69,6 +76,12 @@ class Engine:
         self.total = tot.value
         self.params, self.grads, self.m, self.v = (dev_tensor(x.value, (self.total,), 0, self.device) for x in (p, g, m, v))
         self._taps: Dict[str, torch.Tensor] = {}
+        # non-trainable variables (CMPCv5_BiLSTM: batch-norm moving statistics)
+        self.state_index: Dict[str, int] = {}
+        cnt = C.c_int64()
+        for i in range(lib.cmpc_state_count(h)):
+            _lib.call("cmpc_state_info", h, i, C.byref(name), C.byref(cnt))
+            self.state_index[name.value.decode()] = cnt.value
 
     def close(self):
         if getattr(self, "h", None) is not None and self.h:
@@ -117,6 +130,21 @@ class Engine:
     def pack(self):
         _lib.call("cmpc_pack", self.h, self._stream())
 
+    def get_state(self) -> Dict[str, np.ndarray]:
+        out = {}
+        for n, cnt in self.state_index.items():
+            a = np.empty(cnt, dtype=np.float32)
+            _lib.call("cmpc_get_state", self.h, n.encode(), a.ctypes.data_as(C.c_void_p), cnt)
+            out[n] = a
+        return out
+
+    def set_state(self, named: Dict[str, np.ndarray]):
+        for n, v in named.items():
+            a = np.ascontiguousarray(np.asarray(v, dtype=np.float32).reshape(-1))
+            if n not in self.state_index or self.state_index[n] != a.size:
+                raise KeyError(f"no state variable {n} of {a.size} elements")
+            _lib.call("cmpc_set_state", self.h, n.encode(), a.ctypes.data_as(C.c_void_p), a.size)
+
     def state_dict(self) -> Dict[str, torch.Tensor]:
         torch.cuda.synchronize(self.device)
         return {n: self.params[o: o + int(np.prod(s))].view(s).detach().cpu().clone() for n, (o, s) in self.index.items()}
@@ -128,10 +156,12 @@ class Engine:
         return {n: self.grads[o: o + int(np.prod(s))].view(s).detach().cpu() * inv for n, (o, s) in self.index.items()}
 
     # ---- the three per-step calls --------------------------------------------------------------
-    def forward(self, words, seq_len, c3, c4, c5, target=None, feats_ready: Optional[torch.cuda.Event] = None, fetches=None):
+    def forward(self, words, seq_len, c3, c4, c5, target=None, feats_ready: Optional[torch.cuda.Event] = None, fetches=None, c2=None, im=None):
         f = Feeds()
         f.words, f.seq_len = words.data_ptr(), seq_len.data_ptr()
-        f.c3, f.c4, f.c5 = c3.data_ptr(), c4.data_ptr(), c5.data_ptr()
+        f.c3, f.c4, f.c5 = (c3.data_ptr() if c3 is not None else None), c4.data_ptr(), c5.data_ptr()
+        f.c2 = c2.data_ptr() if c2 is not None else None
+        f.im = im.data_ptr() if im is not None else None
         f.target_fine = target.data_ptr() if target is not None else None
         f.feats_ready = feats_ready.cuda_event if feats_ready is not None else None
         fe = None

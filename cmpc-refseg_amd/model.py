@@ -30,6 +30,9 @@ MU = (104.00698793, 116.66876762, 122.67891434)       # trainval_model.py:371
 
 _LEVELS = ("c5", "c4", "c3")
 _EXG = ("c3", "c4", "c5", "c3_2", "c4_2", "c5_2")
+_LEVELS_V5 = ("c5", "c4")                              # CMPCv5_BiLSTM_model.py:134-137
+_EXG_V5 = ("c4", "c5", "c4_2", "c5_2")                 # :364-375
+MODELS = {"CMPC_model": (_lib.MODEL_CMPC, 0), "CMPCv5_BiLSTM_model": (_lib.MODEL_V5_BILSTM, 0), "CMPCv5_BiLSTM_HSV_model": (_lib.MODEL_V5_BILSTM, 1)}
 
 
 def tdt(dt: int):
@@ -42,7 +45,10 @@ class LSTM_model(object):
                  lr_decay_step=800000, lr_decay_rate=1.0, rnn_size=1000, keep_prob_rnn=1.0, keep_prob_emb=1.0,
                  keep_prob_mlp=1.0, num_rnn_layers=1, optimizer='adam', weight_decay=0.0005, mode='eval',
                  conv5=False, glove_dim=300, emb_name='Gref', emb_dir='data',
+                 batch_norm_decay=0.9997, freeze_bn=False, is_aug=False,      # CMPCv5_BiLSTM_model.py:42,47,49
                  # --- extensions (not in the reference signature) ---
+                 model="CMPC_model",         # which reference module this LSTM_model stands for (get_segmentation_model sets it)
+                 aspp_depth=256, low_dim=48, aspp_rates=(6, 12, 18),          # hard-coded in CMPCv5_BiLSTM_model.py:196,208,225
                  device="cuda:0", dtype="f16", c4_dim=1024, c3_dim=512, parse_dim=500,
                  backbone_width=64, backbone_blocks=(3, 4, 23, 3), head_params: Optional[Dict] = None,
                  backbone_params: Optional[Dict] = None, seed=1234, n_lanes: Optional[int] = None, **ignored):
@@ -56,6 +62,13 @@ class LSTM_model(object):
             raise NotImplementedError("dropout / stacked LSTM are unused by the reference graph")
         if dtype not in ("bf16", "f16", "f32"):
             raise ValueError("dtype must be 'bf16', 'f16' or 'f32'")
+        if model not in MODELS:
+            raise ValueError("model must be one of %s" % (sorted(MODELS),))
+        self.model_name = model
+        model_id, hsv = MODELS[model]
+        self.v5 = model_id == _lib.MODEL_V5_BILSTM
+        if freeze_bn or is_aug:
+            raise NotImplementedError("freeze_bn / is_aug (CMPCv5_BiLSTM_model.py:83-84,528-529) are not built")
         if dtype == "bf16":
             # diagnostic mode: same kernels and rate as f16, but 8-bit significands miss BASELINE's 1e-4 mean-IoU bar on some inputs
             # (measured up to 1.6e-4).  The default, f16 storage, meets it.
@@ -72,7 +85,10 @@ class LSTM_model(object):
         self.cfg = HeadCfg(batch_size=batch_size, num_steps=num_steps, vf_h=vf_h, vf_w=vf_w, H=H, W=W, vf_dim=vf_dim,
                            c4_dim=c4_dim, c3_dim=c3_dim, vocab_size=vocab_size, v_emb_dim=v_emb_dim, mlp_dim=mlp_dim,
                            rnn_size=rnn_size, glove_dim=glove_dim, parse_dim=parse_dim, start_lr=start_lr,
-                           lr_decay_step=lr_decay_step, weight_decay=weight_decay)
+                           lr_decay_step=lr_decay_step, weight_decay=weight_decay,
+                           model=model_id, hsv=hsv, bn_train=int(self.v5 and mode == 'train'), bn_decay=batch_norm_decay,
+                           c2_dim=4 * backbone_width, c2_h=-(-H // 4), c2_w=-(-W // 4), aspp_depth=aspp_depth, low_dim=low_dim,
+                           aspp_rates=tuple(aspp_rates))
         for name, v in (("vf_dim", vf_dim), ("c4_dim", c4_dim), ("c3_dim", c3_dim)):
             if v % 64:
                 raise ValueError(f"{name}={v} must be a multiple of 64 (MFMA K tile)")
@@ -82,7 +98,7 @@ class LSTM_model(object):
             self.eng = Engine(self.cfg, self.dt, self.device, n_lanes=n_lanes)
             self.store = self.eng                         # parameter / gradient accessors (state_dict, grad_dict, p, g, step)
             if head_params is None:
-                head_params = init_head_params(self.cfg, seed=seed)
+                head_params = self._init_params(seed)
                 path = '{}/{}_emb.npy'.format(emb_dir, emb_name)                     # CMPC_model.py:79
                 if os.path.exists(path):
                     glove = np.load(path)                                             # allow_pickle=False
@@ -94,6 +110,8 @@ class LSTM_model(object):
             self.comm_stream = torch.cuda.Stream(device=self.device)       # gradient all-reduce (data-parallel runs)
             self.bb_stream, self.opt_stream = self._side if n_lanes > 1 else (None, None)
             self.backbone = bb.DeepLabResNet(backbone_width, backbone_blocks)
+            if self.v5:
+                self.backbone.taps_wanted = ("2b", 4, 5)      # res2b_relu, res4b22_relu, res5c_relu (CMPCv5_BiLSTM_model.py:86-88)
             # the frozen backbone's variables under their TensorFlow names (deeplab_resnet/model.py): kept for checkpoints
             self.backbone_vars = dict(backbone_params if backbone_params is not None else bb.init_params(backbone_width, backbone_blocks))
             self.backbone.load_tf(self.backbone_vars)
@@ -104,6 +122,42 @@ class LSTM_model(object):
         self._bb_graph_on = os.environ.get("CMPC_BACKBONE_GRAPH", "1") != "0"
         self._bb = {"calls": 0, "next": 0, "graph": [None, None], "inp": [None, None], "out": [None, None]}
         self._keep = []                # feeds / taps of the steps in flight (the handle reads them asynchronously)
+
+    def _init_params(self, seed):
+        """Reference initialisers by variable name (CMPC_model.py:412-417; slim's variance_scaling_initializer for `weights`), driven by the
+        handle's own manifest so that both models share it."""
+        if not self.v5:
+            return init_head_params(self.cfg, seed=seed)
+        import math
+        g = torch.Generator().manual_seed(seed)
+        out = {}
+        for name in self.eng.order:
+            shape = self.eng.index[name][1]
+            leaf = name.rsplit("/", 1)[-1]
+            if leaf in ("DW", "kernel", "W_ci", "W_cf", "W_co"):
+                rf = int(np.prod(shape[:-2])) if len(shape) > 2 else 1
+                fi, fo = (shape[-2] * rf, shape[-1] * rf) if len(shape) >= 2 else (shape[0], shape[0])
+                t = (torch.rand(shape, generator=g, dtype=torch.float64) * 2 - 1) * math.sqrt(6.0 / (fi + fo))
+            elif leaf == "weights":
+                t = torch.randn(shape, generator=g, dtype=torch.float64) * math.sqrt(2.0 / (shape[0] * shape[1] * shape[2]))
+            elif leaf == "gamma":
+                t = torch.ones(shape, dtype=torch.float64)
+            elif leaf == "Variable":
+                t = torch.randn(shape, generator=torch.Generator().manual_seed(7), dtype=torch.float64) * 0.4
+            else:
+                t = torch.zeros(shape, dtype=torch.float64)
+            out[name] = t.float()
+        return out
+
+    # non-trainable variables for checkpoints (checkpoint.py): the batch-norm moving statistics of the v5 graph
+    def extra_vars(self):
+        return self.eng.get_state()
+
+    def extra_var_names(self):
+        return tuple(self.eng.state_index)
+
+    def load_extra_vars(self, named):
+        self.eng.set_state(named)
 
     def set_lanes(self, n: int):
         """n = 3: levels / exchange modules on the handle's three lane streams, backbone and optimizer on side streams;
@@ -192,26 +246,38 @@ class LSTM_model(object):
         visualisers use (test_visualize_graph.py:243-253)."""
         t = self.eng.tap
         out = {k: t(k) for k in ("words_feat", "seq_mask", "words_parse", "nec_lang", "fused", "pred", "up", "sigm", "iu")}
-        for lv in _LEVELS:
+        for lv in (_LEVELS_V5 if self.v5 else _LEVELS):
             for k in ("lat", "vis_la_sp", "spa_graph", "fusion", "gw_w", "gw_v", "score", "up"):
                 out[f"{k}_{lv}"] = t(f"{k}_{lv}")
-        for x in _EXG:
+        for x in (_EXG_V5 if self.v5 else _EXG):
             out[f"exg_{x}"] = t(f"exg_{x}")
+        if self.v5:
+            for k in ("bilstm_fw", "bilstm_bw", "aspp_branches", "aspp_image", "aspp", "dec_cat", "dec_net2") + (("hsv",) if self.cfg.hsv else ()):
+                out[k] = t(k)
         if with_loss:
             s = t("scalars")
             out.update(loss_all=s[0], loss_c3=s[1], loss_c4=s[2], loss_c5=s[3], loss_last=s[4], mIoU=s[5])
         return out
 
-    def head(self, feats, words, seq_len, target=None, after=None):
+    def head(self, feats, words, seq_len, target=None, after=None, im=None):
         """build_graph() on given backbone taps (CMPC_model.py:89-142): one cmpc_forward call.  Returns the fetch dict
-        (views into the handle's workspace: valid until the next call).  `after`: event that marks `feats` complete."""
+        (views into the handle's workspace: valid until the next call).  `after`: event that marks `feats` complete.
+        feats = (c3, c4, c5), or (c2, c4, c5) for the CMPCv5_BiLSTM models, whose HSV variant also needs the image feed `im`."""
         with torch.cuda.device(self.device):
-            c3, c4, c5 = [f.to(tdt(self.dt)).contiguous() for f in feats] if after is None else feats
+            f0, c4, c5 = [f.to(tdt(self.dt)).contiguous() for f in feats] if after is None else feats
             w = self._dev(words, torch.int32)
             sl = self._dev(seq_len, torch.int32)
             tg = self._dev(target, torch.float32) if target is not None else None
-            self.eng.forward(w, sl, c3, c4, c5, tg, feats_ready=after)
-            self._keep.append((w, sl, tg, c3, c4, c5))
+            imd = None
+            if self.v5 and self.cfg.hsv:
+                if im is None:
+                    raise ValueError("CMPCv5_BiLSTM_HSV_model needs the image feed (CMPCv5_BiLSTM_HSV_model.py:120-126)")
+                imd = self._dev(im, torch.float32)
+            if self.v5:
+                self.eng.forward(w, sl, None, c4, c5, tg, feats_ready=after, c2=f0, im=imd)
+            else:
+                self.eng.forward(w, sl, f0, c4, c5, tg, feats_ready=after)
+            self._keep.append((w, sl, tg, f0, c4, c5, imd))
             del self._keep[:-3]
             return self._fetch_dict(tg is not None)
 
@@ -220,23 +286,27 @@ class LSTM_model(object):
         """sess.run([pred, up, sigm, ...], {words, im, seq_len}) (test.py:286-296)."""
         self._check_feeds(words, im, seq_len)
         with torch.cuda.device(self.device):
-            feats, ev = self.features_async(im)
-            o = self.head(feats, words, seq_len, after=ev)
+            imd = self._dev(im, torch.float32)
+            feats, ev = self.features_async(imd)
+            o = self.head(feats, words, seq_len, after=ev, im=imd)
             B, T = self.batch_size, self.num_steps
-            return {"pred": o["pred"].clone(), "up": o["up"].clone(), "sigm": o["sigm"].clone(),
-                    "up_c3": o["up_c3"].clone(), "up_c4": o["up_c4"].clone(), "up_c5": o["up_c5"].clone(),
-                    "words_parse": o["words_parse"].view(B, 1, T, 4).clone(),
-                    # the reference keeps the attributes of the LAST level built, c3 (CMPC_model.py:395,399)
-                    "gw_w": o["gw_w_c3"][:, :, :T].clone(), "gw_v": o["gw_v_c3"][:, :, :T].clone()}
+            last = "c4" if self.v5 else "c3"            # the reference keeps the attributes of the LAST level built (CMPC_model.py:395,399)
+            out = {"pred": o["pred"].clone(), "up": o["up"].clone(), "sigm": o["sigm"].clone(),
+                   "up_c4": o["up_c4"].clone(), "up_c5": o["up_c5"].clone(),
+                   "words_parse": o["words_parse"].view(B, 1, T, 4).clone(),
+                   "gw_w": o[f"gw_w_{last}"][:, :, :T].clone(), "gw_v": o[f"gw_v_{last}"][:, :, :T].clone()}
+            if not self.v5:
+                out["up_c3"] = o["up_c3"].clone()
+            return out
 
     def predict(self, images, sentences, sequence_lenghts):
         """TF-serving signature of export_model_serving.py:57-71: images, sentences, sequence_lenghts -> masks."""
         return self.forward(sentences, images, sequence_lenghts)["sigm"]
 
-    def loss_and_grads(self, feats, words, target_fine, seq_len, after=None):
+    def loss_and_grads(self, feats, words, target_fine, seq_len, after=None, im=None):
         """forward + backward of `cost` (CMPC_model.py:447) into the flat gradient buffer: cmpc_forward + cmpc_backward
         (L2 and the x2 bias multiplier are applied inside the Adam kernel)."""
-        o = self.head(feats, words, seq_len, target_fine, after=after)
+        o = self.head(feats, words, seq_len, target_fine, after=after, im=im)
         with torch.cuda.device(self.device):
             self.eng.backward()
         return o
@@ -255,8 +325,11 @@ class LSTM_model(object):
             # first one's feeds / backbone taps (two alternating buffer sets) may still be read
             if len(self._inflight) >= self.MAX_STEPS_IN_FLIGHT:
                 self._inflight.pop(0).synchronize()
-            feats, ev = self.features_async(im, ready)
-            self.loss_and_grads(feats, words, target_fine, seq_len, after=ev)
+            if not torch.is_tensor(im):
+                ready = None                    # host feeds: the copy below is ordered on the caller's stream, which the backbone then waits for
+            imd = self._dev(im, torch.float32)
+            feats, ev = self.features_async(imd, ready)
+            self.loss_and_grads(feats, words, target_fine, seq_len, after=ev, im=imd)
             sv = self.eng.tap("scalars").clone()
             # Optimizer, bucket by bucket in the order the backward pass finalises them (exchange modules + ConvLSTM, levels c5 / c4 /
             # c3, text encoder): every bucket's Adam + repack waits on the device for that bucket only, so all but the last run
@@ -322,7 +395,8 @@ class LSTM_model(object):
 
 
 def get_segmentation_model(name, **kwargs):
-    """get_model.get_segmentation_model (get_model.py:15-17): name -> <module>.LSTM_model(**kwargs)."""
-    if name not in ("CMPC_model",):
-        raise ValueError("only CMPC_model is built in this round (got %r)" % (name,))
-    return LSTM_model(**kwargs)
+    """get_model.get_segmentation_model (get_model.py:15-17): name -> <module>.LSTM_model(**kwargs).  Built: CMPC_model,
+    CMPCv5_BiLSTM_model, CMPCv5_BiLSTM_HSV_model (get_model.py:1,10,11)."""
+    if name not in MODELS:
+        raise ValueError("model %r is not built (have: %s)" % (name, ", ".join(sorted(MODELS))))
+    return LSTM_model(model=name, **kwargs)

@@ -55,6 +55,18 @@ class HeadCfg:
     end_lr: float = 0.00001
     lr_power: float = 0.9
     weight_decay: float = 0.0005
+    # which graph (get_model.py:15-17): "CMPC_model" or "CMPCv5_BiLSTM_model" (+ hsv = CMPCv5_BiLSTM_HSV_model), and the latter's extra
+    # constructor arguments / hard-coded sizes (CMPCv5_BiLSTM_model.py:42,88,153,196,208,225)
+    model: int = 0
+    hsv: int = 0
+    bn_train: int = 0
+    bn_decay: float = 0.9997
+    c2_dim: int = 256
+    c2_h: int = 80
+    c2_w: int = 80
+    aspp_depth: int = 256
+    low_dim: int = 48
+    aspp_rates: tuple = (6, 12, 18)
 
     @property
     def N(self):

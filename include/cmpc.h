@@ -68,6 +68,9 @@ typedef struct {
     int rsplit;                         /* workgroups along the reduction */
     float alpha;
     const void* zeros;                  /* optional: >= 256 B of device zeros (enables the LDS-DMA pipeline for bf16) */
+    int conv_H, conv_W, conv_dy, conv_dx;   /* conv_W > 0: one tap of a convolution's weight gradient (CMPCv5_BiLSTM_model.py:203-204,235-237 via tf.gradients):
+                                           rows are the pixels (b, y, x) of [*, conv_H, conv_W] maps and row r of A is read at pixel (y + conv_dy, x + conv_dx),
+                                           as zeros outside the image; 0: plain product */
 } cmpc_gemm_tn_args;
 int cmpc_gemm_tn(const cmpc_gemm_tn_args* a, void* stream);
 /* n independent products in as few launches as possible (weight gradients deferred to the end of the backward
@@ -145,7 +148,8 @@ int cmpc_mutan_bwd(int dt, void* Th, const float* g, const void* X1, const float
  *      gw_w = softmax_T(mask*pr*A0 + (1-mask)*FLT_MIN), gw_v = softmax_N(pr*A0)*mask.
  *      f32 copies are kept for backward, dt copies ([B,N,Tp], pad columns 0) feed the GEMMs -- */
 /*      scratch: B * ceil(N/64) * 128 floats (per-chunk column statistics) */
-int cmpc_graph_softmax_fwd(int dt, const float* A0, const float* pr, const float* mask, float* gw_w, float* gw_v,
+/*      mask_after != 0: CMPCv5_BiLSTM_model.py:486-487 -- gw_w = mask * softmax_T(pr*A0): padded words stay in the softmax (their logit is 0) */
+int cmpc_graph_softmax_fwd(int dt, int mask_after, const float* A0, const float* pr, const float* mask, float* gw_w, float* gw_v,
                            void* gw_w_t, void* gw_v_t, float* scratch, int B, int N, int T, int Tp, void* stream);
 int cmpc_graph_softmax_bwd(int dt, const float* dgw_w, const float* dgw_v, const float* gw_w, const float* gw_v,
                            const float* A0, const float* pr, const float* mask, float* dA0, void* dA0_t, float* dpr,
@@ -173,7 +177,7 @@ int cmpc_softmax_n_bwd(const float* dattn, const float* attn, float* dlogits, in
 /* tf.nn.l2_normalize(gv_lang) with no axis -> over the whole [B, M] tensor (:241) */
 int cmpc_l2norm_all_fwd(const float* x, float* y, float* rstd1, int n, void* stream);
 int cmpc_l2norm_all_bwd(const float* dy, const float* y, const float* rstd1, float* dx, int n, void* stream);
-/* out = l2norm_rows(feat + r1*g1[b] + r2*g2[b])  (:256-258,272) */
+/* out = l2norm_rows(feat + r1*g1[b] + r2*g2[b])  (:256-258,272); r2 = g2 = NULL: one gated branch (CMPCv5_BiLSTM_model.py:343-346; dp2 / dg2 unused) */
 int cmpc_exchange_combine_fwd(int dt, const void* feat, const void* r1, const void* r2, const float* g1, const float* g2,
                               int ld_g, void* out, float* rstd, int B, int N, int ld, int C, void* stream);
 /* dfeat (+)= dE; dp1 = dE*g1*[r1>0]; dp2 likewise; dg1/dg2 [B][ld_g] += sum_n dE*r  */
@@ -242,6 +246,42 @@ int cmpc_lang_pool_fwd(const float* parse, const float* wf, float* v, float* rst
 int cmpc_lang_pool_bwd(const float* dv, const float* v, const float* rstd, const float* parse, const float* wf,
                        float* dparse, float* dwf, int B, int T, int ld, int R, int ncls, void* stream);
 
+/* ---- CMPCv5_BiLSTM_model.py ("v5:") / CMPCv5_BiLSTM_HSV_model.py ("hsv:") stages that CMPC_model does not have ----------------
+ * slim conv2d under resnet_v2.resnet_arg_scope (v5:192-193,229-230) = convolution without bias + batch_norm(decay, epsilon 1e-5,
+ * scale=True) + relu.  The convolution is a GEMM / cmpc_conv_nhwc; these entry points are the batch_norm around it.  X [R, ldx] holds the
+ * convolution output, C valid channels, Cpad >= C a multiple of 8 (row length of the statistics vectors).
+ *   cmpc_bn_stats       training mode: per-channel batch statistics.  sums double[2][Cpad] = {sum x, sum x^2} (kept for the moving-average
+ *                       update), mean_rstd float[2][Cpad] = {mean, 1/sqrt(biased var + eps)}
+ *   cmpc_bn_from_moving inference mode: mean_rstd from moving_mean / moving_variance
+ *   cmpc_bn_update_moving  UPDATE_OPS (v5:575-577): moving = decay * moving + (1 - decay) * batch, variance with Bessel's correction
+ *   cmpc_bn_apply_fwd   y[r, c] = relu?(gamma[c] * (x - mean) * rstd + beta[c]) for c < C, 0 for C <= c < Cy (pad channels of the destination
+ *                       block; y may be a column block of a wider map: row stride ldy)
+ *   cmpc_bn_bwd         training-mode backward: g = dy * [y > 0]; dbeta += sum g; dgamma += sum g * xhat;
+ *                       dx = gamma * rstd * (g - mean(g) - xhat * mean(g * xhat)); means_scratch float[2][Cpad] */
+int cmpc_bn_stats(int dt, const void* x, int ldx, int R, int C, int Cpad, float eps, double* sums, float* mean_rstd, void* stream);
+int cmpc_bn_from_moving(const float* moving_mean, const float* moving_var, int C, int Cpad, float eps, float* mean_rstd, void* stream);
+int cmpc_bn_update_moving(const double* sums, int R, float decay, float* moving_mean, float* moving_var, int C, int Cpad, void* stream);
+int cmpc_bn_apply_fwd(int dt, const void* x, int ldx, const float* mean_rstd, int Cpad, const float* gamma, const float* beta, void* y, int ldy, int Cy,
+                      int R, int C, int relu, void* stream);
+int cmpc_bn_bwd(int dt, const void* dy, int lddy, const void* y, int ldy, const void* x, int ldx, const float* mean_rstd, int Cpad, const float* gamma,
+                void* dx, int lddx, float* dgamma, float* dbeta, float* means_scratch, int R, int C, int relu, void* stream);
+/* tf.image.resize_bilinear (legacy, align_corners=False) of a whole map [B, h, w, C] -> [B, H, W, C] (v5:201,246) and its gradient; C % 8 == 0 */
+int cmpc_resize_bilinear_fwd(int dt, const void* x, int ldx, void* y, int ldy, int B, int h, int w, int H, int W, int C, void* stream);
+int cmpc_resize_bilinear_bwd(int dt, const void* dy, int lddy, void* dx, int lddx, int B, int h, int w, int H, int W, int C, void* stream);
+/* hsv:120-126: im f32 [B, H, W, 3] (BGR minus mean) -> + mean, reverse to RGB, tf.image.rgb_to_hsv, legacy bilinear to [h, w]: out [B*h*w, ld]
+ * (3 channels, the rest of the row zero) */
+int cmpc_hsv_map(int dt, const float* im, void* out, int ld, int B, int H, int W, int h, int w, void* stream);
+/* array_ops.reverse_sequence of bidirectional_dynamic_rnn (v5:170-174) on [B, T, ld] float rows (not in place), and the time-major word ids of
+ * the reversed sequences: out_tb[t * B + b] = words[b, t < len ? len - 1 - t : t] */
+int cmpc_reverse_sequence(const float* in, float* out, const int* seq_len, int B, int T, int ld, void* stream);
+int cmpc_reverse_words_tb(const int* words, const int* seq_len, int* out_tb, int B, int T, void* stream);
+/* seq_mask of v5:181: mask[r] = (sum_c |a[r, c]| + |b[r, c]|) != 0 */
+int cmpc_rows_nonzero2(const float* a, const float* b, float* mask, int rows, int ld, int C, void* stream);
+/* the decoder's last 1x1 convolution to ONE channel (v5:205): out[r] = x[r, :C] . w + bias[0]; backward: dx[r, :] = d[r] * w, dw += sum_r d[r] x[r, :],
+ * dbias += sum_r d[r] */
+int cmpc_conv_to1_fwd(int dt, const void* x, int ld, const float* w, const float* bias, float* out, int R, int C, void* stream);
+int cmpc_conv_to1_bwd(int dt, const float* d, const void* x, int ld, const float* w, void* dx, float* dw, float* dbias, int R, int C, void* stream);
+
 /* ---- parameters: packing fp32 masters into padded GEMM operands; TF-Adam (CMPC_model.py:450-478)
  *      with L2 on 'DW' (:433,446, util/loss.py:28-32) and x2 on 'biases' (:464-465) folded in ---- */
 typedef struct {
@@ -304,9 +344,24 @@ typedef struct {
     int n_lanes;                        /* 3: pyramid levels / exchange modules on three lane streams; 1: one stream */
     int device;                         /* HIP device ordinal; -1 = planning only (manifest, operand plan, workspace size:
                                            no GPU is touched; every compute entry point then returns CMPC_EINVAL) */
+    /* which graph: get_model.get_segmentation_model(name) (get_model.py:15-17) */
+    int model;                          /* CMPC_MODEL_CMPC (CMPC_model.py) or CMPC_MODEL_V5_BILSTM (CMPCv5_BiLSTM_model.py: BiLSTM encoder, levels c5 / c4,
+                                           one gated branch, 2-step ConvLSTM, ASPP + DeepLabv3+ decoder on res2b_relu with slim batch-norm) */
+    int hsv;                            /* model V5_BILSTM: CMPCv5_BiLSTM_HSV_model.py -- HSV of the image appended to the c5 / c4 taps (hsv:120-134) */
+    int bn_train;                       /* model V5_BILSTM: batch_norm(is_training = mode == 'train') (v5:153-154): 1 = batch statistics (+ moving-average
+                                           updates in the train step), 0 = moving statistics */
+    float bn_decay;                     /* batch_norm_decay (v5:42), 0.9997 */
+    int c2_dim, c2_h, c2_w;             /* res2b_relu tap (v5:88): channels (256) and map size (H/4 x W/4) */
+    int aspp_depth, low_dim;            /* 256 (v5:208), 48 (v5:196) */
+    int aspp_rates[3];                  /* 6, 12, 18: output_stride 16 (v5:153,225) */
 } cmpc_cfg;
+#define CMPC_MODEL_CMPC 0
+#define CMPC_MODEL_V5_BILSTM 1
 /* fills *cfg with the reference's defaults (CMPC_model.py:15-40), f16 storage (the 16-bit mode that meets the 1e-4 mean-IoU bar), 3 lanes, device 0 */
 int cmpc_default_cfg(cmpc_cfg* cfg);
+/* the same for a given model: CMPC_MODEL_V5_BILSTM sets loss_w = 0.8, 0.1, 0.1, 0 (v5:541-542), bn_train 1, bn_decay 0.9997, c2_dim 256, c2_h = H / 4,
+ * c2_w = W / 4, aspp_depth 256, low_dim 48, rates 6 / 12 / 18 -- vf_h, vf_w, H, W must be set by the caller BEFORE (v5:52-53 does not derive them) */
+int cmpc_default_cfg_model(cmpc_cfg* cfg, int model, int hsv);
 int cmpc_create(const cmpc_cfg* cfg, cmpc_handle* out);
 int cmpc_destroy(cmpc_handle h);
 /* the configuration in effect (defaults resolved, e.g. loss_scale) */
@@ -325,6 +380,12 @@ int cmpc_set_weights(cmpc_handle h, const char* name, const float* host_src, int
 int cmpc_get_weights(cmpc_handle h, const char* name, float* host_dst, int64_t count);
 /* masters -> padded GEMM operands (after cmpc_set_weights, or after the caller modified the master buffer) */
 int cmpc_pack(cmpc_handle h, void* stream);
+/* non-trainable variables of the graph (model V5_BILSTM: the batch-norm moving statistics `text_objseg/<scope>/BatchNorm/moving_mean|moving_variance`,
+ * updated by the UPDATE_OPS of v5:575-577 inside cmpc_backward; none for CMPC_model): enumerate, read, write (host pointers, float32) */
+int cmpc_state_count(cmpc_handle h);
+int cmpc_state_info(cmpc_handle h, int index, const char** name, int64_t* count);
+int cmpc_get_state(cmpc_handle h, const char* name, float* host_dst, int64_t count);
+int cmpc_set_state(cmpc_handle h, const char* name, const float* host_src, int64_t count);
 /* global_step (CMPC_model.py:450) get / set (checkpoint resume, trainval_model.py:82 -lastiter) */
 int cmpc_get_step(cmpc_handle h, int64_t* step);
 int cmpc_set_step(cmpc_handle h, int64_t step);
@@ -338,6 +399,8 @@ typedef struct {
     const float* target_fine;   /* [B, H, W, 1] or NULL for inference (:69) */
     void* feats_ready;          /* optional hipEvent_t recorded (on any stream) once c3/c4/c5 are complete: the text encoder
                                    is enqueued first and only the pyramid levels wait for it; NULL = ordered on `stream` */
+    const void* c2;             /* model V5_BILSTM: res2b_relu [B, c2_h, c2_w, c2_dim] NHWC, cfg.dtype (v5:88); c3 is unused there (may be NULL) */
+    const float* im;            /* model V5_BILSTM with hsv: the image feed itself [B, H, W, 3] f32, BGR minus mean (v5:80; hsv:120-126) */
 } cmpc_feeds;
 typedef struct {                /* optional caller-owned device buffers the fetches are copied into (NULL = skip) */
     float* pred;                /* [B, vf_h, vf_w, 1] logits (CMPC_model.py:140) */

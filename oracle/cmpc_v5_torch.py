@@ -425,7 +425,8 @@ def backbone_taps(bp, im, cfg: Cfg):
 
 
 def tiny_cfg(B=2, T=6, hw=8, C=40, M=24, hsv=False, train_mode=True):
-    """Shrunken graph: backbone width 8 -> res2b 32 ch, res4 128, res5 256; ASPP depth 16 (rates 1, 3, 6: the last leaves most taps outside the 8x8 map), 8 low-level ch."""
-    return Cfg(batch_size=B, num_steps=T, vf_h=hw, vf_w=hw, H=hw * 8, W=hw * 8, vf_dim=256, c4_dim=128, c3_dim=64,
+    """Shrunken graph: backbone width 16 -> res2b 64 ch, res4 256, res5 512; ASPP depth 16 (rates 1, 3, 6: the last leaves most taps
+    outside the 8x8 map), 8 low-level channels."""
+    return Cfg(batch_size=B, num_steps=T, vf_h=hw, vf_w=hw, H=hw * 8, W=hw * 8, vf_dim=512, c4_dim=256, c3_dim=128,
                vocab_size=50, v_emb_dim=C, mlp_dim=M, rnn_size=C, glove_dim=12, parse_dim=20,
-               backbone_width=8, backbone_blocks=(2, 1, 2, 1), hsv=hsv, aspp_depth=16, low_dim=8, aspp_rates=(1, 3, 6), train_mode=train_mode)
+               backbone_width=16, backbone_blocks=(2, 1, 2, 1), hsv=hsv, aspp_depth=16, low_dim=8, aspp_rates=(1, 3, 6), train_mode=train_mode)

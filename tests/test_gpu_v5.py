@@ -1,0 +1,237 @@
+"""GPU parity tests of the CMPCv5_BiLSTM path (BASELINE.json config 4; reference CMPCv5_BiLSTM_model.py and its HSV variant): the HIP
+path through the C ABI against the oracle (oracle/cmpc_v5_torch.py) on identical seeded inputs.  fp32 mode: every tap 2e-5, parameter
+gradients 3e-4; f16 storage: taps 8e-3; mean-IoU delta <= 1e-4 at 512x512, L = 25 (vf_h = vf_w = 64) in fp32 and f16.  PARITY
+UNPINNED against TensorFlow itself (absent), like the rest of the path."""
+import importlib
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from tests import util as U
+from oracle import cmpc_torch as O
+from oracle import cmpc_v5_torch as V
+
+pytestmark = pytest.mark.gpu
+
+
+def model_kwargs(cfg, dtype="f32", mode="train"):
+    kw = U.model_kwargs(cfg, dtype, mode)
+    kw.update(aspp_depth=cfg.aspp_depth, low_dim=cfg.low_dim, aspp_rates=cfg.aspp_rates, batch_norm_decay=cfg.batch_norm_decay)
+    return kw
+
+
+def _name(cfg):
+    return "CMPCv5_BiLSTM_HSV_model" if cfg.hsv else "CMPCv5_BiLSTM_model"
+
+
+def make_case(hsv=False, train=True, seed=0, B=2):
+    torch.set_num_threads(8)
+    cfg = V.tiny_cfg(B=B, hsv=hsv, train_mode=train)
+    hp, bp, bn = V.init_head_params(cfg), O.init_backbone_params(cfg), V.init_bn_state(cfg)
+    g = torch.Generator().manual_seed(5)
+    for k in bn:            # non-trivial moving statistics; non-zero biases / beta (padded words then survive conv + tanh)
+        bn[k] = (torch.rand(bn[k].shape, generator=g) * 0.5 + (0.75 if k.endswith("variance") else -0.25)).float()
+    for k in hp:
+        if k.endswith(("biases", "beta")):
+            hp[k] = (torch.randn(hp[k].shape, generator=g) * 0.05).float()
+    words, im, sl, tgt = O.synth_batch(cfg, seed=seed)
+    feats = V.backbone_taps(bp, im, cfg)
+    return dict(cfg=cfg, hp=hp, bp=bp, bn=bn, words=words, im=im, sl=sl, tgt=tgt, feats=feats)
+
+
+def build(case, dtype, mode="train"):
+    P = U.pkg()
+    m = P.get_segmentation_model(_name(case["cfg"]), head_params=case["hp"], backbone_params=case["bp"], **model_kwargs(case["cfg"], dtype, mode))
+    m.load_extra_vars({k: v.numpy() for k, v in case["bn"].items()})
+    return m
+
+
+def taps_as_oracle(o, cfg):
+    B, T, h, w, C, M, D = cfg.batch_size, cfg.num_steps, cfg.vf_h, cfg.vf_w, cfg.v_emb_dim, cfg.mlp_dim, cfg.aspp_depth
+    h2, w2 = cfg.H // 4, cfg.W // 4
+    Dp = (D + 63) // 64 * 64
+    f = lambda x: x.detach().float().cpu()
+    out = {"words_feat": f(o["words_feat"]).view(B, T, -1)[..., :C].reshape(B, 1, T, C), "seq_mask": f(o["seq_mask"]).view(B, 1, T, 1),
+           "words_parse": f(o["words_parse"]).view(B, 1, T, 4), "nec_lang": f(o["nec_lang"])[:, :C].reshape(B, 1, 1, C),
+           "bilstm_out": torch.cat([f(o["bilstm_fw"]).view(B, T, -1)[..., :C], f(o["bilstm_bw"]).view(B, T, -1)[..., :C]], -1).view(B, 1, T, 2 * C)}
+    for lv in V.LEVELS:
+        for k, c in (("lat", C), ("vis_la_sp", C), ("spa_graph", C), ("fusion", M)):
+            out[f"{k}_{lv}"] = U.unpad_map(o[f"{k}_{lv}"], B, h, w, c)
+        out[f"gw_w_{lv}"], out[f"gw_v_{lv}"] = f(o[f"gw_w_{lv}"])[:, :, :T], f(o[f"gw_v_{lv}"])[:, :, :T]
+        out[f"score_{lv}"], out[f"up_{lv}"] = f(o[f"score_{lv}"]), f(o[f"up_{lv}"])
+    for k in ("exg_c4", "exg_c5", "exg_c4_2", "exg_c5_2", "fused"):
+        out[k] = U.unpad_map(o[k], B, h, w, M)
+    br = f(o["aspp_branches"]).view(B, h, w, 4, Dp)[..., :D].reshape(B, h, w, 4 * D)
+    out["aspp_branches"] = br
+    out["aspp_image"] = f(o["aspp_image"])[:, :D]
+    out["aspp"] = U.unpad_map(o["aspp"], B, h, w, D)
+    dc = f(o["dec_cat"]).view(B, h2, w2, -1)
+    out["dec_cat"] = torch.cat([dc[..., :D], dc[..., Dp:Dp + cfg.low_dim]], -1)
+    out["dec_net2"] = U.unpad_map(o["dec_net2"], B, h2, w2, D)
+    if cfg.hsv:
+        out["hsv"] = U.unpad_map(o["hsv"], B, h, w, 3)
+    for k in ("pred", "up", "sigm"):
+        out[k] = f(o[k])
+    return out
+
+
+def ref_grad(case, grads, n):
+    flags = {k: f for k, _, _, f in V.head_param_specs(case["cfg"])}
+    g = grads[n] / (2.0 if "x2" in flags[n] else 1.0)
+    return g - case["cfg"].weight_decay * case["hp"][n] if "reg" in flags[n] else g
+
+
+@pytest.mark.parametrize("hsv", [False, True])
+def test_v5_forward_backward_fp32_matches_oracle(hsv):
+    case = make_case(hsv=hsv)
+    cfg = case["cfg"]
+    scal, grads, taps, new_bn = V.grads_of(case["hp"], case["bn"], case["feats"], case["words"], case["sl"], case["tgt"], cfg, im=case["im"])
+    m = build(case, "f32")
+    o = m.loss_and_grads([f.to(m.device) for f in case["feats"]], case["words"], case["tgt"], case["sl"], im=case["im"])
+    torch.cuda.synchronize()
+    pt = taps_as_oracle(o, cfg)
+    for k, ref in taps.items():
+        assert U.rel_err(pt[k], ref) < 2e-5, k
+    for k in ("loss_c5", "loss_c4", "loss_last", "loss_all"):
+        assert abs(float(o[k]) - scal[k]) <= 1e-5 * abs(scal[k]), k
+    assert float(o["loss_c3"]) == 0.0 and abs(float(o["mIoU"]) - scal["mIoU"]) <= 1e-4
+    g = m.store.grad_dict()
+    assert set(g) == set(grads)
+    worst = ("", 0.0)
+    for n in grads:
+        ref = ref_grad(case, grads, n)
+        if "spa_graph_key" in n and n.endswith("biases"):
+            assert float(g[n].abs().max()) == 0.0 and float(ref.abs().max()) < 1e-5       # softmax over nodes is invariant to b_k . q
+            continue
+        tol = 3e-3 if ("spa_graph_trans2" in n and n.endswith("biases")) else 3e-4
+        err = U.rel_err(g[n], ref)
+        worst = max(worst, (n, err), key=lambda kv: kv[1])
+        assert err < tol, (n, err)
+    print("v5 fp32 worst gradient error:", worst)
+    # UPDATE_OPS ran in the backward pass (v5:575-577)
+    st = m.extra_vars()
+    for k, ref in new_bn.items():
+        assert np.abs(st[k] - ref.numpy()).max() <= 1e-6 * max(1.0, float(ref.abs().max())), k
+
+
+def test_v5_inference_mode_uses_moving_statistics():
+    case = make_case(hsv=True, train=False)
+    cfg = case["cfg"]
+    with torch.no_grad():
+        taps = V.head_forward(case["hp"], case["bn"], case["feats"], case["words"], case["sl"], cfg, im=case["im"])
+    m = build(case, "f32", mode="eval")
+    out = m.forward(case["words"], case["im"], case["sl"])
+    B, H, W = cfg.batch_size, cfg.H, cfg.W
+    assert tuple(out["pred"].shape) == (B, H // 4, W // 4, 1) and tuple(out["up"].shape) == (B, H, W, 1) and "up_c3" not in out
+    assert U.rel_err(out["up"].float().cpu(), taps["up"]) < 1e-4 and U.rel_err(out["gw_v"].float().cpu(), taps["gw_v_c4"]) < 2e-5
+    before = m.extra_vars()
+    m.forward(case["words"], case["im"], case["sl"])
+    after = m.extra_vars()
+    assert all(np.array_equal(before[k], after[k]) for k in before)            # no UPDATE_OPS outside the train step
+    with pytest.raises(RuntimeError):
+        m.train_step(case["words"], case["im"], case["tgt"], case["sl"])
+
+
+def test_v5_f16_within_tolerance():
+    case = make_case(hsv=True)
+    cfg = case["cfg"]
+    scal, grads, taps, _ = V.grads_of(case["hp"], case["bn"], case["feats"], case["words"], case["sl"], case["tgt"], cfg, im=case["im"])
+    m = build(case, "f16")
+    o = m.loss_and_grads([f.to(m.device) for f in case["feats"]], case["words"], case["tgt"], case["sl"], im=case["im"])
+    torch.cuda.synchronize()
+    pt = taps_as_oracle(o, cfg)
+    for k, ref in taps.items():
+        assert U.rel_err(pt[k], ref) < 1e-2, k
+    assert abs(float(o["loss_all"]) - scal["loss_all"]) <= 5e-3 * abs(scal["loss_all"])
+    g = m.store.grad_dict()
+    assert all(torch.isfinite(v).all() for v in g.values()) and m.grad_nonfinite() == 0
+    errs = {n: round(U.rel_err(g[n], ref_grad(case, grads, n)), 5) for n in (
+        "text_objseg/aspp/conv_3x3_2/weights", "text_objseg/decoder/upsampling_logits/conv_3x3_1/weights", "text_objseg/aspp/conv_1x1_concat/weights",
+        "text_objseg/decoder/low_level_features/conv_1x1/BatchNorm/gamma", "text_objseg/fusion_c5/DW", "text_objseg/rnn/conv_lstm_cell/kernel",
+        "text_objseg/bidirectional_rnn/bw/lstm_cell/kernel", "text_objseg/words_feat/DW", "text_objseg/c4_lateral/DW")}
+    print("v5 f16 gradient errors:", errs)
+    assert max(errs.values()) < 5e-2, errs
+
+
+def test_v5_train_steps_match_tf_adam_and_are_bit_identical():
+    """Three full train steps (backbone included) twice: TF-Adam parameters and the batch-norm moving statistics follow the oracle, and
+    the two runs agree bit for bit (fixed-order sums everywhere, also in the new batch-norm / resize / convolution-gradient kernels)."""
+    case = make_case(hsv=True)
+    cfg = case["cfg"]
+    hp = {k: v.clone() for k, v in case["hp"].items()}
+    bn = {k: v.clone() for k, v in case["bn"].items()}
+    opt = O.TFAdam(hp)
+    runs = []
+    for run in range(2):
+        m = build(case, "f32")
+        for step in range(3):
+            s, scal = m.train_step(case["words"], case["im"], case["tgt"], case["sl"])
+            if run == 0:
+                ref = V.train_step(hp, bn, opt, step, case["feats"], case["words"], case["sl"], case["tgt"], cfg, im=case["im"])
+                assert s == step + 1 and abs(float(scal["loss_all"]) - ref["loss_all"]) <= 3e-4 * abs(ref["loss_all"]), (step, float(scal["loss_all"]), ref["loss_all"])
+        torch.cuda.synchronize()
+        runs.append((m.eng.params.clone(), m.extra_vars(), m.state_dict()))
+    (pa, sa, sd), (pb, sb, _) = runs
+    assert torch.equal(pa, pb) and all(np.array_equal(sa[k], sb[k]) for k in sa)
+    lr = cfg.start_lr
+    for n, ref in hp.items():
+        if "spa_graph_key" in n and n.endswith("biases"):
+            continue
+        assert float((sd[n] - ref).abs().max()) <= 0.35 * lr, n
+    for k, ref in bn.items():
+        assert np.abs(sa[k] - ref.numpy()).max() <= 2e-6 * max(1.0, float(ref.abs().max())), k
+
+
+def test_v5_checkpoint_round_trip_with_moving_statistics(tmp_path):
+    CK = importlib.import_module("cmpc-refseg_amd.checkpoint")
+    case = make_case()
+    a = build(case, "f32")
+    a.train_step(case["words"], case["im"], case["tgt"], case["sl"])
+    path = CK.Saver(fmt="tf").save(a, str(tmp_path / "v5"))
+    names = set(importlib.import_module("cmpc-refseg_amd.tf_bundle").list_variables(path))
+    assert {"text_objseg/aspp/conv_3x3_1/BatchNorm/moving_variance", "text_objseg/text_objseg/aspp/conv_3x3_1/weights/Adam",
+            "text_objseg/bidirectional_rnn/bw/lstm_cell/kernel", "text_objseg/Variable_1"} <= names
+    case2 = make_case(seed=3)
+    b = build(case2, "f32")
+    CK.Saver().restore(b, path)
+    assert torch.equal(a.eng.params, b.eng.params) and b.eng.step == 1
+    sa, sb = a.extra_vars(), b.extra_vars()
+    assert all(np.array_equal(sa[k], sb[k]) for k in sa)
+
+
+@pytest.mark.parametrize("hsv", [True])
+def test_config4_full_size_mean_iou_delta_vs_oracle(hsv):
+    """BASELINE.json config 4: CMPCv5_BiLSTM (+ HSV branch) at 512x512, L = 25, vf_h = vf_w = 64 (N = 4096: the adjacency is never formed),
+    ResNet-101 taps res2b / res4b22 / res5c, batch-norm in training mode.  |mean-IoU(HIP) - mean-IoU(oracle)| <= 1e-4 in fp32 and f16
+    storage on identical inputs and weights; B = 2 keeps the CPU oracle (which does form two 4096 x 4096 adjacencies per image) to ~1 min."""
+    from bench import synth_batch
+    torch.set_num_threads(16)
+    B = 2
+    cfg = V.Cfg(batch_size=B, num_steps=25, vf_h=64, vf_w=64, H=512, W=512, hsv=hsv)
+    hp, bp, bn = V.init_head_params(cfg), O.init_backbone_params(cfg), V.init_bn_state(cfg)
+    w, im, sl, tg = map(torch.from_numpy, synth_batch(B, 25, 512, 512, cfg.vocab_size, 21))
+    with torch.no_grad():
+        feats = V.backbone_taps(bp, im, cfg)
+        taps = V.head_forward(hp, bn, feats, w, sl, cfg, im=im)
+        ref = V.losses(hp, taps, tg, cfg)
+    P = U.pkg()
+    res = {}
+    for dtype in ("f32", "f16"):
+        m = P.get_segmentation_model(_name(cfg), batch_size=B, num_steps=25, vf_h=64, vf_w=64, H=512, W=512, mode="train", dtype=dtype,
+                                     head_params=hp, backbone_params=bp)
+        with torch.no_grad():
+            o = m.head(m.features(im), w, sl, tg, im=im)
+        torch.cuda.synchronize()
+        up = o["up"].float().cpu()
+        res[dtype] = (abs(float(o["mIoU"]) - float(ref["mIoU"])), int(((up > 0) != (taps["up"] > 0)).sum()), U.rel_err(up, taps["up"]),
+                      abs(float(o["loss_all"]) - float(ref["loss_all"])) / abs(float(ref["loss_all"])))
+        gw = o["gw_w_c5"][:, :, :25].float()
+        for b in range(B):
+            assert torch.all(gw[b, :, int(sl[b]):] == 0)
+        del m, o
+        torch.cuda.empty_cache()
+    print("config 4 parity:", {k: f"dIoU={v[0]:.2e} flipped_px={v[1]} up_rel_err={v[2]:.2e} loss_rel={v[3]:.1e}" for k, v in res.items()}, "oracle mIoU", float(ref["mIoU"]))
+    assert res["f32"][0] <= 1e-4 and res["f32"][2] < 1e-3
+    assert res["f16"][0] <= 1e-4 and res["f16"][2] < 2e-2
