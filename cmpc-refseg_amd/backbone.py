@@ -64,9 +64,11 @@ def param_specs(width: int = 64, blocks=(3, 4, 23, 3)) -> List[Tuple[str, Tuple[
     return specs
 
 
-def init_params(width: int = 64, blocks=(3, 4, 23, 3), seed: int = 4321) -> Dict[str, torch.Tensor]:
+def init_params(width: int = 64, blocks=(3, 4, 23, 3), seed: int = 4321, stem_gamma: float = 1.0) -> Dict[str, torch.Tensor]:
     """Synthetic weights (deeplab_resnet_init.ckpt, trainval_model.py:50, is not in the reference tree):
-    He-normal convolutions; BN gamma 1 (0.2 on each block's last BN), beta 0, mean 0, variance 1."""
+    He-normal convolutions; BN gamma 1 (0.2 on each block's last BN), beta 0, mean 0, variance 1.  stem_gamma scales bn_conv1/gamma
+    and with it every tap (the frozen inference network is positively homogeneous): the CMPCv5 models use 1/256 so that random weights
+    give taps of rms ~1 like a trained network's instead of ~1e3 (the image's 0..255 scale), which would saturate their tanh laterals."""
     g = torch.Generator().manual_seed(seed)
     out = {}
     for name, shape in param_specs(width, blocks):
@@ -74,7 +76,7 @@ def init_params(width: int = 64, blocks=(3, 4, 23, 3), seed: int = 4321) -> Dict
             fan_in = shape[0] * shape[1] * shape[2]
             t = torch.randn(shape, generator=g, dtype=torch.float64) * math.sqrt(2.0 / fan_in)
         elif name.endswith("/gamma"):
-            t = torch.full(shape, 0.2 if "branch2c" in name else 1.0, dtype=torch.float64)
+            t = torch.full(shape, 0.2 if "branch2c" in name else (stem_gamma if name == "bn_conv1/gamma" else 1.0), dtype=torch.float64)
         elif name.endswith("/moving_variance"):
             t = torch.ones(shape, dtype=torch.float64)
         else:

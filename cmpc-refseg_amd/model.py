@@ -113,7 +113,8 @@ class LSTM_model(object):
             if self.v5:
                 self.backbone.taps_wanted = ("2b", 4, 5)      # res2b_relu, res4b22_relu, res5c_relu (CMPCv5_BiLSTM_model.py:86-88)
             # the frozen backbone's variables under their TensorFlow names (deeplab_resnet/model.py): kept for checkpoints
-            self.backbone_vars = dict(backbone_params if backbone_params is not None else bb.init_params(backbone_width, backbone_blocks))
+            self.backbone_vars = dict(backbone_params if backbone_params is not None else
+                                      bb.init_params(backbone_width, backbone_blocks, stem_gamma=1.0 / 256.0 if self.v5 else 1.0))
             self.backbone.load_tf(self.backbone_vars)
             self.backbone = self.backbone.to(self.device).to(tdt(self.dt)).to(memory_format=torch.channels_last).eval()
         self.world, self.dp_on = 1, False

@@ -418,6 +418,20 @@ def train_step(p, bn, opt: O.TFAdam, step, feats, words, seq_len, target_fine, c
     return scal
 
 
+STEM_GAMMA = 1.0 / 256.0
+
+
+def init_backbone_params(cfg: Cfg, seed: int = 4321, dtype=torch.float32):
+    """Synthetic backbone for the CMPCv5 graphs: O.init_backbone_params with bn_conv1/gamma = 1/256.  The frozen inference network is
+    positively homogeneous (convolutions, ReLU, BN with beta = mean = 0), so the image's 0..255 scale otherwise reaches the taps as
+    |x| ~ 1e3: harmless for CMPC_model, whose laterals are scale-invariant (l2_normalize right behind a linear conv), but it drives
+    CMPCv5's tanh laterals (v5:121,124) into saturation with a few hypersensitive unsaturated units -- an artefact of random weights
+    (trained ResNet taps are O(1)), which would make every parity number a statement about that artefact.  1/256 gives taps of rms ~1."""
+    bp = O.init_backbone_params(cfg, seed=seed, dtype=dtype)
+    bp["bn_conv1/gamma"] = bp["bn_conv1/gamma"] * STEM_GAMMA
+    return bp
+
+
 def backbone_taps(bp, im, cfg: Cfg):
     """(c2, c4, c5) = res2b_relu, res4b22_relu, res5c_relu (v5:86-88)."""
     _, c4, c5, c2 = O.backbone_forward(bp, im, cfg, extra_taps=("2b",))

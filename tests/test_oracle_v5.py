@@ -14,7 +14,7 @@ def _case(hsv, train, dtype=torch.float64, seed=0):
     torch.set_num_threads(2)
     cfg = V.tiny_cfg(hsv=hsv, train_mode=train)
     hp = V.init_head_params(cfg, dtype=dtype)
-    bp = O.init_backbone_params(cfg, dtype=dtype)
+    bp = V.init_backbone_params(cfg, dtype=dtype)
     bn = V.init_bn_state(cfg, dtype=dtype)
     g = torch.Generator().manual_seed(5)
     for k in bn:                                   # non-trivial moving statistics so that the inference mode is exercised
