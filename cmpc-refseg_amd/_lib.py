@@ -217,6 +217,8 @@ SIGNATURES = {
     "cmpc_phase_marks_read": [_P, _I, C.POINTER(C.c_char_p), C.POINTER(C.c_float)],
     "cmpc_set_lanes": [_P, _I],
     "cmpc_dense_crf": [_P, _P, _I, _I, _F, _F, _F, _F, _F, _I, _P, _P, _P],
+    "cmpc_launch_trace": [_I, _P],
+    "cmpc_launch_trace_read": [_I, C.POINTER(C.c_char_p), C.POINTER(C.c_double), C.POINTER(_L)],
     "cmpc_kernel_timing": [_P, _I],
     "cmpc_kernel_timing_read": [_P, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(_L)],
     "cmpc_plan_info": [_P, C.POINTER(C.POINTER(PackDesc)), C.POINTER(_I), C.POINTER(_L), C.POINTER(_L), C.POINTER(_I)],

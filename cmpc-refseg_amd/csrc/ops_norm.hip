@@ -8,6 +8,7 @@
 #include <stdio.h>
 #include <string.h>
 #include <mutex>
+#include <vector>
 
 // ------------------------------------------------------------------------------------------
 // error plumbing shared by all translation units
@@ -17,10 +18,53 @@ void cmpc_set_error(const char* fmt, ...) {
     va_list ap; va_start(ap, fmt); vsnprintf(g_err, sizeof(g_err), fmt, ap); va_end(ap);
 }
 long g_cmpc_launches = 0;          // host-side count of checked launches (cmpc_launch_count)
+// Launch trace (cmpc_launch_trace): while enabled, every checked launch is followed by a hipEvent on the ONE stream the caller named, so
+// that on an in-order stream the interval between consecutive events is that launch's duration (what rocprofv3 --kernel-trace reports,
+// without a profiler).  Durations are summed per launch name (string literals: the pointers are stable).
+static bool g_trace_on = false;
+static hipStream_t g_trace_stream = nullptr;
+static std::vector<std::pair<const char*, hipEvent_t>> g_trace;
 int cmpc_check_launch(const char* what) {
     ++g_cmpc_launches;
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { cmpc_set_error("%s: %s", what, hipGetErrorString(e)); return CMPC_EHIP; }
+    if (g_trace_on) {
+        hipEvent_t ev = nullptr;
+        if (hipEventCreate(&ev) == hipSuccess) { (void)hipEventRecord(ev, g_trace_stream); g_trace.push_back({what, ev}); }
+    }
+    return CMPC_OK;
+}
+extern "C" int cmpc_launch_trace(int enable, void* stream) {
+    for (auto& t : g_trace) (void)hipEventDestroy(t.second);
+    g_trace.clear();
+    g_trace_on = false;
+    if (enable) {
+        g_trace_stream = (hipStream_t)stream;
+        g_trace_on = true;
+        cmpc_check_launch("(start)");          // the reference point of the first interval
+        --g_cmpc_launches;
+    }
+    return CMPC_OK;
+}
+// per-name totals of the trace recorded so far: index 0 .. n-1 (CMPC_EINVAL past the end); synchronises the traced stream's events
+extern "C" int cmpc_launch_trace_read(int index, const char** name, double* ms, int64_t* launches) {
+    static std::vector<std::pair<const char*, std::pair<double, int64_t>>> agg;
+    if (index == 0) {
+        agg.clear();
+        g_trace_on = false;
+        for (size_t i = 1; i < g_trace.size(); ++i) {
+            if (hipEventSynchronize(g_trace[i].second) != hipSuccess) { cmpc_set_error("launch_trace_read: event"); return CMPC_EHIP; }
+            float d = 0.f;
+            if (hipEventElapsedTime(&d, g_trace[i - 1].second, g_trace[i].second) != hipSuccess) d = 0.f;
+            bool found = false;
+            for (auto& a : agg) if (a.first == g_trace[i].first || strcmp(a.first, g_trace[i].first) == 0) { a.second.first += d; a.second.second += 1; found = true; break; }
+            if (!found) agg.push_back({g_trace[i].first, {(double)d, 1}});
+        }
+    }
+    if (index < 0 || index >= (int)agg.size()) return CMPC_EINVAL;
+    if (name) *name = agg[index].first;
+    if (ms) *ms = agg[index].second.first;
+    if (launches) *launches = agg[index].second.second;
     return CMPC_OK;
 }
 extern "C" const char* cmpc_last_error(void) { return g_err; }

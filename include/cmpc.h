@@ -457,6 +457,12 @@ int cmpc_phase_marks_read(cmpc_handle h, int index, const char** name, float* ms
 int cmpc_set_lanes(cmpc_handle h, int n_lanes);      /* 1 or 3; takes effect from the next cmpc_forward */
 int cmpc_kernel_timing(cmpc_handle h, int enable);
 int cmpc_kernel_timing_read(cmpc_handle h, double* ms, double* flops, double* bytes, int64_t* launches);
+/* Launch trace without a profiler (process-wide): while enabled, every launch of this library is followed by a hipEvent on `stream`, so that
+ * with EVERYTHING on that one in-order stream (cmpc_set_lanes(h, 1), no side streams) the interval between consecutive events is the launch's
+ * duration -- what `rocprofv3 --kernel-trace --stats` reports.  cmpc_launch_trace_read(i) -> per-name totals (name, summed ms, launches),
+ * CMPC_EINVAL past the last name; index 0 ends the recording.  bench.py prices the HBM-bound stage kernels against their byte model with it. */
+int cmpc_launch_trace(int enable, void* stream);
+int cmpc_launch_trace_read(int index, const char** name, double* ms, int64_t* launches);
 /* number of kernel launches / memsets the last forward+backward+optimizer_step issued (host-side counter) */
 int cmpc_launch_count(cmpc_handle h, int64_t* n);
 
