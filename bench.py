@@ -124,6 +124,58 @@ def config4_rate(pkg, dev, args, B=8):
     return out
 
 
+def stage_model(B, es=2, N=1600, T=20, C=1000, M=500, H=320, W=320, n_params=76055608):
+    """Algorithmic work per train step of every launch name of CMPC_model (3 levels, 6 exchange modules, 3 ConvLSTM steps; SURVEY 8d's
+    compulsory-traffic model: a stage reads its unique inputs once and writes its outputs once; a kernel that passes over its input
+    twice shows up as a lower fraction).  name -> ("hbm", bytes) | ("mfma", flops) | ("latency", 0): the small language-side launches
+    ([B, .] / [B*T, .] rows) and the partial-row folds are launch-latency bound and carry no byte model."""
+    R, Cp, Mp, Tp = B * N, 1024, 512, 64
+    MC, MM, AT, AT2, UP = R * Cp * es, R * Mp * es, R * Tp * 4, R * Tp * es, B * H * W * 4
+    hbm = {
+        "l2norm_rows_fwd": 3 * 2 * MC, "l2norm_rows_bwd": 3 * 3 * MC,
+        "mutan_fwd": 3 * 6 * MC, "mutan_bwd": 3 * 12 * MC,
+        "graph_softmax_fwd": 3 * (3 * AT + 2 * AT2), "graph_softmax_bwd": 3 * (6 * AT + AT2),
+        "lowrank_nn": 3 * (AT2 + MC) + 6 * (AT2 + 2 * MC),
+        "sample_stats": 6 * MC, "gconv_pre_fwd": 3 * 3 * MC, "gconv_post_fwd": 3 * 2 * MC, "gconv_post_bwd": 3 * 4 * MC, "gconv_pre_bwd": 3 * 6 * MC,
+        "score_conv_fwd": 4 * MM, "score_conv_bwd": 3 * 3 * MM + 2 * MM, "upsample_fwd": 4 * 2 * UP + UP, "upsample_loss_bwd": 4 * 2 * UP,
+        "act_bwd": 3 * 3 * MM + (3 + 15 + 3) * MC + 12 * MM + 3 * AT,
+        "rowdot1": 12 * MM, "wcolsum": 12 * MM, "rank1_update": 6 * 2 * MM,
+        "exchange_combine_fwd": 6 * 4 * MM, "exchange_combine_bwd": 6 * 7 * MM, "add_n": 6 * 4 * MM,
+        "convlstm_a": 3 * 6 * MM, "convlstm_b": 3 * 7 * MM, "convlstm_c": 3 * 4 * MM, "convlstm_bwd": 3 * 13 * MM,
+        "adam_step": 7 * 4 * n_params, "pack_weights": 8 * n_params,
+    }
+    macs_img = (2048 + 1024 + 512) * C * N + 15 * 1008 * C * N + 3 * C * C * N + 3 * 2008 * M * N + 12 * M * M * N + 3 * (2 * M) * (4 * M) * N
+    mfma = {"gemm_tn_grouped": 2.0 * macs_img * B, "conv_nhwc": 138.2e9 * B}       # dW of every visual weight; frozen backbone forward (SURVEY 8d)
+    out = {k: ("hbm", float(v)) for k, v in hbm.items()}
+    out.update({k: ("mfma", float(v)) for k, v in mfma.items()})
+    return out
+
+
+def launch_trace(pkg, model, steps, feeds):
+    """Per-name kernel time of `steps` train steps with every launch on ONE stream (cmpc_launch_trace: an event behind every launch of the
+    library; the backbone eager instead of replayed from its graph so that its convolutions are launches of the library too)."""
+    import ctypes as C
+    lib = pkg._lib.load()
+    w, im, tg, sl = feeds
+    model.set_lanes(1)
+    graph_on, model._bb_graph_on = model._bb_graph_on, False
+    for _ in range(2):
+        model.train_step(w, im, tg, sl)
+    torch.cuda.synchronize()
+    pkg._lib.call("cmpc_launch_trace", 1, C.c_void_p(torch.cuda.current_stream().cuda_stream))
+    for _ in range(steps):
+        model.train_step(w, im, tg, sl)
+    torch.cuda.synchronize()
+    name, ms, n = C.c_char_p(), C.c_double(), C.c_int64()
+    out, i = {}, 0
+    while lib.cmpc_launch_trace_read(i, C.byref(name), C.byref(ms), C.byref(n)) == 0:
+        out[name.value.decode()] = (ms.value / steps, n.value / steps)
+        i += 1
+    pkg._lib.call("cmpc_launch_trace", 0, None)
+    model._bb_graph_on = graph_on
+    return out
+
+
 def log(msg):
     print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
 
@@ -222,6 +274,11 @@ def main():
         ktime = model.eng.kernel_timing_read()
         model.eng.kernel_timing(False)
         model.set_lanes(3 if int(os.environ.get("CMPC_STREAMS", "3")) > 1 else 1)
+    # the second half of the roofline: every launch name timed on one stream, HBM-bound stages priced against their byte model
+    trace = None
+    if not args.no_kernel_timing and world == 1 and not v5 and args.dtype != "f32":
+        trace = launch_trace(pkg, model, args.steps, (words, im, target, seq_len))
+        model.set_lanes(3 if int(os.environ.get("CMPC_STREAMS", "3")) > 1 else 1)
     # forward-only rate (SURVEY 8d reports both): sess.run([pred, up, sigm]) on the same batch, same K
     dt_fwd = None
     if not args.no_forward_only:
@@ -296,6 +353,41 @@ def main():
                                "kernel": "gemm_nt_v5/v4/v3_kernel<%s> (every 1x1-conv / dX product of the head)" % args.dtype,
                                "measured": "hipEvent pairs around every launch (cmpc_kernel_timing, on the launch stream) over the same K steps re-run on ONE stream (in the timed region the lane streams overlap, so a start->end interval there also contains other streams' kernels)",
                                "launches_per_step": n / args.steps, "ms_per_step_in_kernel": 1e3 * t / args.steps}
+        if trace is not None and ktime is not None and ktime[3] > 0:
+            sm = stage_model(B)
+            step_ms = 1e3 * dt / args.steps
+            fam = {"hbm": [0.0, 0.0], "mfma": [0.0, 0.0], "latency": [0.0, 0.0]}
+            per = {}
+            nt_names = [k for k in trace if k.startswith("gemm_nt(v5)") or k.startswith("gemm_nt(v4") or k.startswith("gemm_nt(pair)")]
+            nt_ms = sum(trace[k][0] for k in nt_names)
+            bound_ms = 0.0
+            for k, (ms_k, n_k) in sorted(trace.items(), key=lambda kv: -kv[1][0]):
+                if k in nt_names:
+                    continue
+                kind, work = sm.get(k, ("latency", 0.0))
+                fam[kind][0] += ms_k; fam[kind][1] += work
+                if kind == "hbm":
+                    per[k] = {"ms": round(ms_k, 4), "launches": n_k, "GB_per_s": round(work / ms_k / 1e6, 1), "frac": round(work / ms_k / 1e6 / 8000.0, 3)}
+                    bound_ms += work / 8e12 * 1e3
+                elif kind == "mfma":
+                    per[k] = {"ms": round(ms_k, 4), "launches": n_k, "TFLOP_per_s": round(work / ms_k / 1e9, 1), "frac": round(work / ms_k / 1e9 / 2500.0, 3)}
+                    bound_ms += work / 2.5e15 * 1e3
+                else:
+                    per[k] = {"ms": round(ms_k, 4), "launches": n_k}
+            nt_flops = ktime[1] / args.steps
+            bound_ms += nt_flops / 2.5e15 * 1e3
+            per["gemm_nt(16-bit tiles)"] = {"ms": round(nt_ms, 4), "launches": sum(trace[k][1] for k in nt_names), "TFLOP_per_s": round(nt_flops / nt_ms / 1e9, 1),
+                                            "frac": round(nt_flops / nt_ms / 1e9 / 2500.0, 3)}
+            hb, hw = fam["hbm"]
+            out["roofline_hbm"] = {"bound": "hbm", "achieved": hw / hb / 1e6, "peak": 8000.0, "unit": "GB/s", "frac": hw / hb / 1e6 / 8000.0,
+                                   "ms_per_step_in_kernels": hb, "algorithmic_bytes_per_step": hw, "traffic": None,
+                                   "what": "every HBM-bound stage kernel of the head (normalisations, softmaxes, gating, ConvLSTM gates, score / upsample / loss, Adam + pack): "
+                                           "compulsory bytes (unique inputs once, outputs once; SURVEY 8d) / time from cmpc_launch_trace on one stream",
+                                   "latency_bound_launches": {"ms_per_step": fam["latency"][0], "what": "language-side [B, .] launches and partial-row folds: no byte model"}}
+            out["roofline_overall"] = {"frac": bound_ms / step_ms, "lower_bound_ms": bound_ms, "ms_per_step": step_ms,
+                                       "one_stream_kernel_ms": sum(v[0] for v in trace.values()),
+                                       "what": "sum over launch names of max(FLOPs / 2.5 PFLOP/s, bytes / 8 TB/s) divided by the measured step time (lanes overlapped)"}
+            out["kernel_breakdown"] = per
         if alt is not None:
             out["alt_dtype"] = alt
         if cfg4 is not None:

@@ -22,6 +22,11 @@ enum { ACT_NONE = 0, ACT_RELU = 1, ACT_TANH = 2, ACT_SIGMOID = 3 };
 
 void cmpc_set_error(const char* fmt, ...);
 int cmpc_check_launch(const char* what);
+// Launch-trace attribution for entry points that launch a stage kernel and THEN fold its partial rows (cmpc_reduce_parts_f32 checks its
+// own launch): `cmpc_op_scope op("mutan_bwd");` at the top of the entry point makes the first fold inside it close the stage kernel's
+// interval under that name (cmpc_trace_producer), so the kernel's time is not booked on the fold.
+struct cmpc_op_scope { const char* prev; bool prev_marked; cmpc_op_scope(const char* name); ~cmpc_op_scope(); };
+void cmpc_trace_producer();
 // Library-owned scratch for per-workgroup partial sums: one growing buffer PER STREAM (up to 64
 // streams), so stage operators running on different streams never share partial rows.
 void* cmpc_ws(size_t bytes, hipStream_t st);

@@ -476,6 +476,7 @@ extern "C" int cmpc_convlstm_bwd(int dt, const void* dh, const void* dc_new, con
                                  const cmpc_convlstm_ln* ln, const double* sums, void* dYg, void* dc_prev,
                                  float* dW_ci, float* dW_cf, float* dW_co, const cmpc_convlstm_dln* dln, void* scr, double* bsums,
                                  int B, int N, int ld, int M, void* stream) {
+    cmpc_op_scope op_("convlstm_bwd");
     if (!ok("convlstm_bwd", dt, ld, M)) return CMPC_EINVAL;
     const size_t lds = WPB * ld * sizeof(float);
     const int gx = rows_grid(N, 64);

@@ -470,6 +470,7 @@ extern "C" int cmpc_conv_to1_fwd(int dt, const void* x, int ld, const float* w, 
     return cmpc_check_launch("conv_to1_fwd");
 }
 extern "C" int cmpc_conv_to1_bwd(int dt, const float* d, const void* x, int ld, const float* w, void* dx, float* dw, float* dbias, int R, int C, void* stream) {
+    cmpc_op_scope op_("conv_to1_bwd");
     if (!d || !x || !w || !dx || !dw || !dbias || R < 1 || ld % 8 || C > ld || ld > 512 * BN_MB) { cmpc_set_error("conv_to1_bwd: bad args"); return CMPC_EINVAL; }
     const int gx = (int)std::min<long>(512, ((long)R + 3) / 4), stride = ld + 8;
     float* part = (float*)cmpc_ws((size_t)gx * stride * sizeof(float), ST);

@@ -654,6 +654,7 @@ extern "C" int cmpc_mutan_fwd(int dt, void* P, const float* g, void* X1, float* 
 
 extern "C" int cmpc_mutan_bwd(int dt, void* Th, const float* g, const void* X1, const float* rstd, const void* dX1,
                               float* dg, int B, int N, int ld, int C, void* stream) {
+    cmpc_op_scope op_("mutan_bwd");
     if (!map_ok("mutan_bwd", ld, C, dt)) return CMPC_EINVAL;
     const int gx = rows_grid(N, 64);
     float* part = (float*)cmpc_ws((size_t)B * gx * 5 * ld * sizeof(float), ST);
@@ -683,6 +684,7 @@ extern "C" int cmpc_graph_softmax_fwd(int dt, int mask_after, const float* A0, c
 extern "C" int cmpc_graph_softmax_bwd(int dt, const float* dgw_w, const float* dgw_v, const float* gw_w, const float* gw_v,
                                       const float* A0, const float* pr, const float* mask, float* dA0, void* dA0_t, float* dpr,
                                       float* scratch, int B, int N, int T_, int Tp, void* stream) {
+    cmpc_op_scope op_("graph_softmax_bwd");
     if (T_ <= 0 || T_ > 64 || Tp < T_ || Tp > 64) { cmpc_set_error("graph_softmax: need 0 < T <= Tp <= 64"); return CMPC_EINVAL; }
     if (!scratch) { cmpc_set_error("graph_softmax: scratch (B*ceil(N/64)*128 floats) required"); return CMPC_EINVAL; }
     const int ch = (N + GS_ROWS - 1) / GS_ROWS;
@@ -722,6 +724,7 @@ extern "C" int cmpc_exchange_combine_fwd(int dt, const void* feat, const void* r
 extern "C" int cmpc_exchange_combine_bwd(int dt, const void* dout, const void* out, const float* rstd, const void* r1, const void* r2,
                                          const float* g1, const float* g2, int ld_g, void* dfeat, int accumulate_dfeat,
                                          void* dp1, void* dp2, float* dg1, float* dg2, int B, int N, int ld, int C, void* stream) {
+    cmpc_op_scope op_("exchange_combine_bwd");
     if (!map_ok("exchange_combine_bwd", ld, C, dt)) return CMPC_EINVAL;
     const int gx = rows_grid(N, 64);
     float* part = (float*)cmpc_ws((size_t)B * gx * 2 * ld * sizeof(float), ST);

@@ -34,6 +34,16 @@ int cmpc_check_launch(const char* what) {
     }
     return CMPC_OK;
 }
+static thread_local const char* t_op = nullptr;
+static thread_local bool t_op_marked = false;
+cmpc_op_scope::cmpc_op_scope(const char* name) : prev(t_op), prev_marked(t_op_marked) { t_op = name; t_op_marked = false; }
+cmpc_op_scope::~cmpc_op_scope() { t_op = prev; t_op_marked = prev_marked; }
+void cmpc_trace_producer() {
+    if (!g_trace_on || !t_op || t_op_marked) return;
+    t_op_marked = true;
+    hipEvent_t ev = nullptr;
+    if (hipEventCreate(&ev) == hipSuccess) { (void)hipEventRecord(ev, g_trace_stream); g_trace.push_back({t_op, ev}); }
+}
 extern "C" int cmpc_launch_trace(int enable, void* stream) {
     for (auto& t : g_trace) (void)hipEventDestroy(t.second);
     g_trace.clear();
@@ -238,6 +248,7 @@ int cmpc_fold_flush_ranges(cmpc_fold_ctx* ctx, const float* const* lo, const flo
 }
 int cmpc_reduce_parts_f32(const float* part, long part_stride, int nouter, int ninner, int nseg, int seg_ld, int seg_C,
                           float* out, long ld_out, long out_seg, int accumulate, hipStream_t st) {
+    cmpc_trace_producer();        // closes the producing stage kernel's trace interval under ITS name (launch trace only)
     const int cols = nseg * seg_ld;
     if (accumulate && t_fold && out >= t_fold->lo && out < t_fold->hi && t_fold->n < t_fold->table_cap &&
         (const char*)part >= t_fold->arena && (const char*)part < t_fold->arena + t_fold->cap) {
@@ -806,6 +817,7 @@ extern "C" int cmpc_bias_act_res(int dt, void* y, const float* bias, const void*
 
 extern "C" int cmpc_act_bwd(int dt, const void* dy, const void* y, void* dpre, int act, int R, int stride, int ld, int C,
                             float* db, float* dsb, int ld_dsb, int rows_per_sample, void* stream) {
+    cmpc_op_scope op_("act_bwd");
     if (!map_ok("act_bwd", ld, C, dt)) return CMPC_EINVAL;
     if (stride < ld || stride % 8) { cmpc_set_error("act_bwd: stride must be >= ld and a multiple of 8"); return CMPC_EINVAL; }
     int N = R, B = 1;
@@ -822,6 +834,7 @@ extern "C" int cmpc_act_bwd(int dt, const void* dy, const void* y, void* dpre, i
 }
 
 extern "C" int cmpc_wcolsum(int dt, const void* x, const float* w, float* out, int ld_out, int B, int N, int ld, int C, float scale, void* stream) {
+    cmpc_op_scope op_("wcolsum");
     if (!map_ok("wcolsum", ld, C, dt)) return CMPC_EINVAL;
     const int gx = rows_grid(N) > 64 ? 64 : rows_grid(N);
     float* part = (float*)cmpc_ws((size_t)B * gx * ld * sizeof(float), ST);
@@ -885,6 +898,7 @@ static int ln_bwd_ws(int B, int gx, int ld, float** part, hipStream_t st) {
 extern "C" int cmpc_gconv_pre_bwd(int dt, const void* dG, const void* G, const void* Y, const double* sums, const float* gamma,
                                   void* dX, int accumulate_dX, void* dY, float* dgamma, float* dbeta, double* bsums,
                                   int B, int N, int ld, int C, void* stream) {
+    cmpc_op_scope op_("gconv_pre_bwd");
     if (!map_ok("gconv_pre_bwd", ld, C, dt)) return CMPC_EINVAL;
     const int gx = rows_grid(N) > 64 ? 64 : rows_grid(N);
     float* part;
@@ -908,6 +922,7 @@ extern "C" int cmpc_gconv_post_fwd(int dt, const void* U, const double* sums, co
 extern "C" int cmpc_gconv_post_bwd(int dt, const void* dout, const void* out, const float* rstd_row, const void* U,
                                    const double* sums, const float* gamma, void* dU, float* dgamma, float* dbeta, double* bsums,
                                    int B, int N, int ld, int C, void* stream) {
+    cmpc_op_scope op_("gconv_post_bwd");
     if (!map_ok("gconv_post_bwd", ld, C, dt)) return CMPC_EINVAL;
     const int gx = rows_grid(N) > 64 ? 64 : rows_grid(N);
     float* part;

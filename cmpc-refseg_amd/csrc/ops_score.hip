@@ -328,6 +328,7 @@ extern "C" int cmpc_score_conv_fwd(int dt, const void* feat, const float* Wk, co
 
 extern "C" int cmpc_score_conv_bwd(int dt, const float* dscore, const void* feat, const float* Wk, void* dfeat, int accumulate,
                                    float* dWk, float* dbias, int B, int h, int w, int ld, int M, void* stream) {
+    cmpc_op_scope op_("score_conv_bwd");
     if (ld % 8 || M > ld || ld > MB * 512) { cmpc_set_error("score_conv_bwd: bad ld/M"); return CMPC_EINVAL; }
     const int total = B * h * w, g = (total + 3) / 4 > 2048 ? 2048 : (total + 3) / 4;
     CMPC_DISPATCH_DT(dt, {
@@ -349,6 +350,7 @@ extern "C" int cmpc_score_conv_bwd(int dt, const float* dscore, const void* feat
 
 extern "C" int cmpc_upsample_fwd(const float* score, float* up, float* sigm, const float* target, float* loss,
                                  int* inter, int* uni, int B, int h, int w, int H, int W, void* stream) {
+    cmpc_op_scope op_("upsample_fwd");
     if (target && (!loss || !inter || !uni)) { cmpc_set_error("upsample_fwd: loss/inter/uni required with target"); return CMPC_EINVAL; }
     const int gx = (H * W + 255) / 256 > 64 ? 64 : (H * W + 255) / 256;
     float* loss_part = nullptr;
