@@ -168,6 +168,8 @@ SIGNATURES = {
     "cmpc_lstm_cell_fwd": [_P, _P, _P, _P, _I, _P, _P, _P, _I, _I, _I, _I, _P],
     "cmpc_lstm_cell_bwd": [_P, _P, _P, _P, _I, _P, _I, _P, _P, _P, _I, _I, _I, _P],
     "cmpc_lstm_bwd_step": [_P, _P, _I, _P, _P, _P, _P, _I, _P, _I, _P, _P, _P, _I, _I, _I, _P],
+    "cmpc_lstm_seq_fwd": [_P, _P, _I, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
+    "cmpc_lstm_seq_bwd": [_P, _I, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
     "cmpc_parse_softmax_fwd": [_P, _I, _P, _P, _I, _P],
     "cmpc_parse_softmax_bwd": [_P, _P, _P, _P, _I, _I, _P],
     "cmpc_lang_pool_fwd": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P],

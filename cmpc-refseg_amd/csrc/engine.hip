@@ -155,6 +155,7 @@ struct ClstmStep { void *Yg, *c_pre, *c_new, *h_new, *dYg, *dc_prev, *dx, *dh; d
 struct LstmDir {
     std::string key, pk, pb;            // operand key ("lstm" / "lstm_fw" / "lstm_bw"), kernel / bias parameter names
     int* words_tb; float *emb, *xg, *gates, *h_all, *c_all, *outs, *douts, *dh, *dc, *dgt, *demb, *demb_parts;
+    int *sync_f, *sync_b;               // {barrier counter, abort flag} of the one-launch recurrence kernels (zeroed with the forward / backward regions)
 };
 // one slim conv2d + batch_norm + relu layer (CMPCv5_BiLSTM_model.py:190-251): the convolution's output, its statistics, the backward scratch
 struct BnLayer {
@@ -234,6 +235,7 @@ struct cmpc_engine_s {
     bool wgrad_overlap = true;          // issue the levels' / exchanges' dW beside the text encoder's backward chain
     bool lowrank = false;               // the graph's T-deep products through cmpc_lowrank_nn (16-bit storage, T <= 24, Cp = 4 * 2^j <= 1024)
     bool mutan_epilogue = true;         // the Mutan heads' tanh as the epilogue of their GEMM (P is written once, as tanh; mutan_fwd only reads it)
+    bool lstm_seq = true;               // the text LSTM's T steps in ONE persistent launch per direction (B <= 8, Cp <= 1024); else 2 launches per step
     cmpc_fold_ctx fold;                 // deferred bias / LayerNorm / peephole gradient folds (one launch per backward pass)
     std::vector<cmpc_fold_desc> fold_descs, fold_shadow[NBK]; cmpc_fold_desc* fold_table[NBK] = {}; int fold_shadow_n[NBK];
     std::vector<Tap> taps;
@@ -550,6 +552,8 @@ void plan_workspace(E* e, Bump& zf, Bump& zb, Bump& g) {
         D.dc = (float*)zb.take((size_t)B * Cp * F);
         D.dgt = (float*)g.take((size_t)T * B * 4 * Cp * F);
         D.demb = (float*)g.take((size_t)T * B * Gp * F); D.demb_parts = (float*)g.take((size_t)8 * T * B * Gp * F);
+        D.sync_f = (int*)zf.take(256); D.sync_b = (int*)zb.take(256);
+        tap(e, fmt("lstm_sync_%d", d), D.sync_f, 3, {2}); tap(e, fmt("lstm_sync_bwd_%d", d), D.sync_b, 3, {2});
     }
     if (e->v5) {
         e->outs_bw = (float*)g.take((size_t)B * T * Cp * F); e->douts_bw = (float*)g.take((size_t)B * T * Cp * F);
@@ -878,6 +882,8 @@ int lstm_dir_fwd(E* e, hipStream_t st, LstmDir& D, const int32_t* seq_len) {
     GemmOpt o; o.bias = (const float*)opp(e, D.key + ".b");
     CK(gemm_nt(st, DT_F32, {{D.emb, Gp, opp(e, D.key + ".t"), ldk, Gp}}, D.xg, 4 * Cp, T * B, 4 * Cp, o));
     const void* wh = opp(e, D.key + ".t", 0, Gp);
+    if (e->lstm_seq)      // all T steps in one persistent launch (W_h in registers, a grid barrier per step)
+        return cmpc_lstm_seq_fwd(D.xg, (const float*)wh, ldk, seq_len, D.gates, D.h_all, D.c_all, D.outs, D.sync_f, B, T, Cp, R, st);
     for (int t = 0; t < T; ++t) {
         float* gt = D.gates + (size_t)t * B * 4 * Cp;
         float *hp = D.h_all + (size_t)t * B * Cp, *cp = D.c_all + (size_t)t * B * Cp;
@@ -893,7 +899,9 @@ int lstm_dir_bwd(E* e, hipStream_t st, LstmDir& D, const int32_t* seq_len) {
     auto gat = [&](int t) { return D.gates + (size_t)t * B * 4 * Cp; };
     auto call = [&](int t) { return D.c_all + (size_t)t * B * Cp; };
     auto dgt = [&](int t) { return D.dgt + (size_t)t * B * 4 * Cp; };
-    if (B <= 8) {
+    if (e->lstm_seq) {
+        CK(cmpc_lstm_seq_bwd((const float*)opp(e, D.key + ".n", Gp, 0), 4 * Cp, D.gates, D.c_all, seq_len, D.douts, D.dgt, D.sync_b, B, T, Cp, R, st));
+    } else if (B <= 8) {
         // one launch per step: dh += dg[t] . W_h^T fused with the cell backward of step t-1
         CK(cmpc_lstm_cell_bwd(gat(T - 1), call(T - 1), call(T), seq_len, T - 1, D.douts + (size_t)(T - 1) * Cp, T * Cp, D.dh, D.dc, dgt(T - 1), B, Cp, R, st));
         const float* wn = (const float*)opp(e, D.key + ".n", Gp, 0);
@@ -1705,6 +1713,8 @@ extern "C" int cmpc_create(const cmpc_cfg* c, cmpc_handle* out) {
     for (auto& d : e->deferred) d.reserve(128);
     if (const char* v = getenv("CMPC_WGRAD_OVERLAP")) e->wgrad_overlap = atoi(v) != 0;       // read once, at create
     if (const char* v = getenv("CMPC_MUTAN_EPILOGUE")) e->mutan_epilogue = atoi(v) != 0;
+    e->lstm_seq = e->B <= 8 && e->Cp <= 1024;
+    if (const char* v = getenv("CMPC_LSTM_SEQ")) e->lstm_seq = e->lstm_seq && atoi(v) != 0;
     e->fold_descs.resize(e->fold.table_cap);
     for (int a = 0; a < E::NBK; ++a) { e->fold_shadow[a].resize(e->fold.table_cap); e->fold_shadow_n[a] = -1; }
     e->fold.descs = e->fold_descs.data(); e->fold.shadow = e->fold_shadow[E::NBK - 1].data();

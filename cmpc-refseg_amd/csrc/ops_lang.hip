@@ -142,6 +142,176 @@ __global__ __launch_bounds__(256) void lstm_bwd_step_kernel(const float* __restr
     dh[o] = 0.f;
 }
 
+// ------------------------------------------------------------------------------------------
+// The whole LSTM recurrence in ONE launch (dynamic_rnn over T steps, CMPC_model.py:144-164 / bidirectional_dynamic_rnn,
+// CMPCv5_BiLSTM_model.py:170-174): a wave owns ONE hidden unit -- its four gate rows of W_h (forward) or its row of W_h^T (backward) stay
+// in registers for all T steps, so the 16 MB of recurrent weights are read once per launch instead of once per step -- a workgroup owns 4
+// units, 256 workgroups cover the (padded) 1024 units.  The previous step's h (forward) / gate gradients (backward) are staged through
+// LDS; lane b < B of the wave runs the cell update of (sample b, unit) and keeps c (forward) or dh / dc (backward) in registers.  Steps
+// are separated by a grid barrier: an agent-scope release / acquire counter in global memory (each workgroup adds 1 per step and waits for
+// G * step).  Every spin loop has a watchdog (SEQ_SPIN_LIMIT polls, ~1 s): on expiry the workgroup raises *abort_flag, which releases
+// every other waiter, and the grid drains -- a launch that cannot make progress ends instead of hanging the GPU.  Co-residency: 256
+// workgroups of 256 threads with <= 64 KB of LDS fit twice per CU, so two such launches (the two directions, two processes on one GPU) can
+// be resident together.  Needs B <= 8 and ld <= 1024; the engine keeps the per-step path for anything else.
+// ------------------------------------------------------------------------------------------
+constexpr long SEQ_SPIN_LIMIT = 1L << 24;
+__device__ __forceinline__ void grid_arrive(unsigned* bar) {
+    __threadfence();
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_fetch_add(bar, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+}
+// returns false when the launch was aborted (watchdog of this or another workgroup)
+__device__ __forceinline__ bool grid_wait(unsigned* bar, unsigned target, int* abort_flag) {
+    __shared__ int ok_s;
+    if (threadIdx.x == 0) {
+        long spins = 0;
+        int ok = 1;
+        while (__hip_atomic_load(bar, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < target) {
+            __builtin_amdgcn_s_sleep(1);
+            if ((++spins & 255) == 0) {
+                if (__hip_atomic_load(abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) { ok = 0; break; }
+                if (spins > SEQ_SPIN_LIMIT) { __hip_atomic_store(abort_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); ok = 0; break; }
+            }
+        }
+        ok_s = ok;
+    }
+    __syncthreads();
+    const bool ok = ok_s != 0;
+    __syncthreads();
+    return ok;
+}
+__device__ __forceinline__ float dot4(const float4& a, const float4& b) { return a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w; }
+
+constexpr int SEQ_B = 8, SEQ_KI = 4;        // B <= 8 samples, ld <= 256 * SEQ_KI
+__global__ __launch_bounds__(256) void lstm_seq_fwd_kernel(const float* __restrict__ xg, const float* __restrict__ Wh, int ldw, const int* __restrict__ seq_len,
+                                                          float* __restrict__ gates, float* __restrict__ h_all, float* __restrict__ c_all,
+                                                          float* __restrict__ outs, unsigned* bar, int* abort_flag, int B, int T, int ld, int R) {
+    extern __shared__ float hs[];                 // [SEQ_B][ld]: h of the previous step
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, u = blockIdx.x * 4 + wv;
+    const bool unit_ok = u < R;
+    float4 w[4][SEQ_KI];
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+        for (int i = 0; i < SEQ_KI; ++i) {
+            const int k = lane * 4 + 256 * i;
+            w[g][i] = (unit_ok && k < ld) ? *reinterpret_cast<const float4*>(Wh + (long)(g * ld + u) * ldw + k) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    float c_reg = 0.f;                            // lane b: cell state of (sample b, unit u)
+    const int len = lane < B ? seq_len[lane] : 0;
+    for (int t = 0; t < T; ++t) {
+        if (t > 0 && !grid_wait(bar, gridDim.x * (unsigned)t, abort_flag)) return;
+        const float* hp = h_all + (long)t * B * ld;
+        for (int i = threadIdx.x * 4; i < B * ld; i += 1024) *reinterpret_cast<float4*>(hs + i) = *reinterpret_cast<const float4*>(hp + i);
+        __syncthreads();
+        float pre[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int b = 0; b < SEQ_B; ++b) {
+            float a[4] = {0.f, 0.f, 0.f, 0.f};
+            if (b < B) {
+#pragma unroll
+                for (int i = 0; i < SEQ_KI; ++i) {
+                    const int k = lane * 4 + 256 * i;
+                    if (k < ld) {
+                        const float4 hv = *reinterpret_cast<const float4*>(hs + b * ld + k);
+#pragma unroll
+                        for (int g = 0; g < 4; ++g) a[g] += dot4(w[g][i], hv);
+                    }
+                }
+            }
+#pragma unroll
+            for (int g = 0; g < 4; ++g) { const float v = wave_sum(a[g]); if (lane == b) pre[g] = v; }
+        }
+        if (lane < B && u < ld) {
+            const int b = lane;
+            const long go = ((long)t * B + b) * 4 * ld + u, so = ((long)(t + 1) * B + b) * ld + u;
+            const bool live = t < len;
+            float is = 0.f, jt = 0.f, fs = 0.f, os = 0.f, cn = 0.f, hn = 0.f;
+            const float h_prev = hs[b * ld + u];
+            if (unit_ok) {
+                is = sigmoidf_(pre[0] + xg[go]); jt = tanhf(pre[1] + xg[go + ld]);
+                fs = sigmoidf_(pre[2] + xg[go + 2 * ld] + 1.0f); os = sigmoidf_(pre[3] + xg[go + 3 * ld]);
+                cn = fs * c_reg + is * jt;
+                hn = os * tanhf(cn);
+            }
+            gates[go] = is; gates[go + ld] = jt; gates[go + 2 * ld] = fs; gates[go + 3 * ld] = os;
+            c_reg = live ? cn : c_reg;
+            c_all[so] = c_reg;
+            h_all[so] = live ? hn : h_prev;
+            outs[((long)b * T + t) * ld + u] = live ? hn : 0.f;
+        }
+        if (t + 1 < T) grid_arrive(bar); else __syncthreads();
+    }
+}
+
+// dgates [T, B, 4 ld] <- the backward recurrence over `douts` [B, T, ld] (gradient of the outputs); Wn [ld rows][4 ld]: row k = W_h^T row of
+// hidden unit k (the packed input-major operand)
+__global__ __launch_bounds__(256) void lstm_seq_bwd_kernel(const float* __restrict__ Wn, int ldw, const float* __restrict__ gates, const float* __restrict__ c_all,
+                                                          const int* __restrict__ seq_len, const float* __restrict__ douts, float* __restrict__ dgates,
+                                                          unsigned* bar, int* abort_flag, int B, int T, int ld, int R) {
+    extern __shared__ float dgs[];                // [4][4 ld]: the gate gradients of 4 samples of the previous step (two passes for B = 8)
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, u = blockIdx.x * 4 + wv;
+    const bool unit_ok = u < R;
+    const int K4 = 4 * ld;
+    float4 wn[4 * SEQ_KI];
+#pragma unroll
+    for (int i = 0; i < 4 * SEQ_KI; ++i) {
+        const int k = lane * 4 + 256 * i;
+        wn[i] = (unit_ok && k < K4) ? *reinterpret_cast<const float4*>(Wn + (long)u * ldw + k) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    float dh_carry = 0.f, dc = 0.f;               // lane b: state gradients of (sample b, unit u)
+    const int len = lane < B ? seq_len[lane] : 0;
+    for (int t = T - 1; t >= 0; --t) {
+        float mv = 0.f;
+        if (t < T - 1) {
+            if (!grid_wait(bar, gridDim.x * (unsigned)(T - 1 - t), abort_flag)) return;
+            const float* dg = dgates + (long)(t + 1) * B * K4;
+            for (int half = 0; half < (B + 3) / 4; ++half) {
+                const int nb = min(4, B - half * 4);
+                __syncthreads();
+                for (int i = threadIdx.x * 4; i < nb * K4; i += 1024) *reinterpret_cast<float4*>(dgs + i) = *reinterpret_cast<const float4*>(dg + (long)half * 4 * K4 + i);
+                __syncthreads();
+#pragma unroll
+                for (int bb = 0; bb < 4; ++bb) {
+                    float a = 0.f;
+                    if (bb < nb) {
+#pragma unroll
+                        for (int i = 0; i < 4 * SEQ_KI; ++i) {
+                            const int k = lane * 4 + 256 * i;
+                            if (k < K4) a += dot4(wn[i], *reinterpret_cast<const float4*>(dgs + bb * K4 + k));
+                        }
+                    }
+                    const float v = wave_sum(a);
+                    if (lane == half * 4 + bb) mv = v;
+                }
+            }
+        }
+        if (lane < B && u < ld) {
+            const int b = lane;
+            const long go = ((long)t * B + b) * K4 + u, so = ((long)t * B + b) * ld + u;      // c_all[t] = c_prev, c_all[t + 1] = c_out
+            const float dh_in = dh_carry + (unit_ok ? mv : 0.f);
+            const bool live = t < len;
+            float d0 = 0.f, d1 = 0.f, d2 = 0.f, d3 = 0.f;
+            if (!unit_ok) { dh_carry = 0.f; dc = 0.f; }
+            else if (!live) dh_carry = dh_in;      // state gradients pass through for finished sequences
+            else {
+                const float is = gates[go], jt = gates[go + ld], fs = gates[go + 2 * ld], os = gates[go + 3 * ld];
+                const float cn = c_all[so + (long)B * ld], tc = tanhf(cn);
+                const float dhn = douts[((long)b * T + t) * ld + u] + dh_in;
+                const float dcn = dc + dhn * os * (1.f - tc * tc);
+                d0 = dcn * jt * is * (1.f - is);
+                d1 = dcn * is * (1.f - jt * jt);
+                d2 = dcn * c_all[so] * fs * (1.f - fs);
+                d3 = dhn * tc * os * (1.f - os);
+                dc = dcn * fs;
+                dh_carry = 0.f;
+            }
+            dgates[go] = d0; dgates[go + ld] = d1; dgates[go + 2 * ld] = d2; dgates[go + 3 * ld] = d3;
+        }
+        if (t > 0) grid_arrive(bar);
+    }
+}
+
 __global__ void parse_softmax_fwd_kernel(const float* __restrict__ logits, int ld, const float* __restrict__ mask, float* __restrict__ parse, int n) {
     const int r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= n) return;
@@ -369,6 +539,29 @@ extern "C" int cmpc_lstm_bwd_step(const float* dgates_t, const float* Wn, int ld
     hipLaunchKernelGGL(lstm_bwd_step_kernel, dim3((ld + 3) / 4), dim3(256), 0, ST, dgates_t, Wn, ldw, gates_act_tm1, c_prev, c_out, seq_len, tm1,
                        dout_tm1, ld_dout, dh, dc, dgates_tm1, B, ld, R);
     return cmpc_check_launch("lstm_bwd_step");
+}
+// One launch for the T steps of a direction (see lstm_seq_fwd_kernel).  xg [T, B, 4 ld]: the x-side pre-activations incl. bias; Wh: the gate rows
+// of W_h, [4 ld rows][ldw], k contiguous; h_all / c_all [(T + 1), B, ld] with slice 0 = the initial state; sync: 8 bytes of device memory the
+// caller zeroed (barrier counter, abort flag).  Returns CMPC_EINVAL when B > 8 or ld > 1024 (use the per-step entry points then).
+extern "C" int cmpc_lstm_seq_fwd(const float* xg, const float* Wh, int ldw, const int* seq_len, float* gates, float* h_all, float* c_all, float* outs,
+                                 void* sync, int B, int T, int ld, int R, void* stream) {
+    if (!xg || !Wh || !seq_len || !gates || !h_all || !c_all || !outs || !sync || B < 1 || B > SEQ_B || T < 1 || ld < 64 || ld % 64 || ld > 256 * SEQ_KI || R > ld || ldw % 4) {
+        cmpc_set_error("lstm_seq_fwd: need 1 <= B <= %d, ld a multiple of 64 and <= %d, 16-B aligned rows", SEQ_B, 256 * SEQ_KI); return CMPC_EINVAL;
+    }
+    hipLaunchKernelGGL(lstm_seq_fwd_kernel, dim3(ld / 4), dim3(256), (size_t)SEQ_B * ld * sizeof(float), ST, xg, Wh, ldw, seq_len, gates, h_all, c_all, outs,
+                       (unsigned*)sync, (int*)sync + 1, B, T, ld, R);
+    return cmpc_check_launch("lstm_seq_fwd");
+}
+extern "C" int cmpc_lstm_seq_bwd(const float* Wn, int ldw, const float* gates, const float* c_all, const int* seq_len, const float* douts, float* dgates,
+                                 void* sync, int B, int T, int ld, int R, void* stream) {
+    if (!Wn || !gates || !c_all || !seq_len || !douts || !dgates || !sync || B < 1 || B > SEQ_B || T < 1 || ld < 64 || ld % 64 || ld > 256 * SEQ_KI || R > ld || ldw % 4) {
+        cmpc_set_error("lstm_seq_bwd: need 1 <= B <= %d, ld a multiple of 64 and <= %d, 16-B aligned rows", SEQ_B, 256 * SEQ_KI); return CMPC_EINVAL;
+    }
+    const size_t lds = (size_t)4 * 4 * ld * sizeof(float);
+    static const bool attr = ((void)hipFuncSetAttribute((const void*)lstm_seq_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 4 * 256 * SEQ_KI * (int)sizeof(float)), true);
+    (void)attr;
+    hipLaunchKernelGGL(lstm_seq_bwd_kernel, dim3(ld / 4), dim3(256), lds, ST, Wn, ldw, gates, c_all, seq_len, douts, dgates, (unsigned*)sync, (int*)sync + 1, B, T, ld, R);
+    return cmpc_check_launch("lstm_seq_bwd");
 }
 extern "C" int cmpc_parse_softmax_fwd(const float* logits, int ld, const float* mask, float* parse, int n, void* stream) {
     hipLaunchKernelGGL(parse_softmax_fwd_kernel, dim3((n + 63) / 64), dim3(64), 0, ST, logits, ld, mask, parse, n);

@@ -238,6 +238,15 @@ int cmpc_lstm_cell_bwd(const float* gates_act, const float* c_prev, const float*
 int cmpc_lstm_bwd_step(const float* dgates_t, const float* Wn, int ldw, const float* gates_act_tm1, const float* c_prev, const float* c_out,
                        const int* seq_len, int tm1, const float* dout_tm1, int ld_dout, float* dh, float* dc, float* dgates_tm1,
                        int B, int ld, int R, void* stream);
+/* The whole recurrence of one direction in ONE launch (persistent workgroups, W_h in registers, a grid barrier per step; B <= 8, ld <= 1024,
+ * otherwise CMPC_EINVAL: use the per-step entry points).  xg [T, B, 4 ld]: x-side pre-activations incl. bias; Wh [4 ld rows][ldw]: gate rows of W_h,
+ * k contiguous; gates [T, B, 4 ld] receives the activated gates; h_all / c_all [(T+1), B, ld], slice 0 = initial state; outs [B, T, ld];
+ * sync: 8 bytes of ZEROED device memory per launch (barrier counter + abort flag: non-zero afterwards = the launch was aborted by its watchdog).
+ * cmpc_lstm_seq_bwd: dgates [T, B, 4 ld] from douts [B, T, ld]; Wn [ld rows][4 ld] = rows of W_h^T */
+int cmpc_lstm_seq_fwd(const float* xg, const float* Wh, int ldw, const int* seq_len, float* gates, float* h_all, float* c_all, float* outs,
+                      void* sync, int B, int T, int ld, int R, void* stream);
+int cmpc_lstm_seq_bwd(const float* Wn, int ldw, const float* gates, const float* c_all, const int* seq_len, const float* douts, float* dgates,
+                      void* sync, int B, int T, int ld, int R, void* stream);
 /* softmax over the 4 parser classes times seq_mask (:352-353) */
 int cmpc_parse_softmax_fwd(const float* logits, int ld, const float* mask, float* parse, int n, void* stream);
 int cmpc_parse_softmax_bwd(const float* dparse, const float* parse, const float* mask, float* dlogits, int ld, int n, void* stream);

@@ -294,10 +294,11 @@ def test_head_16bit_within_tolerance(case, dtype, tap_tol, loss_tol, grad_tol):
     assert max(errs.values()) < grad_tol, errs
 
 
-@pytest.mark.parametrize("switch", ["CMPC_LOWRANK", "CMPC_MUTAN_EPILOGUE", "CMPC_WGRAD_OVERLAP"])
+@pytest.mark.parametrize("switch", ["CMPC_LOWRANK", "CMPC_MUTAN_EPILOGUE", "CMPC_WGRAD_OVERLAP", "CMPC_LSTM_SEQ"])
 def test_alternative_paths_agree(case, switch, monkeypatch):
     """The A/B switches read by cmpc_create select paths that are also the fall-backs of other configurations (the graph's T-deep
-    products through gemm_nt when T > 24 / C > 1024, the Mutan tanh inside mutan_fwd, the dW launches after the text encoder): on the
+    products through gemm_nt when T > 24 / C > 1024, the Mutan tanh inside mutan_fwd, the dW launches after the text encoder, the per-step
+    LSTM launches when B > 8): on the
     same f16 inputs they agree with the default path to rounding (every tap, the loss, a gradient per stage)."""
     def run():
         m = _model(case, "f16")
@@ -306,6 +307,11 @@ def test_alternative_paths_agree(case, switch, monkeypatch):
         taps = {k: v.float().cpu().clone() for k, v in U.product_taps_as_oracle(o, case["cfg"]).items()}
         return taps, float(o["loss_all"]), {k: v.cpu().clone() for k, v in m.store.grad_dict().items()}
     ta, la, ga = run()
+    if switch == "CMPC_LSTM_SEQ":       # the one-launch recurrence ran, and its watchdog stayed quiet
+        m = _model(case, "f16")
+        m.loss_and_grads([f.to(m.device) for f in case["feats"]], case["words"], case["tgt"], case["sl"])
+        torch.cuda.synchronize()
+        assert int(m.eng.tap("lstm_sync_0")[1]) == 0 and int(m.eng.tap("lstm_sync_bwd_0")[1]) == 0 and int(m.eng.tap("lstm_sync_0")[0]) > 0
     monkeypatch.setenv(switch, "0")
     tb, lb, gb = run()
     for k in ta:
