@@ -235,7 +235,7 @@ struct cmpc_engine_s {
     bool wgrad_overlap = true;          // issue the levels' / exchanges' dW beside the text encoder's backward chain
     bool lowrank = false;               // the graph's T-deep products through cmpc_lowrank_nn (16-bit storage, T <= 24, Cp = 4 * 2^j <= 1024)
     bool mutan_epilogue = true;         // the Mutan heads' tanh as the epilogue of their GEMM (P is written once, as tanh; mutan_fwd only reads it)
-    bool lstm_seq = true;               // the text LSTM's T steps in ONE persistent launch per direction (B <= 8, Cp <= 1024); else 2 launches per step
+    bool lstm_seq = false;              // the text LSTM's T steps in ONE persistent launch per direction (B <= 8, Cp <= 1024; opt-in, see cmpc_create)
     cmpc_fold_ctx fold;                 // deferred bias / LayerNorm / peephole gradient folds (one launch per backward pass)
     std::vector<cmpc_fold_desc> fold_descs, fold_shadow[NBK]; cmpc_fold_desc* fold_table[NBK] = {}; int fold_shadow_n[NBK];
     std::vector<Tap> taps;
@@ -1713,8 +1713,11 @@ extern "C" int cmpc_create(const cmpc_cfg* c, cmpc_handle* out) {
     for (auto& d : e->deferred) d.reserve(128);
     if (const char* v = getenv("CMPC_WGRAD_OVERLAP")) e->wgrad_overlap = atoi(v) != 0;       // read once, at create
     if (const char* v = getenv("CMPC_MUTAN_EPILOGUE")) e->mutan_epilogue = atoi(v) != 0;
-    e->lstm_seq = e->B <= 8 && e->Cp <= 1024;
-    if (const char* v = getenv("CMPC_LSTM_SEQ")) e->lstm_seq = e->lstm_seq && atoi(v) != 0;
+    // Opt-in (CMPC_LSTM_SEQ=1): measured SLOWER inside the multi-stream step (13.26 vs 10.71 ms per B=8 train step): its 256 spinning
+    // workgroups cannot co-reside with the MFMA kernels of the other streams (2 waves x 256 VGPRs per SIMD fill the register file), so every
+    // grid barrier waits for whole GEMM / persistent dW workgroups to retire.  It pays only where the recurrence has the GPU to itself.
+    e->lstm_seq = false;
+    if (const char* v = getenv("CMPC_LSTM_SEQ")) e->lstm_seq = atoi(v) != 0 && e->B <= 8 && e->Cp <= 1024;
     e->fold_descs.resize(e->fold.table_cap);
     for (int a = 0; a < E::NBK; ++a) { e->fold_shadow[a].resize(e->fold.table_cap); e->fold_shadow_n[a] = -1; }
     e->fold.descs = e->fold_descs.data(); e->fold.shadow = e->fold_shadow[E::NBK - 1].data();

@@ -307,12 +307,12 @@ def test_alternative_paths_agree(case, switch, monkeypatch):
         taps = {k: v.float().cpu().clone() for k, v in U.product_taps_as_oracle(o, case["cfg"]).items()}
         return taps, float(o["loss_all"]), {k: v.cpu().clone() for k, v in m.store.grad_dict().items()}
     ta, la, ga = run()
-    if switch == "CMPC_LSTM_SEQ":       # the one-launch recurrence ran, and its watchdog stayed quiet
+    monkeypatch.setenv(switch, "1" if switch == "CMPC_LSTM_SEQ" else "0")         # the one-launch recurrence is opt-in, the others opt-out
+    if switch == "CMPC_LSTM_SEQ":       # it runs, and its watchdog stays quiet
         m = _model(case, "f16")
         m.loss_and_grads([f.to(m.device) for f in case["feats"]], case["words"], case["tgt"], case["sl"])
         torch.cuda.synchronize()
         assert int(m.eng.tap("lstm_sync_0")[1]) == 0 and int(m.eng.tap("lstm_sync_bwd_0")[1]) == 0 and int(m.eng.tap("lstm_sync_0")[0]) > 0
-    monkeypatch.setenv(switch, "0")
     tb, lb, gb = run()
     for k in ta:
         assert U.rel_err(tb[k], ta[k]) < 3e-3, (switch, k)
