@@ -344,7 +344,7 @@ def main():
             # HBM-side bytes per launch from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE on this
             # same command, scripts/pmc_traffic.py); bench.py cannot run the profiler on itself
             traffic = None
-            tp = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r02_gemm_nt_traffic.json")
+            tp = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r03_gemm_nt_traffic.json")
             if args.dtype != "f32" and B == 8 and os.path.exists(tp):
                 traffic = json.load(open(tp))["hbm_bytes_per_launch"]
             out["roofline"] = {"bound": "mfma", "achieved": f / t / 1e12, "peak": peak, "unit": "TFLOP/s",
