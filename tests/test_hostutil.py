@@ -129,3 +129,22 @@ def test_resize_and_pad_crop_pixels():
     mask = np.zeros((60, 80), bool); mask[20:40, 30:50] = True
     m = H.resize_and_pad(mask, 320, 320)
     assert m.shape == (320, 320) and abs(m.sum() / (320 * 320) - 400 / (60 * 80) * (240 * 320) / (320 * 320)) < 5e-3
+
+
+def test_tokeniser_matches_the_references_own_functions():
+    """hostutil's tokeniser against outputs of the REFERENCE's util/text_processing.py:9-67 itself (tests/golden/make_text_fixtures.py ran
+    it in the build container on 169 expressions of data/referit_query_test.json + edge cases, two vocabularies, T = 20 and 8): ids,
+    lengths, end- and front-padded forms, bit for bit."""
+    import json
+    H = importlib.import_module("cmpc-refseg_amd.hostutil")
+    G = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_text_processing.json")))
+    sents = G["sentences"]
+    assert len(sents) >= 160
+    for vname, v in G["vocab"].items():
+        vocab = dict(v["subset"])
+        vocab["<pad>"], vocab["<unk>"] = v["pad"], v["unk"]
+        assert [H.sentence2vocab_indices(s, vocab) for s in sents] == v["raw"], vname
+        for T in G["T"]:
+            got = [H.preprocess_sentence_lstm(s, vocab, T) for s in sents]
+            assert [g[0] for g in got] == v["lstm"][str(T)]["ids"] and [g[1] for g in got] == v["lstm"][str(T)]["len"], (vname, T)
+            assert [H.preprocess_sentence(s, vocab, T) for s in sents] == v["front"][str(T)], (vname, T)
