@@ -243,7 +243,7 @@ def tf_conv2d(x_nchw, w_hwio, stride=1, dilation=1):
     pl, pr = _same_pad(x_nchw.shape[3], k, stride, dilation)
     if pt or pb or pl or pr:
         x_nchw = F.pad(x_nchw, (pl, pr, pt, pb))
-    return F.conv2d(x_nchw, w_hwio.permute(3, 2, 0, 1), stride=stride, dilation=dilation)
+    return F.conv2d(x_nchw.contiguous(), w_hwio.permute(3, 2, 0, 1).contiguous(), stride=stride, dilation=dilation)
 
 
 def _bn(x, p, name, relu):
