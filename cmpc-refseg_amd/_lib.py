@@ -170,10 +170,10 @@ SIGNATURES = {
     "cmpc_lstm_bwd_step": [_P, _P, _I, _P, _P, _P, _P, _I, _P, _I, _P, _P, _P, _I, _I, _I, _P],
     "cmpc_lstm_seq_fwd": [_P, _P, _I, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
     "cmpc_lstm_seq_bwd": [_P, _I, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
-    "cmpc_parse_softmax_fwd": [_P, _I, _P, _P, _I, _P],
-    "cmpc_parse_softmax_bwd": [_P, _P, _P, _P, _I, _I, _P],
-    "cmpc_lang_pool_fwd": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
-    "cmpc_lang_pool_bwd": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
+    "cmpc_parse_softmax_fwd": [_P, _I, _P, _P, _I, _I, _P],
+    "cmpc_parse_softmax_bwd": [_P, _P, _P, _P, _I, _I, _I, _P],
+    "cmpc_lang_pool_fwd": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
+    "cmpc_lang_pool_bwd": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
     "cmpc_bn_stats": [_I, _P, _I, _I, _I, _I, _F, _P, _P, _P],
     "cmpc_bn_from_moving": [_P, _P, _I, _I, _F, _P, _P],
     "cmpc_bn_update_moving": [_P, _I, _F, _P, _P, _I, _I, _P],

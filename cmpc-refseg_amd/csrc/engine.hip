@@ -98,6 +98,83 @@ __global__ void col_add3_kernel(float* __restrict__ dst, int stride, int col, co
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) dst[(long)i * stride + col] += a[i] + b[i] + c[i];
 }
+// dst[r, :] = src[0, :] for r < rows (tf.tile of a language vector over the sampled frames, CMPC_video_mm_tgraph_allvec.py:341)
+__global__ void tile_rows_kernel(const float* __restrict__ src, float* __restrict__ dst, int rows, int ld) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < rows * ld) dst[i] = src[i % ld];
+}
+// out[c] = sum_{r < rows} src[r, c]
+__global__ void sum_rows_kernel(const float* __restrict__ src, float* __restrict__ out, int rows, int ld, int accumulate) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= ld) return;
+    float s = accumulate ? out[c] : 0.f;
+    for (int r = 0; r < rows; ++r) s += src[(long)r * ld + c];
+    out[c] = s;
+}
+// The temporal graph's message passing on its F <= 8 nodes (CMPC_video_mm_tgraph_allvec.py:484-497): adj = softmax_g(scale * q[f] . k[g]),
+// Y[f] = sum_g adj[f, g] X[g].  One workgroup; everything is [F, ld] float32.
+__global__ __launch_bounds__(256) void tgraph_fwd_kernel(const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ X, float* __restrict__ adj,
+                                                        float* __restrict__ Y, int Fr, int ld, int C, float scale) {
+    __shared__ float sa[8][8];
+    __shared__ float red[4];
+    for (int f = 0; f < Fr; ++f)
+        for (int g = 0; g < Fr; ++g) {
+            float d = 0.f;
+            for (int c = threadIdx.x; c < C; c += 256) d += q[(long)f * ld + c] * k[(long)g * ld + c];
+            d = block_sum_256(d, red);
+            if (threadIdx.x == 0) sa[f][g] = d * scale;
+        }
+    __syncthreads();
+    if (threadIdx.x < Fr) {
+        const int f = threadIdx.x;
+        float m = sa[f][0];
+        for (int g = 1; g < Fr; ++g) m = fmaxf(m, sa[f][g]);
+        float sum = 0.f;
+        for (int g = 0; g < Fr; ++g) { sa[f][g] = expf(sa[f][g] - m); sum += sa[f][g]; }
+        for (int g = 0; g < Fr; ++g) { sa[f][g] /= sum; adj[f * 8 + g] = sa[f][g]; }
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < ld; c += 256)
+        for (int f = 0; f < Fr; ++f) {
+            float y = 0.f;
+            if (c < C) for (int g = 0; g < Fr; ++g) y += sa[f][g] * X[(long)g * ld + c];
+            Y[(long)f * ld + c] = y;
+        }
+}
+// dX[g] (+)= sum_f adj[f, g] dY[f];  dadj = dY . X^T -> softmax backward -> dS;  dq[f] = scale * sum_g dS[f, g] k[g];  dk[g] = scale * sum_f dS[f, g] q[f]
+__global__ __launch_bounds__(256) void tgraph_bwd_kernel(const float* __restrict__ dY, const float* __restrict__ adj, const float* __restrict__ X, const float* __restrict__ q,
+                                                        const float* __restrict__ k, float* __restrict__ dX, int acc_dX, float* __restrict__ dq, float* __restrict__ dk,
+                                                        int Fr, int ld, int C, float scale) {
+    __shared__ float da[8][8];
+    __shared__ float red[4];
+    for (int f = 0; f < Fr; ++f)
+        for (int g = 0; g < Fr; ++g) {
+            float d = 0.f;
+            for (int c = threadIdx.x; c < C; c += 256) d += dY[(long)f * ld + c] * X[(long)g * ld + c];
+            d = block_sum_256(d, red);
+            if (threadIdx.x == 0) da[f][g] = d;
+        }
+    __syncthreads();
+    if (threadIdx.x < Fr) {
+        const int f = threadIdx.x;
+        float dot = 0.f;
+        for (int g = 0; g < Fr; ++g) dot += da[f][g] * adj[f * 8 + g];
+        for (int g = 0; g < Fr; ++g) da[f][g] = adj[f * 8 + g] * (da[f][g] - dot) * scale;
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < ld; c += 256)
+        for (int a = 0; a < Fr; ++a) {
+            float x = 0.f, vq = 0.f, vk = 0.f;
+            if (c < C)
+                for (int b = 0; b < Fr; ++b) {
+                    x += adj[b * 8 + a] * dY[(long)b * ld + c];
+                    vq += da[a][b] * k[(long)b * ld + c];
+                    vk += da[b][a] * q[(long)b * ld + c];
+                }
+            dX[(long)a * ld + c] = acc_dX ? dX[(long)a * ld + c] + x : x;
+            dq[(long)a * ld + c] = vq; dk[(long)a * ld + c] = vk;
+        }
+}
 // scalars[0..5] = loss_all, loss_c3, loss_c4, loss_c5, loss_last, mIoU  (CMPC_model.py:440-447,486-490)
 __global__ void scalars_kernel(const float* __restrict__ l_last, const float* __restrict__ l5, const float* __restrict__ l4, const float* __restrict__ l3,
                                const int* __restrict__ inter, const int* __restrict__ uni, int B, float w0, float w5, float w4, float w3,
@@ -135,6 +212,11 @@ struct LevelBuf {          // one pyramid level (c5 / c4 / c3), forward then bac
     int cin;
     const void* feat;
     void* X0t;             // model V5_BILSTM: tanh(lateral) before the l2-normalisation (kept for the backward pass)
+    // model VIDEO (CMPC_video_mm_tgraph_allvec.py): temporal pooling / temporal graph / temporal context of one level; small tensors float32
+    void *X1m, *X0m, *CTX, *GLO, *ctA_t, *ctGv_t, *ctPT, *ctPTt, *TGN16, *TGNt, *dCTX, *dGLO, *dctA0_t, *dX0f;
+    float *g1, *lt, *kqv, *tlog, *tatt, *TG, *q, *k, *adj, *TY, *TG1, *TU, *TGN, *rrow_t, *ctv, *ctPTf, *ctk0s, *ctA0, *ctA, *ctGv, *ctsc, *ctx_rstd, *pb;
+    float *dTGN, *dTU, *dTG1, *dTY, *dTG, *dq, *dk, *dtatt, *dtlog, *dkqv, *dlt, *dac, *dctv, *dctPT, *dctk0s, *dctA, *dctA0, *dprc, *ctsc2, *dea;
+    double *tsums1, *tsums2, *tbs;
     void *X0, *P, *X1, *PT, *PTt, *gw_w_t, *gw_v_t, *Zt, *Y, *G, *U, *X2, *F;
     float *lat_rstd, *g, *mut_rstd, *Wd, *PTf, *k0s, *A0, *pr, *gw_w, *gw_v, *gsc, *Ztf, *rrow, *sb;
     double *sums1, *sums2;
@@ -196,6 +278,8 @@ struct cmpc_engine_s {
     float *vl, *vl_rstd, *nec, *nec_rstd, *dparse, *dwf, *dvl, *dnec;
     // model variant (cfg.model): CMPC_model = 3 levels (c5, c4, c3), 3 exchange modules per round, 3 ConvLSTM steps; CMPCv5_BiLSTM = 2 / 2 / 2
     bool v5 = false; int nlev = 3, nex = 3, ncl = 3;
+    bool vid = false; int Fr = 1, RF = 0, NC = 4;      // model VIDEO: sampled frames, rows of the per-frame maps (Fr * N, batch 1); parser classes (4 or 5)
+    float *ac = nullptr, *ac_rstd = nullptr, *dac = nullptr, *ea_t = nullptr, *ones_t = nullptr, *zeros_nt = nullptr;
     LstmDir ldir[2]; int ndir = 1;
     float *outs_bw = nullptr, *douts_bw = nullptr, *wft = nullptr, *dwft = nullptr;     // v5: un-reversed backward outputs / their gradient; tanh(words_feat conv)
     void* hsv = nullptr;                                               // v5 hsv: [R, 64] map (3 channels)
@@ -289,7 +373,10 @@ void build_manifest(E* e) {
     const int C = e->C, M = e->M, R = e->RNN;
     const int hx = (e->v5 && e->cfg.hsv) ? 3 : 0;
     add_param(e, "Variable", {e->V, e->G}, 0.f, 1.f);
-    if (!e->v5) {
+    if (e->vid) {                                                                  // vid:105-133: MultiRNNCell([BasicLSTMCell]) under scope "RNN"
+        add_param(e, "RNN/multi_rnn_cell/cell_0/basic_lstm_cell/kernel", {e->G + R, 4 * R}, 0.f, 1.f);
+        add_param(e, "RNN/multi_rnn_cell/cell_0/basic_lstm_cell/bias", {4 * R}, 0.f, 1.f);
+    } else if (!e->v5) {
         add_param(e, "rnn/lstm_cell/kernel", {e->G + R, 4 * R}, 0.f, 1.f);
         add_param(e, "rnn/lstm_cell/bias", {4 * R}, 0.f, 1.f);
     } else {                                                                       // BiLSTM(), v5:159-187
@@ -303,19 +390,30 @@ void build_manifest(E* e) {
     add_conv(e, "c4_lateral", 1, e->cfg.c4_dim + hx, C);
     if (!e->v5) add_conv(e, "c3_lateral", 1, e->cfg.c3_dim, C);
     add_conv(e, "words_parse_1", 1, R, e->P);
-    add_conv(e, "words_parse_2", 1, e->P, 4);
+    add_conv(e, "words_parse_2", 1, e->P, e->NC);
     for (int li = 0; li < e->nlev; ++li) {
         const char* lv = lvn(e, li);
         for (int hd = 1; hd <= 5; ++hd) {
             add_conv(e, fmt("vis_trans_%s_head%d", lv, hd), 1, C + 8, C);
             add_conv(e, fmt("lang_trans_%s_head%d", lv, hd), 1, R, C);
         }
+        if (e->vid) {                                                              // build_temp_graph / build_temp_ctx, vid:458-530
+            add_conv(e, fmt("tg_vtrans_%s", lv), 1, C, C);
+            add_conv(e, fmt("tg_ltrans_%s", lv), 1, R, R);
+            add_conv(e, fmt("tg_query_%s", lv), 1, C, C);
+            add_conv(e, fmt("tg_key_%s", lv), 1, C, C);
+            add_ln(e, fmt("gconv_feat_ln_temp_graph_%s", lv), C);
+            add_conv(e, fmt("gconv_update_temp_graph_%s", lv), 1, C, C);
+            add_ln(e, fmt("gconv_update_ln_temp_graph_%s", lv), C);
+            add_conv(e, fmt("mm_trans_%s", lv), 1, C, C);
+            add_conv(e, fmt("ctx_trans_%s", lv), 1, C, C);
+        }
         add_conv(e, fmt("words_trans_%s", lv), 1, R, R);
         add_conv(e, fmt("spa_graph_trans2_%s", lv), 1, C, C);
         add_ln(e, fmt("gconv_feat_ln_spa_graph_%s", lv), C);
         add_conv(e, fmt("gconv_update_spa_graph_%s", lv), 1, C, C);
         add_ln(e, fmt("gconv_update_ln_spa_graph_%s", lv), C);
-        add_conv(e, fmt("fusion_%s", lv), 1, 2 * C + R + 8, M);
+        add_conv(e, fmt("fusion_%s", lv), 1, (e->vid ? 3 : 2) * C + R + 8, M);        // vid:398-400: [lateral | spatial graph | temporal context | lang | grid]
     }
     for (int li = 0; li < e->nlev; ++li) add_conv(e, fmt("score_%s", lvn(e, li)), 3, M, 1);
     for (int xi = 0; xi < 2 * e->nex; ++xi) {
@@ -420,7 +518,7 @@ void plan_operands(E* e) {
     }
     if (e->v5) linear(e, "wfeat", "words_feat/DW", L, 2 * R, R, 2 * Cp, Cp, true, true, {{0, R, 0}, {R, R, Cp}});      // [fw | bw] -> R (v5:182)
     linear(e, "parse1", "words_parse_1/DW", L, R, P, Cp, Pp);
-    linear(e, "parse2", "words_parse_2/DW", L, P, 4, Pp, 64);
+    linear(e, "parse2", "words_parse_2/DW", L, P, e->NC, Pp, 64);
     e->stage0_ndesc = (int)e->descs.size();       // what the text encoder + parser read: packed (and published) first
     const int cins[3] = {e->cfg.vf_dim, e->cfg.c4_dim, e->cfg.c3_dim};
     for (int i = 0; i < e->nlev; ++i) {
@@ -452,8 +550,22 @@ void plan_operands(E* e) {
         linear(e, fmt("t2_%s", lv), fmt("spa_graph_trans2_%s/DW", lv), L, C, C, Cp, Cp);
         linear(e, fmt("gupd_%s", lv), fmt("gconv_update_spa_graph_%s/DW", lv), V, C, C, Cp, Cp);
         const std::string fus = fmt("fusion_%s/DW", lv);
-        linear(e, fmt("fus_%s", lv), fus, V, 2 * C + R + 8, M, 2 * Cp + 64, Mp, true, true, {{0, C, 0}, {C, C, Cp}, {2 * C + R, 8, 2 * Cp}});
-        linear(e, fmt("fusl_%s", lv), fus, L, R, M, Cp, Mp, true, true, {{2 * C, R, 0}});
+        if (!e->vid) {
+            linear(e, fmt("fus_%s", lv), fus, V, 2 * C + R + 8, M, 2 * Cp + 64, Mp, true, true, {{0, C, 0}, {C, C, Cp}, {2 * C + R, 8, 2 * Cp}});
+            linear(e, fmt("fusl_%s", lv), fus, L, R, M, Cp, Mp, true, true, {{2 * C, R, 0}});
+        } else {
+            // three visual K-segments; the tiled language vector is a per-sample bias and the grid a per-position bias (both float32 products)
+            linear(e, fmt("fus_%s", lv), fus, V, 3 * C + R + 8, M, 3 * Cp, Mp, true, true, {{0, C, 0}, {C, C, Cp}, {2 * C, C, 2 * Cp}});
+            linear(e, fmt("fusl_%s", lv), fus, L, R, M, Cp, Mp, true, true, {{3 * C, R, 0}});
+            linear(e, fmt("fussp_%s", lv), fus, L, 8, M, 64, Mp, true, false, {{3 * C + R, 8, 0}});
+            linear(e, fmt("tgv_%s", lv), fmt("tg_vtrans_%s/DW", lv), L, C, C, Cp, Cp);
+            linear(e, fmt("tgl_%s", lv), fmt("tg_ltrans_%s/DW", lv), L, R, R, Cp, Cp);
+            linear(e, fmt("tgq_%s", lv), fmt("tg_query_%s/DW", lv), L, C, C, Cp, Cp);
+            linear(e, fmt("tgk_%s", lv), fmt("tg_key_%s/DW", lv), L, C, C, Cp, Cp);
+            linear(e, fmt("tgu_%s", lv), fmt("gconv_update_temp_graph_%s/DW", lv), L, C, C, Cp, Cp);
+            linear(e, fmt("mmt_%s", lv), fmt("mm_trans_%s/DW", lv), L, C, C, Cp, Cp);
+            linear(e, fmt("ctxt_%s", lv), fmt("ctx_trans_%s/DW", lv), L, C, C, Cp, Cp);
+        }
     }
     for (int xi = 0; xi < 2 * e->nex; ++xi) {
         const char* x = exn(e, xi);
@@ -535,8 +647,9 @@ void plan_workspace(E* e, Bump& zf, Bump& zb, Bump& g) {
     const int B = e->B, T = e->T, N = e->N, R = e->R, Cp = e->Cp, Mp = e->Mp, Gp = e->Gp, Pp = e->Pp, Tp = e->Tp, H = e->H, W = e->W;
     const size_t es = e->esz, F = 4, D = 8;
     const int vd = e->dt;
+    const int RL = e->vid ? e->RF : R, BL = e->vid ? e->Fr : B;        // rows / "samples" of the per-frame maps (lateral, Mutan) of the video model
     e->zero_page = zf.take(256);
-    e->spatial = g.take((size_t)R * 64 * es);
+    e->spatial = g.take((size_t)RL * 64 * es);
     // ---- text encoder / parser / language pools
     for (int d = 0; d < e->ndir; ++d) {
         LstmDir& D = e->ldir[d];
@@ -567,27 +680,34 @@ void plan_workspace(E* e, Bump& zf, Bump& zb, Bump& g) {
     e->mask = (float*)g.take((size_t)B * T * F);
     e->h1 = (float*)g.take((size_t)B * T * Pp * F);
     e->lg = (float*)g.take((size_t)B * T * 64 * F);
-    e->parse = (float*)g.take((size_t)B * T * 4 * F);
+    e->parse = (float*)g.take((size_t)B * T * 8 * F);
     e->dlg = (float*)g.take((size_t)B * T * 64 * F);
     e->dh1 = (float*)g.take((size_t)B * T * Pp * F);
     e->vl = (float*)g.take((size_t)B * Cp * F); e->vl_rstd = (float*)g.take((size_t)B * F);
     e->nec = (float*)g.take((size_t)B * Cp * F); e->nec_rstd = (float*)g.take((size_t)B * F);
-    e->dparse = (float*)zb.take((size_t)B * T * 4 * F);
+    e->dparse = (float*)zb.take((size_t)B * T * 8 * F);
     e->dwf = (float*)zb.take((size_t)B * T * Cp * F);
     e->dvl = (float*)g.take((size_t)B * Cp * F);
     e->dnec = (float*)g.take((size_t)B * Cp * F);
-    tap(e, "words_feat", e->wf, 0, {B * T, Cp}); tap(e, "seq_mask", e->mask, 0, {B * T}); tap(e, "words_parse", e->parse, 0, {B * T, 4});
-    tap(e, "valid_lang", e->vl, 0, {B, Cp}); tap(e, "nec_lang", e->nec, 0, {B, Cp}); tap(e, "spatial", e->spatial, vd, {R, 64});
+    tap(e, "words_feat", e->wf, 0, {B * T, Cp}); tap(e, "seq_mask", e->mask, 0, {B * T}); tap(e, "words_parse", e->parse, 0, {B * T, e->NC});
+    tap(e, "valid_lang", e->vl, 0, {B, Cp}); tap(e, "nec_lang", e->nec, 0, {B, Cp}); tap(e, "spatial", e->spatial, vd, {RL, 64});
+    if (e->vid) {
+        e->ac = (float*)g.take((size_t)B * Cp * F); e->ac_rstd = (float*)g.take(256); e->dac = (float*)g.take((size_t)B * Cp * F);
+        e->ea_t = (float*)g.take((size_t)e->Fr * Cp * F);
+        e->ones_t = (float*)g.take((size_t)64 * F);                     // filled with 1 at create: pr / mask of the temporal-context softmax over the Fr graph nodes
+        e->zeros_nt = (float*)g.take((size_t)N * Tp * F);               // never written: the absent column-softmax gradient of that softmax
+        tap(e, "ac_lang", e->ac, 0, {B, Cp});
+    }
     // ---- pyramid levels
     const int cins[3] = {e->cfg.vf_dim, e->cfg.c4_dim, e->cfg.c3_dim};
     const int nch = (N + 63) / 64;
     for (int i = 0; i < e->nlev; ++i) {
         LevelBuf& L = e->lv[i]; const char* n = lvn(e, i);
         L.cin = cins[i];
-        L.X0 = g.take((size_t)R * Cp * es); L.lat_rstd = (float*)g.take((size_t)R * F);
+        L.X0 = g.take((size_t)RL * Cp * es); L.lat_rstd = (float*)g.take((size_t)RL * F);
         L.X0t = e->v5 ? g.take((size_t)R * Cp * es) : nullptr;
-        L.g = (float*)g.take((size_t)B * 5 * Cp * F); L.P = g.take((size_t)R * 5 * Cp * es);
-        L.X1 = g.take((size_t)R * Cp * es); L.mut_rstd = (float*)g.take((size_t)R * F);
+        L.g = (float*)g.take((size_t)BL * 5 * Cp * F); L.P = g.take((size_t)RL * 5 * Cp * es);
+        L.X1 = g.take((size_t)RL * Cp * es); L.mut_rstd = (float*)g.take((size_t)RL * F);
         L.Wd = (float*)zf.take((size_t)B * Tp * Cp * F);
         L.PTf = (float*)g.take((size_t)B * Tp * Cp * F); L.PT = g.take((size_t)B * Tp * Cp * es);
         L.PTt = g.take((size_t)Cp * B * Tp * es);
@@ -606,7 +726,7 @@ void plan_workspace(E* e, Bump& zf, Bump& zb, Bump& g) {
         // backward
         L.dfus = g.take((size_t)R * Mp * es); L.dscore = (float*)g.take((size_t)B * e->h * e->w * F);
         L.dpre = g.take((size_t)R * Mp * es); L.dsb = (float*)zb.take((size_t)B * Mp * F);
-        L.dX1 = g.take((size_t)R * Cp * es); L.dX2 = g.take((size_t)R * Cp * es); L.dvl = (float*)g.take((size_t)B * Cp * F);
+        L.dX1 = (e->vid ? zb : g).take((size_t)RL * Cp * es); L.dX2 = g.take((size_t)R * Cp * es); L.dvl = (float*)g.take((size_t)B * Cp * F);
         L.bs = (double*)g.take((size_t)B * STAT_PARTS * 2 * D);
         L.dU = g.take((size_t)R * Cp * es); L.dG = g.take((size_t)R * Cp * es); L.dY = g.take((size_t)R * Cp * es);
         L.Zf = (float*)(e->lowrank ? zf : zb).take((size_t)B * Tp * Cp * F); L.Z = g.take((size_t)B * Tp * Cp * es);     // lowrank: Z = gw_v^T . X1 is a forward product
@@ -618,9 +738,38 @@ void plan_workspace(E* e, Bump& zf, Bump& zb, Bump& g) {
         L.dpr = (float*)g.take((size_t)B * T * F); L.gsc2 = (float*)g.take((size_t)B * nch * 128 * F);
         L.dPT = (float*)zb.take((size_t)B * Tp * Cp * F); L.dk0s = (float*)zb.take((size_t)B * Tp * F);
         L.dWd = (float*)g.take((size_t)B * Tp * Cp * F); L.dwf = (float*)g.take((size_t)B * T * Cp * F);
-        L.dg = (float*)zb.take((size_t)B * 5 * Cp * F);
-        L.dX0 = g.take((size_t)R * Cp * es); L.dV = g.take((size_t)R * Cp * es);
-        tap(e, fmt("lat_%s", n), L.X0, vd, {R, Cp}); tap(e, fmt("vis_la_sp_%s", n), L.X1, vd, {R, Cp});
+        L.dg = (float*)zb.take((size_t)BL * 5 * Cp * F);
+        L.dX0 = g.take((size_t)RL * Cp * es); L.dV = g.take((size_t)RL * Cp * es);
+        if (e->vid) {
+            const int Fr = e->Fr, mid = Fr / 2;
+            L.X1m = (char*)L.X1 + (size_t)mid * N * Cp * es; L.X0m = (char*)L.X0 + (size_t)mid * N * Cp * es;
+            L.g1 = (float*)g.take((size_t)5 * Cp * F);
+            L.lt = (float*)g.take((size_t)Cp * F); L.kqv = (float*)g.take((size_t)Cp * F);
+            L.tlog = (float*)g.take((size_t)Fr * N * F); L.tatt = (float*)g.take((size_t)Fr * N * F);
+            L.TG = (float*)zf.take((size_t)Tp * Cp * F); L.q = (float*)g.take((size_t)Tp * Cp * F); L.k = (float*)g.take((size_t)Tp * Cp * F);
+            L.adj = (float*)g.take(256); L.TY = (float*)g.take((size_t)Tp * Cp * F); L.TG1 = (float*)g.take((size_t)Tp * Cp * F);
+            L.TU = (float*)g.take((size_t)Tp * Cp * F); L.TGN = (float*)g.take((size_t)Tp * Cp * F); L.rrow_t = (float*)g.take((size_t)Tp * F);
+            L.tsums1 = (double*)g.take((size_t)STAT_PARTS * 2 * D); L.tsums2 = (double*)g.take((size_t)STAT_PARTS * 2 * D); L.tbs = (double*)g.take((size_t)STAT_PARTS * 2 * D);
+            L.ctv = (float*)g.take((size_t)Tp * Cp * F); L.ctPTf = (float*)g.take((size_t)Tp * Cp * F); L.ctPT = g.take((size_t)Tp * Cp * es);
+            L.ctPTt = g.take((size_t)Cp * Tp * es); L.ctk0s = (float*)g.take((size_t)Tp * F);
+            L.ctA0 = (float*)g.take((size_t)N * Tp * F); L.ctA = (float*)g.take((size_t)N * Tp * F); L.ctGv = (float*)g.take((size_t)N * Tp * F);
+            L.ctA_t = g.take((size_t)N * Tp * es); L.ctGv_t = g.take((size_t)N * Tp * es); L.ctsc = (float*)g.take((size_t)nch * 128 * F); L.ctsc2 = (float*)g.take((size_t)nch * 128 * F);
+            L.TGN16 = g.take((size_t)Tp * Cp * es); L.TGNt = g.take((size_t)Cp * Tp * es);
+            L.GLO = g.take((size_t)N * Cp * es); L.CTX = g.take((size_t)N * Cp * es); L.ctx_rstd = (float*)g.take((size_t)N * F);
+            L.pb = (float*)g.take((size_t)N * Mp * F);
+            // backward
+            L.dCTX = g.take((size_t)N * Cp * es); L.dGLO = g.take((size_t)N * Cp * es); L.dX0f = g.take((size_t)N * Cp * es);
+            L.dTGN = (float*)zb.take((size_t)Tp * Cp * F); L.dTU = (float*)g.take((size_t)Tp * Cp * F); L.dTG1 = (float*)g.take((size_t)Tp * Cp * F);
+            L.dTY = (float*)g.take((size_t)Tp * Cp * F); L.dTG = (float*)g.take((size_t)Tp * Cp * F); L.dq = (float*)g.take((size_t)Tp * Cp * F); L.dk = (float*)g.take((size_t)Tp * Cp * F);
+            L.dtatt = (float*)g.take((size_t)Fr * N * F); L.dtlog = (float*)g.take((size_t)Fr * N * F);
+            L.dkqv = (float*)zb.take((size_t)Cp * F); L.dlt = (float*)g.take((size_t)Cp * F); L.dac = (float*)g.take((size_t)Cp * F);
+            L.dctv = (float*)g.take((size_t)Tp * Cp * F); L.dctPT = (float*)zb.take((size_t)Tp * Cp * F); L.dctk0s = (float*)zb.take((size_t)Tp * F);
+            L.dctA = (float*)g.take((size_t)N * Tp * F); L.dctA0 = (float*)g.take((size_t)N * Tp * F); L.dctA0_t = g.take((size_t)N * Tp * es);
+            L.dprc = (float*)g.take((size_t)64 * F); L.dea = (float*)g.take((size_t)Cp * F);
+            tap(e, fmt("mm_%s", n), L.X1, vd, {RL, Cp}); tap(e, fmt("tg_pool_%s", n), L.TG, 0, {Tp, Cp}); tap(e, fmt("tgraph_%s", n), L.TGN, 0, {Tp, Cp});
+            tap(e, fmt("temp_ctx_%s", n), L.CTX, vd, {N, Cp});
+        }
+        tap(e, fmt("lat_%s", n), L.X0, vd, {RL, Cp}); tap(e, fmt("vis_la_sp_%s", n), L.X1, vd, {RL, Cp});
         tap(e, fmt("spa_graph_%s", n), L.X2, vd, {R, Cp}); tap(e, fmt("fusion_%s", n), L.F, vd, {R, Mp});
         tap(e, fmt("gw_w_%s", n), L.gw_w, 0, {B, N, Tp}); tap(e, fmt("gw_v_%s", n), L.gw_v, 0, {B, N, Tp});
         tap(e, fmt("score_%s", n), L.score, 0, {B, e->h, e->w, 1}); tap(e, fmt("up_%s", n), L.up, 0, {B, H, W, 1});
@@ -1694,12 +1843,17 @@ extern "C" int cmpc_create(const cmpc_cfg* c, cmpc_handle* out) {
                 r[4] = (float)((xmin + xmax) / 2); r[5] = (float)((ymin + ymax) / 2); r[6] = (float)(1.0 / e->w); r[7] = (float)(1.0 / e->h);
             }
         float* tmp = nullptr;
-        ECK(hipMalloc(&tmp, (size_t)e->R * 64 * sizeof(float)));
-        for (int b = 0; b < e->B; ++b) ECK(hipMemcpy(tmp + (size_t)b * e->N * 64, sp.data(), sp.size() * sizeof(float), hipMemcpyHostToDevice));
-        if (e->dt == DT_F32) ECK(hipMemcpy(e->spatial, tmp, (size_t)e->R * 64 * sizeof(float), hipMemcpyDeviceToDevice));
-        else if (cmpc_cast(DT_F32, tmp, e->dt, e->spatial, (int64_t)e->R * 64, nullptr) != CMPC_OK) { (void)hipFree(tmp); return fail(CMPC_EHIP); }
+        const int reps = e->vid ? e->Fr : e->B;          // tf.tile(spatial, [sample_frames, 1, 1, 1]) for the per-frame Mutan of the video model (vid:333)
+        ECK(hipMalloc(&tmp, (size_t)reps * e->N * 64 * sizeof(float)));
+        for (int b = 0; b < reps; ++b) ECK(hipMemcpy(tmp + (size_t)b * e->N * 64, sp.data(), sp.size() * sizeof(float), hipMemcpyHostToDevice));
+        if (e->dt == DT_F32) ECK(hipMemcpy(e->spatial, tmp, (size_t)reps * e->N * 64 * sizeof(float), hipMemcpyDeviceToDevice));
+        else if (cmpc_cast(DT_F32, tmp, e->dt, e->spatial, (int64_t)reps * e->N * 64, nullptr) != CMPC_OK) { (void)hipFree(tmp); return fail(CMPC_EHIP); }
         ECK(hipDeviceSynchronize());
         (void)hipFree(tmp);
+    }
+    if (e->vid) {
+        std::vector<float> on(64, 1.0f);
+        ECK(hipMemcpy(e->ones_t, on.data(), on.size() * sizeof(float), hipMemcpyHostToDevice));
     }
     if (e->v5) {
         std::vector<float> on((size_t)e->B * e->N, 1.0f / (float)e->N);       // tf.reduce_mean over the map (v5:242)

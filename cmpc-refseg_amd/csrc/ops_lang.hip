@@ -312,39 +312,40 @@ __global__ __launch_bounds__(256) void lstm_seq_bwd_kernel(const float* __restri
     }
 }
 
-__global__ void parse_softmax_fwd_kernel(const float* __restrict__ logits, int ld, const float* __restrict__ mask, float* __restrict__ parse, int n) {
+__global__ void parse_softmax_fwd_kernel(const float* __restrict__ logits, int ld, const float* __restrict__ mask, float* __restrict__ parse, int n, int ncls) {
     const int r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= n) return;
     const float* l = logits + (long)r * ld;
-    const float m = fmaxf(fmaxf(l[0], l[1]), fmaxf(l[2], l[3]));
-    const float e0 = expf(l[0] - m), e1 = expf(l[1] - m), e2 = expf(l[2] - m), e3 = expf(l[3] - m);
-    const float s = e0 + e1 + e2 + e3, mk = mask[r];
-    parse[r * 4 + 0] = e0 / s * mk; parse[r * 4 + 1] = e1 / s * mk; parse[r * 4 + 2] = e2 / s * mk; parse[r * 4 + 3] = e3 / s * mk;
+    float m = l[0];
+    for (int k = 1; k < ncls; ++k) m = fmaxf(m, l[k]);
+    float e[8], s = 0.f;
+    for (int k = 0; k < ncls; ++k) { e[k] = expf(l[k] - m); s += e[k]; }
+    const float mk = mask[r];
+    for (int k = 0; k < ncls; ++k) parse[r * ncls + k] = e[k] / s * mk;
 }
 
 __global__ void parse_softmax_bwd_kernel(const float* __restrict__ dparse, const float* __restrict__ parse, const float* __restrict__ mask,
-                                         float* __restrict__ dlogits, int ld, int n) {
+                                         float* __restrict__ dlogits, int ld, int n, int ncls) {
     const int r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= n) return;
     const float mk = mask[r];
-    float p[4], d[4], dot = 0.f;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) { p[k] = parse[r * 4 + k]; d[k] = dparse[r * 4 + k] * mk; dot += p[k] * d[k]; }
-#pragma unroll
-    for (int k = 0; k < 4; ++k) dlogits[(long)r * ld + k] = (mk != 0.f) ? p[k] * (d[k] - dot) : 0.f;
-    for (int k = 4; k < ld; ++k) dlogits[(long)r * ld + k] = 0.f;
+    float p[8], d[8], dot = 0.f;
+    for (int k = 0; k < ncls; ++k) { p[k] = parse[r * ncls + k]; d[k] = dparse[r * ncls + k] * mk; dot += p[k] * d[k]; }
+    for (int k = 0; k < ncls; ++k) dlogits[(long)r * ld + k] = (mk != 0.f) ? p[k] * (d[k] - dot) : 0.f;
+    for (int k = ncls; k < ld; ++k) dlogits[(long)r * ld + k] = 0.f;
 }
+
 
 // valid_lang / nec_lang (CMPC_model.py:166-192): v[b] = l2norm(sum_t w[b,t] wf[b,t,:]), w = sum of the first ncls parser classes.
 // One 1024-thread block per sample: thread = 1..4 columns, the T word weights staged in LDS, the T loads of a column independent.
 __global__ __launch_bounds__(1024) void lang_pool_fwd_kernel(const float* __restrict__ parse, const float* __restrict__ wf, float* __restrict__ v,
-                                                            float* __restrict__ rstd, int T, int ld, int R, int ncls) {
+                                                            float* __restrict__ rstd, int T, int ld, int R, int ncls, int lo, int ps) {
     __shared__ float wgt[64];
     __shared__ float red[16];
     const int b = blockIdx.x, tid = threadIdx.x;
     if (tid < T) {
         float w = 0.f;
-        for (int k = 0; k < ncls; ++k) w += parse[((long)b * T + tid) * 4 + k];
+        for (int k = 0; k < ncls; ++k) w += parse[((long)b * T + tid) * ps + lo + k];
         wgt[tid] = w;
     }
     __syncthreads();
@@ -375,7 +376,7 @@ __global__ __launch_bounds__(1024) void lang_pool_fwd_kernel(const float* __rest
 // dparse[b,t,k<ncls] += draw . wf[b,t,:];  dwf[b,t,:] += w[b,t] draw.   (both accumulate: the two pools share the buffers)
 __global__ __launch_bounds__(256) void lang_pool_bwd_kernel(const float* __restrict__ dv, const float* __restrict__ v, const float* __restrict__ rstd,
                                                            const float* __restrict__ parse, const float* __restrict__ wf,
-                                                           float* __restrict__ dparse, float* __restrict__ dwf, int T, int ld, int R, int ncls) {
+                                                           float* __restrict__ dparse, float* __restrict__ dwf, int T, int ld, int R, int ncls, int lo, int ps) {
     __shared__ float red[4];
     const int b = blockIdx.x, t = blockIdx.y;
     float dot = 0.f;
@@ -384,7 +385,7 @@ __global__ __launch_bounds__(256) void lang_pool_bwd_kernel(const float* __restr
     const float rs = rstd[b], a = fabsf(rs);
     if (rs < 0.f) dot = 0.f;
     float wgt = 0.f;
-    for (int k = 0; k < ncls; ++k) wgt += parse[((long)b * T + t) * 4 + k];
+    for (int k = 0; k < ncls; ++k) wgt += parse[((long)b * T + t) * ps + lo + k];
     float dw = 0.f;
     for (int c = threadIdx.x; c < R; c += 256) {
         const float draw = a * (dv[(long)b * ld + c] - v[(long)b * ld + c] * dot);
@@ -394,7 +395,7 @@ __global__ __launch_bounds__(256) void lang_pool_bwd_kernel(const float* __restr
     }
     dw = block_sum_256(dw, red);
     if (threadIdx.x == 0)
-        for (int k = 0; k < ncls; ++k) dparse[((long)b * T + t) * 4 + k] += dw;
+        for (int k = 0; k < ncls; ++k) dparse[((long)b * T + t) * ps + lo + k] += dw;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -440,7 +441,14 @@ __global__ __launch_bounds__(256) void pack_kernel(const float* __restrict__ mas
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
         if (k < Kp && sc >= 0) {
             const int sr = seg_map(k, d.nks, d.ks_src, d.ks_len, d.ks_dst);
-            if (sr >= 0) v = *reinterpret_cast<const float4*>(master + d.src_off + (long)sr * d.ld_src + sc);
+            if (sr >= 0) {
+                const float* src = master + d.src_off + (long)sr * d.ld_src + sc;
+                if ((d.ld_src & 3) == 0) v = *reinterpret_cast<const float4*>(src);
+                else {          // master rows that are not 16-B aligned (the 5-class parser of the video model, [500, 5]): scalar reads clipped to the row
+                    const int lim = d.ld_src - sc;
+                    v.x = src[0]; v.y = lim > 1 ? src[1] : 0.f; v.z = lim > 2 ? src[2] : 0.f; v.w = lim > 3 ? src[3] : 0.f;
+                }
+            }
         }
         if (!d.transpose) {
             if (k < Kp && n < Np) {
@@ -563,24 +571,26 @@ extern "C" int cmpc_lstm_seq_bwd(const float* Wn, int ldw, const float* gates, c
     hipLaunchKernelGGL(lstm_seq_bwd_kernel, dim3(ld / 4), dim3(256), lds, ST, Wn, ldw, gates, c_all, seq_len, douts, dgates, (unsigned*)sync, (int*)sync + 1, B, T, ld, R);
     return cmpc_check_launch("lstm_seq_bwd");
 }
-extern "C" int cmpc_parse_softmax_fwd(const float* logits, int ld, const float* mask, float* parse, int n, void* stream) {
-    hipLaunchKernelGGL(parse_softmax_fwd_kernel, dim3((n + 63) / 64), dim3(64), 0, ST, logits, ld, mask, parse, n);
+extern "C" int cmpc_parse_softmax_fwd(const float* logits, int ld, const float* mask, float* parse, int n, int ncls, void* stream) {
+    if (ncls < 2 || ncls > 8 || ncls > ld) { cmpc_set_error("parse_softmax: 2 <= ncls <= 8"); return CMPC_EINVAL; }
+    hipLaunchKernelGGL(parse_softmax_fwd_kernel, dim3((n + 63) / 64), dim3(64), 0, ST, logits, ld, mask, parse, n, ncls);
     return cmpc_check_launch("parse_softmax_fwd");
 }
-extern "C" int cmpc_parse_softmax_bwd(const float* dparse, const float* parse, const float* mask, float* dlogits, int ld, int n, void* stream) {
-    hipLaunchKernelGGL(parse_softmax_bwd_kernel, dim3((n + 63) / 64), dim3(64), 0, ST, dparse, parse, mask, dlogits, ld, n);
+extern "C" int cmpc_parse_softmax_bwd(const float* dparse, const float* parse, const float* mask, float* dlogits, int ld, int n, int ncls, void* stream) {
+    if (ncls < 2 || ncls > 8 || ncls > ld) { cmpc_set_error("parse_softmax: 2 <= ncls <= 8"); return CMPC_EINVAL; }
+    hipLaunchKernelGGL(parse_softmax_bwd_kernel, dim3((n + 63) / 64), dim3(64), 0, ST, dparse, parse, mask, dlogits, ld, n, ncls);
     return cmpc_check_launch("parse_softmax_bwd");
 }
-extern "C" int cmpc_lang_pool_fwd(const float* parse, const float* wf, float* v, float* rstd, int B, int T, int ld, int R, int ncls, void* stream) {
-    if (ncls < 1 || ncls > 4) { cmpc_set_error("lang_pool: ncls must be 1..4"); return CMPC_EINVAL; }
+extern "C" int cmpc_lang_pool_fwd(const float* parse, const float* wf, float* v, float* rstd, int B, int T, int ld, int R, int ncls, int cls_lo, int pstride, void* stream) {
+    if (ncls < 1 || cls_lo < 0 || cls_lo + ncls > pstride || pstride > 8) { cmpc_set_error("lang_pool: classes [cls_lo, cls_lo + ncls) must lie inside a parse row of pstride <= 8"); return CMPC_EINVAL; }
     if (T > 64 || ld > 2048) { cmpc_set_error("lang_pool: T <= 64 and ld <= 2048"); return CMPC_EINVAL; }
-    hipLaunchKernelGGL(lang_pool_fwd_kernel, dim3(B), dim3(1024), 0, ST, parse, wf, v, rstd, T, ld, R, ncls);
+    hipLaunchKernelGGL(lang_pool_fwd_kernel, dim3(B), dim3(1024), 0, ST, parse, wf, v, rstd, T, ld, R, ncls, cls_lo, pstride);
     return cmpc_check_launch("lang_pool_fwd");
 }
 extern "C" int cmpc_lang_pool_bwd(const float* dv, const float* v, const float* rstd, const float* parse, const float* wf,
-                                  float* dparse, float* dwf, int B, int T, int ld, int R, int ncls, void* stream) {
-    if (ncls < 1 || ncls > 4) { cmpc_set_error("lang_pool: ncls must be 1..4"); return CMPC_EINVAL; }
-    hipLaunchKernelGGL(lang_pool_bwd_kernel, dim3(B, T), dim3(256), 0, ST, dv, v, rstd, parse, wf, dparse, dwf, T, ld, R, ncls);
+                                  float* dparse, float* dwf, int B, int T, int ld, int R, int ncls, int cls_lo, int pstride, void* stream) {
+    if (ncls < 1 || cls_lo < 0 || cls_lo + ncls > pstride || pstride > 8) { cmpc_set_error("lang_pool: classes [cls_lo, cls_lo + ncls) must lie inside a parse row of pstride <= 8"); return CMPC_EINVAL; }
+    hipLaunchKernelGGL(lang_pool_bwd_kernel, dim3(B, T), dim3(256), 0, ST, dv, v, rstd, parse, wf, dparse, dwf, T, ld, R, ncls, cls_lo, pstride);
     return cmpc_check_launch("lang_pool_bwd");
 }
 

@@ -248,12 +248,14 @@ int cmpc_lstm_seq_fwd(const float* xg, const float* Wh, int ldw, const int* seq_
 int cmpc_lstm_seq_bwd(const float* Wn, int ldw, const float* gates, const float* c_all, const int* seq_len, const float* douts, float* dgates,
                       void* sync, int B, int T, int ld, int R, void* stream);
 /* softmax over the 4 parser classes times seq_mask (:352-353) */
-int cmpc_parse_softmax_fwd(const float* logits, int ld, const float* mask, float* parse, int n, void* stream);
-int cmpc_parse_softmax_bwd(const float* dparse, const float* parse, const float* mask, float* dlogits, int ld, int n, void* stream);
-/* valid_lang (ncls=2) / nec_lang (ncls=3): v[b] = l2norm(sum_t (sum_{k<ncls} parse[b,t,k]) wf[b,t,:]) */
-int cmpc_lang_pool_fwd(const float* parse, const float* wf, float* v, float* rstd, int B, int T, int ld, int R, int ncls, void* stream);
+/* ncls classes per word (4: CMPC_model.py:351; 5: CMPC_video_mm_tgraph_allvec.py:406); parse rows are ncls wide */
+int cmpc_parse_softmax_fwd(const float* logits, int ld, const float* mask, float* parse, int n, int ncls, void* stream);
+int cmpc_parse_softmax_bwd(const float* dparse, const float* parse, const float* mask, float* dlogits, int ld, int n, int ncls, void* stream);
+/* valid_lang (classes 0,1) / nec_lang (0..2) / the video model's action vector (class 3 alone, vid:203-213):
+ * v[b] = l2norm(sum_t (sum_{cls_lo <= k < cls_lo + ncls} parse[b,t,k]) wf[b,t,:]); pstride = classes per parse row */
+int cmpc_lang_pool_fwd(const float* parse, const float* wf, float* v, float* rstd, int B, int T, int ld, int R, int ncls, int cls_lo, int pstride, void* stream);
 int cmpc_lang_pool_bwd(const float* dv, const float* v, const float* rstd, const float* parse, const float* wf,
-                       float* dparse, float* dwf, int B, int T, int ld, int R, int ncls, void* stream);
+                       float* dparse, float* dwf, int B, int T, int ld, int R, int ncls, int cls_lo, int pstride, void* stream);
 
 /* ---- CMPCv5_BiLSTM_model.py ("v5:") / CMPCv5_BiLSTM_HSV_model.py ("hsv:") stages that CMPC_model does not have ----------------
  * slim conv2d under resnet_v2.resnet_arg_scope (v5:192-193,229-230) = convolution without bias + batch_norm(decay, epsilon 1e-5,
