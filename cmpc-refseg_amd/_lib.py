@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libcmpc_hip.so")
 
 DT_F32, DT_BF16, DT_F16 = 0, 1, 2
-MODEL_CMPC, MODEL_V5_BILSTM = 0, 1
+MODEL_CMPC, MODEL_V5_BILSTM, MODEL_VIDEO = 0, 1, 2
 ABI_VERSION = 2          # CMPC_ABI_VERSION of include/cmpc.h this binding was written against
 ACT_NONE, ACT_RELU, ACT_TANH, ACT_SIGMOID = 0, 1, 2, 3
 
@@ -104,7 +104,7 @@ class EngineCfg(C.Structure):
         ("weight_decay", C.c_float), ("loss_w", C.c_float * 4),
         ("dtype", C.c_int), ("loss_scale", C.c_float), ("n_lanes", C.c_int), ("device", C.c_int),
         ("model", C.c_int), ("hsv", C.c_int), ("bn_train", C.c_int), ("bn_decay", C.c_float),
-        ("c2_dim", C.c_int), ("c2_h", C.c_int), ("c2_w", C.c_int), ("aspp_depth", C.c_int), ("low_dim", C.c_int), ("aspp_rates", C.c_int * 3),
+        ("c2_dim", C.c_int), ("c2_h", C.c_int), ("c2_w", C.c_int), ("aspp_depth", C.c_int), ("low_dim", C.c_int), ("aspp_rates", C.c_int * 3), ("sample_frames", C.c_int),
     ]
 
 

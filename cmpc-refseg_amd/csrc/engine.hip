@@ -557,7 +557,7 @@ void plan_operands(E* e) {
             // three visual K-segments; the tiled language vector is a per-sample bias and the grid a per-position bias (both float32 products)
             linear(e, fmt("fus_%s", lv), fus, V, 3 * C + R + 8, M, 3 * Cp, Mp, true, true, {{0, C, 0}, {C, C, Cp}, {2 * C, C, 2 * Cp}});
             linear(e, fmt("fusl_%s", lv), fus, L, R, M, Cp, Mp, true, true, {{3 * C, R, 0}});
-            linear(e, fmt("fussp_%s", lv), fus, L, 8, M, 64, Mp, true, false, {{3 * C + R, 8, 0}});
+            linear(e, fmt("fussp_%s", lv), fus, V, 8, M, 64, Mp, true, false, {{3 * C + R, 8, 0}});
             linear(e, fmt("tgv_%s", lv), fmt("tg_vtrans_%s/DW", lv), L, C, C, Cp, Cp);
             linear(e, fmt("tgl_%s", lv), fmt("tg_ltrans_%s/DW", lv), L, R, R, Cp, Cp);
             linear(e, fmt("tgq_%s", lv), fmt("tg_query_%s/DW", lv), L, C, C, Cp, Cp);
@@ -1159,17 +1159,17 @@ int parser_fwd(E* e, hipStream_t st) {
     const int BT = e->B * e->T, P = e->P, Cp = e->Cp, Pp = e->Pp;
     GemmOpt a; a.n_valid = P; a.bias = pptr(e, "words_parse_1/biases"); a.act = ACT_RELU;
     CK(gemm_nt(st, DT_F32, {{e->wf, Cp, opp(e, "parse1.t"), Cp, Cp}}, e->h1, Pp, BT, Pp, a));
-    GemmOpt b; b.n_valid = 4; b.bias = pptr(e, "words_parse_2/biases");
+    GemmOpt b; b.n_valid = e->NC; b.bias = pptr(e, "words_parse_2/biases");
     CK(gemm_nt(st, DT_F32, {{e->h1, Pp, opp(e, "parse2.t"), Pp, Pp}}, e->lg, 64, BT, 64, b));
-    return cmpc_parse_softmax_fwd(e->lg, 64, e->mask, e->parse, BT, st);
+    return cmpc_parse_softmax_fwd(e->lg, 64, e->mask, e->parse, BT, e->NC, st);
 }
 // dwf accumulates on top of e->dwf
 int parser_bwd(E* e, hipStream_t st) {
     const int BT = e->B * e->T, R = e->RNN, P = e->P, Cp = e->Cp, Pp = e->Pp;
     TnOpt d; d.defer = true;
-    CK(cmpc_parse_softmax_bwd(e->dparse, e->parse, e->mask, e->dlg, 64, BT, st));
-    CK(colsum(st, DT_F32, e->dlg, BT, 64, 64, 4, gptr(e, "words_parse_2/biases")));
-    CK(gemm_tn(e, st, DT_F32, e->h1, Pp, Pp, e->dlg, 64, 64, gptr(e, "words_parse_2/DW"), 4, BT, P, 4, OFF0, d));
+    CK(cmpc_parse_softmax_bwd(e->dparse, e->parse, e->mask, e->dlg, 64, BT, e->NC, st));
+    CK(colsum(st, DT_F32, e->dlg, BT, 64, 64, e->NC, gptr(e, "words_parse_2/biases")));
+    CK(gemm_tn(e, st, DT_F32, e->h1, Pp, Pp, e->dlg, 64, 64, gptr(e, "words_parse_2/DW"), e->NC, BT, P, e->NC, OFF0, d));
     GemmOpt a; a.n_valid = P;
     CK(gemm_nt(st, DT_F32, {{e->dlg, 64, opp(e, "parse2.n"), 64, 64}}, e->dh1, Pp, BT, Pp, a));
     CK(colsum(st, DT_F32, e->dh1, BT, Pp, Pp, P, gptr(e, "words_parse_1/biases"), e->h1, e->dh1, ACT_RELU));
@@ -1198,7 +1198,7 @@ int level_lang_fwd(E* e, hipStream_t st, int li) {
       CK(cmpc_cast(DT_F32, L.PTf, dt, L.PT, (int64_t)B * Tp * Cp, st));
       if (!e->lowrank) CK(transpose_cast(st, L.PTf, dt, L.PTt, B * Tp, Cp));   // PT^T [Cp][B*Tp] (GEMM operand of dX1 += dA0 . PT)
       CK(cmpc_rowdot1(DT_F32, L.Wd, pptr(e, fmt("spa_graph_trans2_%s/biases", lv)), 0, L.k0s, 1, B * Tp, Cp, C, scale, st));
-      hipLaunchKernelGGL(col_get_kernel, dim3((B * T + 255) / 256), dim3(256), 0, st, e->parse, 4, 2, L.pr, B * T);
+      hipLaunchKernelGGL(col_get_kernel, dim3((B * T + 255) / 256), dim3(256), 0, st, e->parse, e->NC, 2, L.pr, B * T);
       CK(cmpc_check_launch("col_get")); }
     { GemmOpt s; s.n_valid = M;
       CK(gemm_nt(st, DT_F32, {{e->vl, Cp, opp(e, fmt("fusl_%s.t", lv)), Cp, Cp}}, L.sb, Mp, B, Mp, s)); }
@@ -1367,6 +1367,277 @@ int level_bwd(E* e, hipStream_t st, int li, const float* target) {
     float* glw = gptr(e, fmt("%s_lateral/DW", lv));
     if (e->v5 && e->cfg.hsv) CK(gemm_tn(e, st, dt, e->hsv, 64, 64, L.dV, Cp, Cp, glw + (size_t)L.cin * C, C, R, 3, C, OFF0, d));
     return gemm_tn(e, st, dt, L.feat, L.cin, L.cin, L.dV, Cp, Cp, glw, C, R, L.cin, C, OFF0, d);
+}
+
+// ------------------------------------------------------------------------------------------
+// The video model's level (CMPC_video_mm_tgraph_allvec.py:368-402, "vid:", batch 1): laterals + Mutan on the Fr sampled frames (rows
+// f * N + n), a temporal graph over per-frame language-attention pools, and -- for the middle frame -- a temporal context, CMPC_model's
+// word graph and the fusion over [lateral | spatial graph | temporal context | language | grid].  Two folds keep C x C products off the
+// maps, as in CMPC_model's word graph: tg_vtrans goes into the query (logit = X1 . (W_v lt); the constant b_v . lt cancels in the softmax
+// over the nodes, so its exact bias gradient is 0), mm_trans into the node side of the affinity (PT = ct . W_m^T, k0 = ct . b_m).
+// ------------------------------------------------------------------------------------------
+int level_lang_fwd_video(E* e, hipStream_t st, int li) {
+    LevelBuf& L = e->lv[li]; const char* lv = lvn(e, li);
+    const int T = e->T, C = e->C, Cp = e->Cp, Tp = e->Tp, M = e->M, Mp = e->Mp, dt = e->dt, Fr = e->Fr, N = e->N;
+    // Mutan gates from the entity+attribute vector (vid:370-371), tiled over the frames (vid:341)
+    { GemmOpt o; o.bias = (const float*)opp(e, fmt("mlang_%s.b", lv)); o.act = ACT_TANH;
+      CK(gemm_nt(st, DT_F32, {{e->vl, Cp, opp(e, fmt("mlang_%s.t", lv)), Cp, Cp}}, L.g1, 5 * Cp, 1, 5 * Cp, o));
+      hipLaunchKernelGGL(tile_rows_kernel, dim3((Fr * 5 * Cp + 255) / 256), dim3(256), 0, st, L.g1, L.g, Fr, 5 * Cp);
+      CK(cmpc_check_launch("tile_rows")); }
+    // temporal pooling query: lt = conv(tg_ltrans)(ac_lang); kqv = W_v . lt (vid:464-472)
+    { GemmOpt o; o.n_valid = C; o.bias = pptr(e, fmt("tg_ltrans_%s/biases", lv));
+      CK(gemm_nt(st, DT_F32, {{e->ac, Cp, opp(e, fmt("tgl_%s.t", lv)), Cp, Cp}}, L.lt, Cp, 1, Cp, o));
+      GemmOpt k; k.n_valid = C;
+      CK(gemm_nt(st, DT_F32, {{L.lt, Cp, opp(e, fmt("tgv_%s.n", lv)), Cp, Cp}}, L.kqv, Cp, 1, Cp, k)); }
+    // word graph of the middle frame: as CMPC_model's language side (B = 1)
+    { const float scale = 1.0f / sqrtf((float)C);
+      GemmOpt a; a.n_valid = C; a.bias = pptr(e, fmt("words_trans_%s/biases", lv));
+      CK(gemm_nt(st, DT_F32, {{e->wf, Cp, opp(e, fmt("wtrans_%s.t", lv)), Cp, Cp}}, L.Wd, Cp, T, Cp, a));
+      GemmOpt b; b.n_valid = C;
+      CK(gemm_nt(st, DT_F32, {{L.Wd, Cp, opp(e, fmt("t2_%s.n", lv)), Cp, Cp}}, L.PTf, Cp, Tp, Cp, b));
+      CK(cmpc_cast(DT_F32, L.PTf, dt, L.PT, (int64_t)Tp * Cp, st));
+      if (!e->lowrank) CK(transpose_cast(st, L.PTf, dt, L.PTt, Tp, Cp));
+      CK(cmpc_rowdot1(DT_F32, L.Wd, pptr(e, fmt("spa_graph_trans2_%s/biases", lv)), 0, L.k0s, 1, Tp, Cp, C, scale, st));
+      hipLaunchKernelGGL(col_get_kernel, dim3((T + 255) / 256), dim3(256), 0, st, e->parse, e->NC, 2, L.pr, T);
+      CK(cmpc_check_launch("col_get")); }
+    // fusion: the tiled language vector (all but "unnecessary", vid:394-395) as a per-sample bias, the grid as a per-position bias
+    { GemmOpt sv; sv.n_valid = M;
+      CK(gemm_nt(st, DT_F32, {{e->nec, Cp, opp(e, fmt("fusl_%s.t", lv)), Cp, Cp}}, L.sb, Mp, 1, Mp, sv));
+      GemmOpt pv; pv.n_valid = M; pv.c_f32 = 1;
+      CK(gemm_nt(st, dt, {{e->spatial, 64, opp(e, fmt("fussp_%s.t", lv)), 64, 64}}, L.pb, Mp, N, Mp, pv)); }
+    return CMPC_OK;
+}
+
+int level_fwd_video(E* e, hipStream_t st, int li, const float* target) {
+    LevelBuf& L = e->lv[li]; const char* lv = lvn(e, li);
+    const int N = e->N, T = e->T, C = e->C, Cp = e->Cp, Tp = e->Tp, M = e->M, Mp = e->Mp, dt = e->dt, Fr = e->Fr, RF = e->RF;
+    const float scale = 1.0f / sqrtf((float)C);
+    // -- laterals + Mutan on every sampled frame (vid:151-157,330-366)
+    { GemmOpt o; o.n_valid = C; o.bias = pptr(e, fmt("%s_lateral/biases", lv));
+      CK(gemm_nt(st, dt, {{L.feat, L.cin, opp(e, fmt("lat_%s.t", lv)), L.cin, L.cin}}, L.X0, Cp, RF, Cp, o));
+      CK(cmpc_l2norm_rows_fwd(dt, L.X0, L.X0, L.lat_rstd, nullptr, RF, Cp, C, st)); }
+    { const int ldk = Cp + 64; const std::string k = fmt("mutan_%s.t", lv);
+      GemmOpt p; p.bias = (const float*)opp(e, fmt("mutan_%s.b", lv)); if (e->mutan_epilogue) p.act = ACT_TANH;
+      CK(gemm_nt(st, dt, {{L.X0, Cp, opp(e, k), ldk, Cp}, {e->spatial, 64, opp(e, k, 0, Cp), ldk, 64}}, L.P, 5 * Cp, RF, 5 * Cp, p));
+      CK(cmpc_mutan_fwd(dt, L.P, L.g, L.X1, L.mut_rstd, Fr, N, Cp, C, e->mutan_epilogue ? 1 : 0, st)); }
+    // -- temporal graph (vid:458-503): per-frame attention pooling with the action vector, 5 x 5 adjacency, graph_conv, l2norm
+    CK(cmpc_rowdot1(dt, L.X1, L.kqv, 0, L.tlog, Fr, N, Cp, C, scale, st));
+    CK(cmpc_softmax_n_fwd(L.tlog, L.tatt, Fr, N, st));
+    CK(cmpc_wcolsum(dt, L.X1, L.tatt, L.TG, Cp, Fr, N, Cp, C, 1.0f, st));
+    { GemmOpt o; o.n_valid = C; o.bias = pptr(e, fmt("tg_query_%s/biases", lv));
+      CK(gemm_nt(st, DT_F32, {{L.TG, Cp, opp(e, fmt("tgq_%s.t", lv)), Cp, Cp}}, L.q, Cp, Fr, Cp, o));
+      o.bias = pptr(e, fmt("tg_key_%s/biases", lv));
+      CK(gemm_nt(st, DT_F32, {{L.TG, Cp, opp(e, fmt("tgk_%s.t", lv)), Cp, Cp}}, L.k, Cp, Fr, Cp, o)); }
+    hipLaunchKernelGGL(tgraph_fwd_kernel, dim3(1), dim3(256), 0, st, L.q, L.k, L.TG, L.adj, L.TY, Fr, Cp, C, scale);
+    CK(cmpc_check_launch("tgraph_fwd"));
+    { const std::string ln1 = fmt("gconv_feat_ln_temp_graph_%s", lv), ln2 = fmt("gconv_update_ln_temp_graph_%s", lv);
+      CK(cmpc_sample_stats(DT_F32, L.TY, L.tsums1, 1, Fr, Cp, C, st));
+      CK(cmpc_gconv_pre_fwd(DT_F32, L.TY, L.TG, L.tsums1, pptr(e, ln1 + "/gamma"), pptr(e, ln1 + "/beta"), L.TG1, 1, Fr, Cp, C, st));
+      GemmOpt u; u.n_valid = C; u.bias = pptr(e, fmt("gconv_update_temp_graph_%s/biases", lv));
+      CK(gemm_nt(st, DT_F32, {{L.TG1, Cp, opp(e, fmt("tgu_%s.t", lv)), Cp, Cp}}, L.TU, Cp, Fr, Cp, u));
+      CK(cmpc_sample_stats(DT_F32, L.TU, L.tsums2, 1, Fr, Cp, C, st));
+      CK(cmpc_gconv_post_fwd(DT_F32, L.TU, L.tsums2, pptr(e, ln2 + "/gamma"), pptr(e, ln2 + "/beta"), L.TGN, L.rrow_t, 1, Fr, Cp, C, st)); }
+    // -- temporal context of the middle frame (vid:505-530): every pixel attends over the Fr graph nodes
+    { GemmOpt o; o.n_valid = C; o.bias = pptr(e, fmt("ctx_trans_%s/biases", lv));
+      CK(gemm_nt(st, DT_F32, {{L.TGN, Cp, opp(e, fmt("ctxt_%s.t", lv)), Cp, Cp}}, L.ctv, Cp, Fr, Cp, o));
+      GemmOpt b; b.n_valid = C;
+      CK(gemm_nt(st, DT_F32, {{L.ctv, Cp, opp(e, fmt("mmt_%s.n", lv)), Cp, Cp}}, L.ctPTf, Cp, Tp, Cp, b));
+      CK(cmpc_cast(DT_F32, L.ctPTf, dt, L.ctPT, (int64_t)Tp * Cp, st));
+      if (!e->lowrank) CK(transpose_cast(st, L.ctPTf, dt, L.ctPTt, Tp, Cp));
+      CK(cmpc_rowdot1(DT_F32, L.ctv, pptr(e, fmt("mm_trans_%s/biases", lv)), 0, L.ctk0s, 1, Tp, Cp, C, scale, st));
+      GemmOpt c; c.c_f32 = 1; c.alpha = scale; c.sbias = L.ctk0s; c.ld_sbias = Tp; c.rows_per_sample = N;
+      CK(gemm_nt(st, dt, {{L.X1m, Cp, L.ctPT, Cp, Cp}}, L.ctA0, Tp, N, Tp, c));
+      CK(cmpc_graph_softmax_fwd(dt, 0, L.ctA0, e->ones_t, e->ones_t, L.ctA, L.ctGv, L.ctA_t, L.ctGv_t, L.ctsc, 1, N, Fr, Tp, st));
+      if (e->lowrank) {
+          CK(cmpc_cast(DT_F32, L.TGN, dt, L.TGN16, (int64_t)Tp * Cp, st));
+          CK(cmpc_lowrank_nn(dt, L.ctA_t, Tp, 0, L.TGN16, Cp, 0, L.GLO, Cp, 0, N, Cp, C, Fr, 1, 1.0f, 0, st));
+      } else {
+          CK(cmpc_cast(DT_F32, L.TGN, dt, L.TGN16, (int64_t)Tp * Cp, st));
+          CK(transpose_cast(st, L.TGN, dt, L.TGNt, Tp, Cp));
+          GemmOpt y; y.n_valid = C;
+          CK(gemm_nt(st, dt, {{L.ctA_t, Tp, L.TGNt, Tp, Tp}}, L.GLO, Cp, N, Cp, y));
+      }
+      CK(cmpc_l2norm_rows_fwd(dt, L.GLO, L.CTX, L.ctx_rstd, nullptr, N, Cp, C, st)); }
+    // -- spatial word graph on the middle frame's multimodal map (vid:388-390,435-456): CMPC_model's, B = 1
+    { GemmOpt c; c.c_f32 = 1; c.alpha = scale; c.sbias = L.k0s; c.ld_sbias = Tp; c.rows_per_sample = N;
+      CK(gemm_nt(st, dt, {{L.X1m, Cp, L.PT, Cp, Cp}}, L.A0, Tp, N, Tp, c));
+      CK(cmpc_graph_softmax_fwd(dt, 0, L.A0, L.pr, e->mask, L.gw_w, L.gw_v, L.gw_w_t, L.gw_v_t, L.gsc, 1, N, T, Tp, st));
+      if (e->lowrank) {
+          TnOpt zt;
+          CK(gemm_tn(e, st, dt, L.gw_v_t, Tp, Tp, L.X1m, Cp, Cp, L.Zf, Cp, N, T, C, OFF0, zt));
+          CK(cmpc_cast(DT_F32, L.Zf, dt, L.Z, (int64_t)Tp * Cp, st));
+          CK(cmpc_lowrank_nn(dt, L.gw_w_t, Tp, 0, L.Z, Cp, 0, L.Y, Cp, 0, N, Cp, C, T, 1, 1.0f, 0, st));
+      } else {
+          TnOpt z;
+          CK(gemm_tn(e, st, dt, L.X1m, Cp, Cp, L.gw_v_t, Tp, Tp, L.Ztf, Tp, N, C, T, OFF0, z));
+          CK(cmpc_cast(DT_F32, L.Ztf, dt, L.Zt, (int64_t)Cp * Tp, st));
+          GemmOpt y; y.n_valid = C;
+          CK(gemm_nt(st, dt, {{L.gw_w_t, Tp, L.Zt, Tp, Tp}}, L.Y, Cp, N, Cp, y));
+      }
+      CK(cmpc_sample_stats(dt, L.Y, L.sums1, 1, N, Cp, C, st));
+      const std::string ln1 = fmt("gconv_feat_ln_spa_graph_%s", lv), ln2 = fmt("gconv_update_ln_spa_graph_%s", lv);
+      CK(cmpc_gconv_pre_fwd(dt, L.Y, L.X1m, L.sums1, pptr(e, ln1 + "/gamma"), pptr(e, ln1 + "/beta"), L.G, 1, N, Cp, C, st));
+      GemmOpt u; u.n_valid = C; u.bias = pptr(e, fmt("gconv_update_spa_graph_%s/biases", lv));
+      CK(gemm_nt(st, dt, {{L.G, Cp, opp(e, fmt("gupd_%s.t", lv)), Cp, Cp}}, L.U, Cp, N, Cp, u));
+      CK(cmpc_sample_stats(dt, L.U, L.sums2, 1, N, Cp, C, st));
+      CK(cmpc_gconv_post_fwd(dt, L.U, L.sums2, pptr(e, ln2 + "/gamma"), pptr(e, ln2 + "/beta"), L.X2, L.rrow, 1, N, Cp, C, st)); }
+    // -- fusion over [lateral of the middle frame | spatial graph | temporal context] + language and grid biases (vid:396-401)
+    { const int ldk = 3 * Cp; const std::string k = fmt("fus_%s.t", lv);
+      GemmOpt f; f.n_valid = M; f.bias = pptr(e, fmt("fusion_%s/biases", lv)); f.sbias = L.sb; f.ld_sbias = Mp; f.pbias = L.pb; f.ld_pbias = Mp;
+      f.rows_per_sample = N; f.act = ACT_RELU;
+      CK(gemm_nt(st, dt, {{L.X0m, Cp, opp(e, k), ldk, Cp}, {L.X2, Cp, opp(e, k, 0, Cp), ldk, Cp}, {L.CTX, Cp, opp(e, k, 0, 2 * Cp), ldk, Cp}}, L.F, Mp, N, Mp, f)); }
+    CK(cmpc_score_conv_fwd(dt, L.F, pptr(e, fmt("score_%s/DW", lv)), pptr(e, fmt("score_%s/biases", lv)), L.score, 1, e->h, e->w, Mp, M, st));
+    return cmpc_upsample_fwd(L.score, L.up, nullptr, target, L.loss, L.iu, L.iu + 1, 1, e->h, e->w, e->H, e->W, st);
+}
+
+// in: L.dfus (sum of the exchange modules' gradients of this level's fusion map); out: every parameter gradient of the level, L.dvl (d nec,
+// the fusion's language bias), L.dea (d entity+attribute vector), L.dac (d action vector), L.dwf / L.dpr (word side of the spatial graph)
+int level_bwd_video(E* e, hipStream_t st, int li, const float* target) {
+    LevelBuf& L = e->lv[li]; const char* lv = lvn(e, li);
+    const int N = e->N, T = e->T, C = e->C, Cp = e->Cp, Tp = e->Tp, M = e->M, Mp = e->Mp, dt = e->dt, Rr = e->RNN, Fr = e->Fr, RF = e->RF, es = e->esz;
+    const float scale = 1.0f / sqrtf((float)C);
+    TnOpt d; d.defer = true;
+    GemmOpt oc; oc.n_valid = C;
+    CK(cmpc_upsample_loss_bwd(L.up, target, L.dscore, e->cfg.loss_w[1 + li] * e->cfg.loss_scale, 1, e->h, e->w, e->H, e->W, st));
+    CK(cmpc_score_conv_bwd(dt, L.dscore, L.F, pptr(e, fmt("score_%s/DW", lv)), L.dfus, 1, gptr(e, fmt("score_%s/DW", lv)),
+                           gptr(e, fmt("score_%s/biases", lv)), 1, e->h, e->w, Mp, M, st));
+    // -- fusion
+    { CK(colsum(st, dt, L.dfus, N, Mp, Mp, M, gptr(e, fmt("fusion_%s/biases", lv)), L.F, L.dpre, ACT_RELU, L.dsb, Mp, N));
+      float* gw = gptr(e, fmt("fusion_%s/DW", lv));
+      CK(gemm_tn(e, st, dt, L.X0m, Cp, Cp, L.dpre, Mp, Mp, gw, M, N, C, M, OFF0, d));
+      CK(gemm_tn(e, st, dt, L.X2, Cp, Cp, L.dpre, Mp, Mp, gw + (size_t)C * M, M, N, C, M, OFF0, d));
+      CK(gemm_tn(e, st, dt, L.CTX, Cp, Cp, L.dpre, Mp, Mp, gw + (size_t)2 * C * M, M, N, C, M, OFF0, d));
+      CK(gemm_tn(e, st, DT_F32, e->nec, Cp, Cp, L.dsb, Mp, Mp, gw + (size_t)3 * C * M, M, 1, Rr, M, OFF0, d));
+      CK(gemm_tn(e, st, dt, e->spatial, 64, 64, L.dpre, Mp, Mp, gw + (size_t)(3 * C + Rr) * M, M, N, 8, M, OFF0, d));
+      const std::string k = fmt("fus_%s.n", lv);
+      CK(gemm_nt(st, dt, {{L.dpre, Mp, opp(e, k), Mp, Mp}}, L.dX0f, Cp, N, Cp, oc));
+      CK(gemm_nt(st, dt, {{L.dpre, Mp, opp(e, k, Cp, 0), Mp, Mp}}, L.dX2, Cp, N, Cp, oc));
+      CK(gemm_nt(st, dt, {{L.dpre, Mp, opp(e, k, 2 * Cp, 0), Mp, Mp}}, L.dCTX, Cp, N, Cp, oc));
+      GemmOpt v; v.n_valid = Rr;
+      CK(gemm_nt(st, DT_F32, {{L.dsb, Mp, opp(e, fmt("fusl_%s.n", lv)), Mp, Mp}}, L.dvl, Cp, 1, Cp, v)); }
+    void* dX1m = (char*)L.dX1 + (size_t)(Fr / 2) * N * Cp * es;        // L.dX1 [RF, Cp] starts at zero (backward region): every producer accumulates
+    // -- spatial word graph (CMPC_model's backward with B = 1; its node input is the middle frame of the multimodal map)
+    { const std::string ln1 = fmt("gconv_feat_ln_spa_graph_%s", lv), ln2 = fmt("gconv_update_ln_spa_graph_%s", lv);
+      CK(cmpc_gconv_post_bwd(dt, L.dX2, L.X2, L.rrow, L.U, L.sums2, pptr(e, ln2 + "/gamma"), L.dU, gptr(e, ln2 + "/gamma"), gptr(e, ln2 + "/beta"), L.bs, 1, N, Cp, C, st));
+      CK(colsum(st, dt, L.dU, N, Cp, Cp, C, gptr(e, fmt("gconv_update_spa_graph_%s/biases", lv))));
+      CK(gemm_tn(e, st, dt, L.G, Cp, Cp, L.dU, Cp, Cp, gptr(e, fmt("gconv_update_spa_graph_%s/DW", lv)), C, N, C, C, OFF0, d));
+      CK(gemm_nt(st, dt, {{L.dU, Cp, opp(e, fmt("gupd_%s.n", lv)), Cp, Cp}}, L.dG, Cp, N, Cp, oc));
+      CK(cmpc_gconv_pre_bwd(dt, L.dG, L.G, L.Y, L.sums1, pptr(e, ln1 + "/gamma"), dX1m, 1, L.dY, gptr(e, ln1 + "/gamma"), gptr(e, ln1 + "/beta"), L.bs, 1, N, Cp, C, st));
+      TnOpt zt;
+      if (!e->lowrank) {
+          CK(gemm_tn(e, st, dt, L.gw_v_t, Tp, Tp, L.X1m, Cp, Cp, L.Zf, Cp, N, T, C, OFF0, zt));
+          CK(cmpc_cast(DT_F32, L.Zf, dt, L.Z, (int64_t)Tp * Cp, st));
+      }
+      GemmOpt gw; gw.c_f32 = 1;
+      CK(gemm_nt(st, dt, {{L.dY, Cp, L.Z, Cp, Cp}}, L.dgw_w, Tp, N, Tp, gw));
+      CK(gemm_tn(e, st, dt, L.gw_w_t, Tp, Tp, L.dY, Cp, Cp, L.dZf, Cp, N, T, C, OFF0, zt));
+      CK(cmpc_cast(DT_F32, L.dZf, dt, L.dZ, (int64_t)Tp * Cp, st));
+      if (!e->lowrank) {
+          TnOpt z2;
+          CK(gemm_tn(e, st, dt, L.dY, Cp, Cp, L.gw_w_t, Tp, Tp, L.dZtf, Tp, N, C, T, OFF0, z2));
+          CK(cmpc_cast(DT_F32, L.dZtf, dt, L.dZt, (int64_t)Cp * Tp, st));
+      }
+      CK(gemm_nt(st, dt, {{L.X1m, Cp, L.dZ, Cp, Cp}}, L.dgw_v, Tp, N, Tp, gw));
+      GemmOpt ax; ax.n_valid = C; ax.accumulate = 1;
+      if (e->lowrank) CK(cmpc_lowrank_nn(dt, L.gw_v_t, Tp, 0, L.dZ, Cp, 0, dX1m, Cp, 0, N, Cp, C, T, 1, 1.0f, 1, st));
+      else CK(gemm_nt(st, dt, {{L.gw_v_t, Tp, L.dZt, Tp, Tp}}, dX1m, Cp, N, Cp, ax));
+      CK(cmpc_graph_softmax_bwd(dt, L.dgw_w, L.dgw_v, L.gw_w, L.gw_v, L.A0, L.pr, e->mask, L.dA0, L.dA0_t, L.dpr, L.gsc2, 1, N, T, Tp, st));
+      GemmOpt a0 = ax; a0.alpha = scale;
+      if (e->lowrank) CK(cmpc_lowrank_nn(dt, L.dA0_t, Tp, 0, L.PT, Cp, 0, dX1m, Cp, 0, N, Cp, C, T, 1, scale, 1, st));
+      else CK(gemm_nt(st, dt, {{L.dA0_t, Tp, L.PTt, Tp, Tp}}, dX1m, Cp, N, Cp, a0));
+      TnOpt pt; pt.alpha = scale;
+      CK(gemm_tn(e, st, dt, L.dA0_t, Tp, Tp, L.X1m, Cp, Cp, L.dPT, Cp, N, T, C, OFF0, pt));
+      CK(colsum(st, DT_F32, L.dA0, N, Tp, Tp, T, nullptr, nullptr, nullptr, ACT_NONE, L.dk0s, Tp, N));
+      CK(cmpc_wcolsum(DT_F32, L.Wd, L.dk0s, gptr(e, fmt("spa_graph_trans2_%s/biases", lv)), 0, 1, Tp, Cp, C, scale, st));
+      CK(gemm_nt(st, DT_F32, {{L.dPT, Cp, opp(e, fmt("t2_%s.t", lv)), Cp, Cp}}, L.dWd, Cp, Tp, Cp, oc));
+      CK(gemm_tn(e, st, DT_F32, L.dPT, Cp, Cp, L.Wd, Cp, Cp, gptr(e, fmt("spa_graph_trans2_%s/DW", lv)), C, Tp, C, C, OFF0, d));
+      CK(cmpc_rank1_update(DT_F32, L.dWd, L.dk0s, pptr(e, fmt("spa_graph_trans2_%s/biases", lv)), nullptr, nullptr, 0, scale, 0.0f, 1, Tp, Cp, C, st));
+      CK(colsum(st, DT_F32, L.dWd, Tp, Cp, Cp, C, gptr(e, fmt("words_trans_%s/biases", lv))));
+      CK(gemm_tn(e, st, DT_F32, e->wf, Cp, Cp, L.dWd, Cp, Cp, gptr(e, fmt("words_trans_%s/DW", lv)), C, T, C, C, OFF0, d));
+      CK(gemm_nt(st, DT_F32, {{L.dWd, Cp, opp(e, fmt("wtrans_%s.n", lv)), Cp, Cp}}, L.dwf, Cp, T, Cp, oc)); }
+    // -- temporal context
+    { CK(cmpc_l2norm_rows_bwd(dt, L.dCTX, L.CTX, L.ctx_rstd, L.dGLO, N, Cp, C, 0, st));
+      GemmOpt gw; gw.c_f32 = 1;
+      CK(gemm_nt(st, dt, {{L.dGLO, Cp, L.TGN16, Cp, Cp}}, L.dctA, Tp, N, Tp, gw));
+      TnOpt zt;
+      CK(gemm_tn(e, st, dt, L.ctA_t, Tp, Tp, L.dGLO, Cp, Cp, L.dTGN, Cp, N, Fr, C, OFF0, zt));                  // d tgraph via the attention-weighted sum
+      CK(cmpc_graph_softmax_bwd(dt, L.dctA, e->zeros_nt, L.ctA, L.ctGv, L.ctA0, e->ones_t, e->ones_t, L.dctA0, L.dctA0_t, L.dprc, L.ctsc2, 1, N, Fr, Tp, st));
+      GemmOpt a0; a0.n_valid = C; a0.accumulate = 1; a0.alpha = scale;
+      if (e->lowrank) CK(cmpc_lowrank_nn(dt, L.dctA0_t, Tp, 0, L.ctPT, Cp, 0, dX1m, Cp, 0, N, Cp, C, Fr, 1, scale, 1, st));
+      else CK(gemm_nt(st, dt, {{L.dctA0_t, Tp, L.ctPTt, Tp, Tp}}, dX1m, Cp, N, Cp, a0));
+      TnOpt pt; pt.alpha = scale;
+      CK(gemm_tn(e, st, dt, L.dctA0_t, Tp, Tp, L.X1m, Cp, Cp, L.dctPT, Cp, N, Fr, C, OFF0, pt));
+      CK(colsum(st, DT_F32, L.dctA0, N, Tp, Tp, Fr, nullptr, nullptr, nullptr, ACT_NONE, L.dctk0s, Tp, N));
+      CK(cmpc_wcolsum(DT_F32, L.ctv, L.dctk0s, gptr(e, fmt("mm_trans_%s/biases", lv)), 0, 1, Tp, Cp, C, scale, st));
+      CK(gemm_nt(st, DT_F32, {{L.dctPT, Cp, opp(e, fmt("mmt_%s.t", lv)), Cp, Cp}}, L.dctv, Cp, Tp, Cp, oc));
+      CK(gemm_tn(e, st, DT_F32, L.dctPT, Cp, Cp, L.ctv, Cp, Cp, gptr(e, fmt("mm_trans_%s/DW", lv)), C, Tp, C, C, OFF0, d));
+      CK(cmpc_rank1_update(DT_F32, L.dctv, L.dctk0s, pptr(e, fmt("mm_trans_%s/biases", lv)), nullptr, nullptr, 0, scale, 0.0f, 1, Tp, Cp, C, st));
+      // ct = tgraph . W_c + b_c on the Fr node rows (pad rows of dctv are zero)
+      CK(colsum(st, DT_F32, L.dctv, Fr, Cp, Cp, C, gptr(e, fmt("ctx_trans_%s/biases", lv))));
+      CK(gemm_tn(e, st, DT_F32, L.TGN, Cp, Cp, L.dctv, Cp, Cp, gptr(e, fmt("ctx_trans_%s/DW", lv)), C, Fr, C, C, OFF0, d));
+      GemmOpt ag; ag.n_valid = C; ag.accumulate = 1;
+      CK(gemm_nt(st, DT_F32, {{L.dctv, Cp, opp(e, fmt("ctxt_%s.n", lv)), Cp, Cp}}, L.dTGN, Cp, Fr, Cp, ag)); }
+    // -- temporal graph
+    { const std::string ln1 = fmt("gconv_feat_ln_temp_graph_%s", lv), ln2 = fmt("gconv_update_ln_temp_graph_%s", lv);
+      CK(cmpc_gconv_post_bwd(DT_F32, L.dTGN, L.TGN, L.rrow_t, L.TU, L.tsums2, pptr(e, ln2 + "/gamma"), L.dTU, gptr(e, ln2 + "/gamma"), gptr(e, ln2 + "/beta"), L.tbs, 1, Fr, Cp, C, st));
+      CK(colsum(st, DT_F32, L.dTU, Fr, Cp, Cp, C, gptr(e, fmt("gconv_update_temp_graph_%s/biases", lv))));
+      CK(gemm_tn(e, st, DT_F32, L.TG1, Cp, Cp, L.dTU, Cp, Cp, gptr(e, fmt("gconv_update_temp_graph_%s/DW", lv)), C, Fr, C, C, OFF0, d));
+      CK(gemm_nt(st, DT_F32, {{L.dTU, Cp, opp(e, fmt("tgu_%s.n", lv)), Cp, Cp}}, L.dTG1, Cp, Fr, Cp, oc));
+      CK(cmpc_gconv_pre_bwd(DT_F32, L.dTG1, L.TG1, L.TY, L.tsums1, pptr(e, ln1 + "/gamma"), L.dTG, 0, L.dTY, gptr(e, ln1 + "/gamma"), gptr(e, ln1 + "/beta"), L.tbs, 1, Fr, Cp, C, st));
+      hipLaunchKernelGGL(tgraph_bwd_kernel, dim3(1), dim3(256), 0, st, L.dTY, L.adj, L.TG, L.q, L.k, L.dTG, 1, L.dq, L.dk, Fr, Cp, C, scale);
+      CK(cmpc_check_launch("tgraph_bwd"));
+      GemmOpt ag; ag.n_valid = C; ag.accumulate = 1;
+      CK(colsum(st, DT_F32, L.dq, Fr, Cp, Cp, C, gptr(e, fmt("tg_query_%s/biases", lv))));
+      CK(gemm_tn(e, st, DT_F32, L.TG, Cp, Cp, L.dq, Cp, Cp, gptr(e, fmt("tg_query_%s/DW", lv)), C, Fr, C, C, OFF0, d));
+      CK(gemm_nt(st, DT_F32, {{L.dq, Cp, opp(e, fmt("tgq_%s.n", lv)), Cp, Cp}}, L.dTG, Cp, Fr, Cp, ag));
+      CK(colsum(st, DT_F32, L.dk, Fr, Cp, Cp, C, gptr(e, fmt("tg_key_%s/biases", lv))));
+      CK(gemm_tn(e, st, DT_F32, L.TG, Cp, Cp, L.dk, Cp, Cp, gptr(e, fmt("tg_key_%s/DW", lv)), C, Fr, C, C, OFF0, d));
+      CK(gemm_nt(st, DT_F32, {{L.dk, Cp, opp(e, fmt("tgk_%s.n", lv)), Cp, Cp}}, L.dTG, Cp, Fr, Cp, ag));
+      // pooling: TG[f] = sum_n tatt[f, n] X1[f, n];  tlog = scale * X1 . kqv
+      CK(cmpc_rowdot1(dt, L.X1, L.dTG, Cp, L.dtatt, Fr, N, Cp, C, 1.0f, st));
+      CK(cmpc_softmax_n_bwd(L.dtatt, L.tatt, L.dtlog, Fr, N, st));
+      CK(cmpc_rank1_update(dt, L.dX1, L.tatt, L.dTG, nullptr, nullptr, Cp, 1.0f, 0.0f, Fr, N, Cp, C, st));
+      CK(cmpc_rank1_update(dt, L.dX1, L.dtlog, L.kqv, nullptr, nullptr, 0, scale, 0.0f, Fr, N, Cp, C, st));
+      CK(cmpc_wcolsum(dt, L.X1, L.dtlog, L.dkqv, Cp, 1, RF, Cp, C, scale, st));
+      CK(gemm_nt(st, DT_F32, {{L.dkqv, Cp, opp(e, fmt("tgv_%s.t", lv)), Cp, Cp}}, L.dlt, Cp, 1, Cp, oc));
+      CK(gemm_tn(e, st, DT_F32, L.dkqv, Cp, Cp, L.lt, Cp, Cp, gptr(e, fmt("tg_vtrans_%s/DW", lv)), C, 1, C, C, OFF0, d));
+      CK(colsum(st, DT_F32, L.dlt, 1, Cp, Cp, C, gptr(e, fmt("tg_ltrans_%s/biases", lv))));
+      CK(gemm_tn(e, st, DT_F32, e->ac, Cp, Cp, L.dlt, Cp, Cp, gptr(e, fmt("tg_ltrans_%s/DW", lv)), C, 1, Rr, C, OFF0, d));
+      GemmOpt v; v.n_valid = Rr;
+      CK(gemm_nt(st, DT_F32, {{L.dlt, Cp, opp(e, fmt("tgl_%s.n", lv)), Cp, Cp}}, L.dac, Cp, 1, Cp, v)); }
+    // -- Mutan on the Fr frames (dX1 complete), laterals
+    { CK(cmpc_mutan_bwd(dt, L.P, L.g, L.X1, L.mut_rstd, L.dX1, L.dg, Fr, N, Cp, C, st));
+      void* dP = L.P;
+      const int64_t base_w = poff(e, fmt("vis_trans_%s_head1/DW", lv));
+      Offs ov, os;
+      for (int hd = 0; hd < 5; ++hd) {
+          const int64_t rel = poff(e, fmt("vis_trans_%s_head%d/DW", lv, hd + 1)) - base_w;
+          ov.push_back({0, (int64_t)hd * Cp, rel}); os.push_back({0, (int64_t)hd * Cp, rel + (int64_t)C * C});
+          CK(colsum(st, dt, (char*)dP + (size_t)hd * Cp * es, RF, 5 * Cp, Cp, C, gptr(e, fmt("vis_trans_%s_head%d/biases", lv, hd + 1))));
+      }
+      float* gwv = gptr(e, fmt("vis_trans_%s_head1/DW", lv));
+      CK(gemm_tn(e, st, dt, L.X0, Cp, Cp, dP, 5 * Cp, Cp, gwv, C, RF, C, C, ov, d));
+      CK(gemm_tn(e, st, dt, e->spatial, 64, 64, dP, 5 * Cp, Cp, gwv, C, RF, 8, C, os, d));
+      CK(gemm_nt(st, dt, {{dP, 5 * Cp, opp(e, fmt("mutan_%s.n", lv)), 5 * Cp, 5 * Cp}}, L.dX0, Cp, RF, Cp, oc));
+      // the gates were tiled over the frames: their gradient is the sum over the frames
+      hipLaunchKernelGGL(sum_rows_kernel, dim3((5 * Cp + 255) / 256), dim3(256), 0, st, L.dg, L.g1 /* reused: d gates [5 Cp] */, Fr, 5 * Cp, 0);
+      CK(cmpc_check_launch("sum_rows"));
+      float* dg1 = L.g1;
+      const int64_t base_l = poff(e, fmt("lang_trans_%s_head1/DW", lv));
+      Offs ol;
+      for (int hd = 0; hd < 5; ++hd) {
+          CK(colsum(st, DT_F32, dg1 + (size_t)hd * Cp, 1, 5 * Cp, Cp, C, gptr(e, fmt("lang_trans_%s_head%d/biases", lv, hd + 1)),
+                    L.g + (size_t)hd * Cp, dg1 + (size_t)hd * Cp, ACT_TANH));
+          ol.push_back({0, (int64_t)hd * Cp, poff(e, fmt("lang_trans_%s_head%d/DW", lv, hd + 1)) - base_l});
+      }
+      CK(gemm_tn(e, st, DT_F32, e->vl, Cp, Cp, dg1, 5 * Cp, Cp, gptr(e, fmt("lang_trans_%s_head1/DW", lv)), C, 1, Rr, C, ol, d));
+      GemmOpt v; v.n_valid = Rr;
+      CK(gemm_nt(st, DT_F32, {{dg1, 5 * Cp, opp(e, fmt("mlang_%s.n", lv)), 5 * Cp, 5 * Cp}}, L.dea, Cp, 1, Cp, v)); }
+    // the middle frame's lateral also fed the fusion conv
+    CK(add_n(st, dt, (char*)L.dX0 + (size_t)(Fr / 2) * N * Cp * es, {L.dX0f}, true, (long)N * Cp));
+    CK(cmpc_l2norm_rows_bwd(dt, L.dX0, L.X0, L.lat_rstd, L.dV, RF, Cp, C, 0, st));
+    CK(colsum(st, dt, L.dV, RF, Cp, Cp, C, gptr(e, fmt("%s_lateral/biases", lv))));
+    return gemm_tn(e, st, dt, L.feat, L.cin, L.cin, L.dV, Cp, Cp, gptr(e, fmt("%s_lateral/DW", lv)), C, RF, L.cin, C, OFF0, d);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1708,12 +1979,13 @@ extern "C" int cmpc_default_cfg(cmpc_cfg* c) {
     c->dtype = DT_F16; c->n_lanes = 3; c->device = 0; c->loss_scale = 0.f;
     c->model = CMPC_MODEL_CMPC; c->hsv = 0; c->bn_train = 0; c->bn_decay = 0.9997f;
     c->c2_dim = 256; c->c2_h = c->H / 4; c->c2_w = c->W / 4; c->aspp_depth = 256; c->low_dim = 48;
-    c->aspp_rates[0] = 6; c->aspp_rates[1] = 12; c->aspp_rates[2] = 18;
+    c->aspp_rates[0] = 6; c->aspp_rates[1] = 12; c->aspp_rates[2] = 18; c->sample_frames = 5;
     return CMPC_OK;
 }
 // the caller's graph-shaping fields (batch_size, num_steps, vf_h, vf_w, H, W, ...) are kept; only the model-specific ones are set
 extern "C" int cmpc_default_cfg_model(cmpc_cfg* c, int model, int hsv) {
-    if (!c || (model != CMPC_MODEL_CMPC && model != CMPC_MODEL_V5_BILSTM)) { cmpc_set_error("default_cfg_model: bad argument"); return CMPC_EINVAL; }
+    if (!c || (model != CMPC_MODEL_CMPC && model != CMPC_MODEL_V5_BILSTM && model != CMPC_MODEL_VIDEO)) { cmpc_set_error("default_cfg_model: bad argument"); return CMPC_EINVAL; }
+    c->sample_frames = 5;                             // CMPC_video_mm_tgraph_allvec.py:69
     c->model = model; c->hsv = (model == CMPC_MODEL_V5_BILSTM && hsv) ? 1 : 0;
     c->bn_decay = 0.9997f; c->c2_dim = 256; c->c2_h = c->H / 4; c->c2_w = c->W / 4; c->aspp_depth = 256; c->low_dim = 48;
     c->aspp_rates[0] = 6; c->aspp_rates[1] = 12; c->aspp_rates[2] = 18;
@@ -1754,7 +2026,12 @@ extern "C" int cmpc_create(const cmpc_cfg* c, cmpc_handle* out) {
     }
     if (pad64(c->v_emb_dim) > 2048 || pad64(c->mlp_dim) > 2048) { cmpc_set_error("create: v_emb_dim, mlp_dim <= 2048 (per-column registers of the map kernels)"); return CMPC_EINVAL; }
     if (c->n_lanes != 1 && c->n_lanes != 3) { cmpc_set_error("create: n_lanes must be 1 or 3"); return CMPC_EINVAL; }
-    if (c->model != CMPC_MODEL_CMPC && c->model != CMPC_MODEL_V5_BILSTM) { cmpc_set_error("create: model must be CMPC_MODEL_CMPC (0) or CMPC_MODEL_V5_BILSTM (1)"); return CMPC_EINVAL; }
+    if (c->model != CMPC_MODEL_CMPC && c->model != CMPC_MODEL_V5_BILSTM && c->model != CMPC_MODEL_VIDEO) {
+        cmpc_set_error("create: model must be CMPC_MODEL_CMPC (0), CMPC_MODEL_V5_BILSTM (1) or CMPC_MODEL_VIDEO (2)"); return CMPC_EINVAL;
+    }
+    if (c->model == CMPC_MODEL_VIDEO && (c->batch_size != 1 || c->sample_frames < 1 || c->sample_frames > 8)) {
+        cmpc_set_error("create (CMPC_video): the graph is only valid for batch_size = 1 (CMPC_video_mm_tgraph_allvec.py:323-324,379); 1 <= sample_frames <= 8"); return CMPC_EINVAL;
+    }
     if (c->model == CMPC_MODEL_V5_BILSTM) {
         if (c->c2_dim < 64 || c->c2_dim % 64 || c->c2_h < c->vf_h || c->c2_w < c->vf_w || c->aspp_depth < 8 || c->aspp_depth % 4 || pad64(c->aspp_depth) > 512 ||
             c->low_dim < 4 || c->low_dim % 4 || c->low_dim > 64 || c->aspp_rates[0] < 1 || c->aspp_rates[1] < 1 || c->aspp_rates[2] < 1 || c->mlp_dim % 4 ||
@@ -1789,6 +2066,8 @@ extern "C" int cmpc_create(const cmpc_cfg* c, cmpc_handle* out) {
     e->C = c->v_emb_dim; e->Cp = pad64(e->C); e->M = c->mlp_dim; e->Mp = pad64(e->M); e->G = c->glove_dim; e->Gp = pad64(e->G);
     e->P = c->parse_dim; e->Pp = pad64(e->P); e->Tp = 64; e->RNN = c->rnn_size; e->dt = c->dtype; e->esz = c->dtype == DT_F32 ? 4 : 2;
     e->v5 = c->model == CMPC_MODEL_V5_BILSTM;
+    e->vid = c->model == CMPC_MODEL_VIDEO;
+    if (e->vid) { e->Fr = c->sample_frames; e->RF = e->Fr * e->N; e->NC = 5; }
     if (e->v5) {
         e->nlev = 2; e->nex = 2; e->ncl = 2; e->ndir = 2;
         e->D = c->aspp_depth; e->Dp = pad64(e->D); e->LOW = c->low_dim; e->CATp = e->Dp + 64; e->C2 = c->c2_dim; e->h2 = c->c2_h; e->w2 = c->c2_w; e->R2 = e->B * e->h2 * e->w2;
@@ -1796,6 +2075,8 @@ extern "C" int cmpc_create(const cmpc_cfg* c, cmpc_handle* out) {
         for (int d = 0; d < 2; ++d) {
             e->ldir[d].key = fmt("lstm_%s", dn[d]); e->ldir[d].pk = fmt("bidirectional_rnn/%s/lstm_cell/kernel", dn[d]); e->ldir[d].pb = fmt("bidirectional_rnn/%s/lstm_cell/bias", dn[d]);
         }
+    } else if (e->vid) {
+        e->ldir[0].key = "lstm"; e->ldir[0].pk = "RNN/multi_rnn_cell/cell_0/basic_lstm_cell/kernel"; e->ldir[0].pb = "RNN/multi_rnn_cell/cell_0/basic_lstm_cell/bias";
     } else { e->ldir[0].key = "lstm"; e->ldir[0].pk = "rnn/lstm_cell/kernel"; e->ldir[0].pb = "rnn/lstm_cell/bias"; }
     // the graph's T-deep products as streaming kernels (cmpc_lowrank_nn); decided before the workspace is planned (Z moves to the forward pass)
     e->lowrank = e->dt != DT_F32 && e->T <= 24 && e->Cp <= 1024 && ((e->Cp / 4) & (e->Cp / 4 - 1)) == 0;
@@ -2156,15 +2437,17 @@ extern "C" int cmpc_forward(cmpc_handle e, const cmpc_feeds* f, const cmpc_fetch
     HCK(hipMemsetAsync(e->ws, 0, e->zf_bytes, main));                         // every accumulate-into buffer of the forward pass
     CK(text_fwd(e, main, f->words, f->seq_len));
     CK(parser_fwd(e, main));
-    CK(cmpc_lang_pool_fwd(e->parse, e->wf, e->vl, e->vl_rstd, B, e->T, Cp, e->RNN, 2, main));      // valid_lang: entity + attribute
-    CK(cmpc_lang_pool_fwd(e->parse, e->wf, e->nec, e->nec_rstd, B, e->T, Cp, e->RNN, 3, main));    // nec_lang: + relation
+    CK(cmpc_lang_pool_fwd(e->parse, e->wf, e->vl, e->vl_rstd, B, e->T, Cp, e->RNN, 2, 0, e->NC, main));      // valid_lang: entity + attribute (video: ea_lang)
+    // nec_lang: + relation; the video model's valid_lang: all but "unnecessary" (vid:215-227), and its action vector (vid:203-213)
+    CK(cmpc_lang_pool_fwd(e->parse, e->wf, e->nec, e->nec_rstd, B, e->T, Cp, e->RNN, e->vid ? 4 : 3, 0, e->NC, main));
+    if (e->vid) CK(cmpc_lang_pool_fwd(e->parse, e->wf, e->ac, e->ac_rstd, B, e->T, Cp, e->RNN, 1, 3, e->NC, main));
     CK(params_ready(e, main, 1));
     CK(mark(e, "fwd:text_done", main));
     // Everything that is a function of the text alone (the levels' language operands, the exchange modules' queries) goes first, on
     // the lanes, while the backbone (caller's side stream) is still running; each lane then waits for the visual features itself.
     hipStream_t st[3];
     CK(fork_lanes(e, main, st));
-    for (int i = 0; i < NL; ++i) { CK(level_lang_fwd(e, st[i], i)); CK(exchange_lang_fwd(e, st[i], i)); CK(exchange_lang_fwd(e, st[i], NX + i)); }
+    for (int i = 0; i < NL; ++i) { CK(e->vid ? level_lang_fwd_video(e, st[i], i) : level_lang_fwd(e, st[i], i)); CK(exchange_lang_fwd(e, st[i], i)); CK(exchange_lang_fwd(e, st[i], NX + i)); }
     if (f->feats_ready) for (int i = 0; i < (e->cfg.n_lanes > 1 ? 3 : 1); ++i) HCK(hipStreamWaitEvent(st[i], (hipEvent_t)f->feats_ready, 0));
     CK(mark(e, "fwd:feats_ready", st[0]));
     if (e->v5) {
@@ -2176,7 +2459,7 @@ extern "C" int cmpc_forward(cmpc_handle e, const cmpc_feeds* f, const cmpc_fetch
         CK(decoder_low_fwd(e, st[2]));
     }
     const char* lvm[3] = {"fwd:level_c5_done", "fwd:level_c4_done", "fwd:level_c3_done"};
-    for (int i = 0; i < NL; ++i) { CK(level_fwd(e, st[i], i, f->target_fine)); CK(mark(e, lvm[i], st[i])); }
+    for (int i = 0; i < NL; ++i) { CK(e->vid ? level_fwd_video(e, st[i], i, f->target_fine) : level_fwd(e, st[i], i, f->target_fine)); CK(mark(e, lvm[i], st[i])); }
     CK(join_lanes(e, main));
     // gated_exchange_fusion_lstm_2times (CMPC_model.py:261-293: modules c3, c4, c5 = lv[2], lv[1], lv[0], each reading the other two;
     // CMPCv5_BiLSTM_model.py:349-388: modules c4, c5 = lv[1], lv[0], each reading the other one)
@@ -2304,13 +2587,13 @@ extern "C" int cmpc_backward(cmpc_handle e, void* stream) {
     CK(fork_lanes(e, main, st));
     if (NX > 2) CK(add_n(main, DT_F32, e->dnec, {e->ex[0].dnec, e->ex[1].dnec, e->ex[2].dnec, e->ex[3].dnec, e->ex[4].dnec, e->ex[5].dnec}, false, (long)B * Cp));
     else CK(add_n(main, DT_F32, e->dnec, {e->ex[0].dnec, e->ex[1].dnec, e->ex[2].dnec, e->ex[3].dnec}, false, (long)B * Cp));
-    CK(cmpc_lang_pool_bwd(e->dnec, e->nec, e->nec_rstd, e->parse, e->wf, e->dparse, e->dwf, B, T, Cp, e->RNN, 3, main));
+    if (!e->vid) CK(cmpc_lang_pool_bwd(e->dnec, e->nec, e->nec_rstd, e->parse, e->wf, e->dparse, e->dwf, B, T, Cp, e->RNN, 3, 0, e->NC, main));
     CK(flush_bucket(e, main, 0));
     for (int i = 0; i < NL; ++i) {
         const void* src[3];
         const int n = fan_in(0, NL - 1 - i, src);
         CK(add_fan(st[i], e->lv[i].dfus, src, n));
-        CK(level_bwd(e, st[i], i, target));
+        CK(e->vid ? level_bwd_video(e, st[i], i, target) : level_bwd(e, st[i], i, target));
         const char* lvb[3] = {"bwd:level_c5_done", "bwd:level_c4_done", "bwd:level_c3_done"};
         CK(mark(e, lvb[i], st[i]));
     }
@@ -2331,11 +2614,19 @@ extern "C" int cmpc_backward(cmpc_handle e, void* stream) {
     CK(mark(e, "bwd:dW_main_done", wst));
     if (wst != main) { wg_done = next_event(e); HCK(hipEventRecord(wg_done, wst)); }
     HOSTPROF("dW main");
-    if (NL > 2) CK(add_n(main, DT_F32, e->dvl, {e->lv[0].dvl, e->lv[1].dvl, e->lv[2].dvl}, false, (long)B * Cp));
+    if (e->vid) {
+        // video: the fusion's language bias is the exchange modules' vector (all but "unnecessary"), Mutan's the entity+attribute one, the
+        // temporal pooling's the action one
+        CK(add_n(main, DT_F32, e->dnec, {e->lv[0].dvl, e->lv[1].dvl, e->lv[2].dvl}, true, (long)B * Cp));
+        CK(cmpc_lang_pool_bwd(e->dnec, e->nec, e->nec_rstd, e->parse, e->wf, e->dparse, e->dwf, B, T, Cp, e->RNN, 4, 0, e->NC, main));
+        CK(add_n(main, DT_F32, e->dvl, {e->lv[0].dea, e->lv[1].dea, e->lv[2].dea}, false, (long)B * Cp));
+        CK(add_n(main, DT_F32, e->dac, {e->lv[0].dac, e->lv[1].dac, e->lv[2].dac}, false, (long)B * Cp));
+        CK(cmpc_lang_pool_bwd(e->dac, e->ac, e->ac_rstd, e->parse, e->wf, e->dparse, e->dwf, B, T, Cp, e->RNN, 1, 3, e->NC, main));
+    } else if (NL > 2) CK(add_n(main, DT_F32, e->dvl, {e->lv[0].dvl, e->lv[1].dvl, e->lv[2].dvl}, false, (long)B * Cp));
     else CK(add_n(main, DT_F32, e->dvl, {e->lv[0].dvl, e->lv[1].dvl}, false, (long)B * Cp));
-    CK(cmpc_lang_pool_bwd(e->dvl, e->vl, e->vl_rstd, e->parse, e->wf, e->dparse, e->dwf, B, T, Cp, e->RNN, 2, main));
+    CK(cmpc_lang_pool_bwd(e->dvl, e->vl, e->vl_rstd, e->parse, e->wf, e->dparse, e->dwf, B, T, Cp, e->RNN, 2, 0, e->NC, main));
     const float* dpr3 = NL > 2 ? e->lv[2].dpr : e->zeros_bt;
-    hipLaunchKernelGGL(col_add3_kernel, dim3((B * T + 255) / 256), dim3(256), 0, main, e->dparse, 4, 2, e->lv[0].dpr, e->lv[1].dpr, dpr3, B * T);
+    hipLaunchKernelGGL(col_add3_kernel, dim3((B * T + 255) / 256), dim3(256), 0, main, e->dparse, e->NC, 2, e->lv[0].dpr, e->lv[1].dpr, dpr3, B * T);
     CK(cmpc_check_launch("col_add3"));
     if (NL > 2) CK(add_n(main, DT_F32, e->dwf, {e->lv[0].dwf, e->lv[1].dwf, e->lv[2].dwf}, true, (long)B * T * Cp));
     else CK(add_n(main, DT_F32, e->dwf, {e->lv[0].dwf, e->lv[1].dwf}, true, (long)B * T * Cp));

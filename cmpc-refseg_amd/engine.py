@@ -50,6 +50,8 @@ class Engine:
                 setattr(c, k, getattr(cfg, k))
             for i, r in enumerate(cfg.aspp_rates):
                 c.aspp_rates[i] = int(r)
+        if cfg.model == _lib.MODEL_VIDEO:
+            c.sample_frames = int(cfg.sample_frames)
         if loss_w is not None:
             for i, w in enumerate(loss_w):
                 c.loss_w[i] = w

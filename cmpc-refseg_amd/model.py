@@ -32,7 +32,9 @@ _LEVELS = ("c5", "c4", "c3")
 _EXG = ("c3", "c4", "c5", "c3_2", "c4_2", "c5_2")
 _LEVELS_V5 = ("c5", "c4")                              # CMPCv5_BiLSTM_model.py:134-137
 _EXG_V5 = ("c4", "c5", "c4_2", "c5_2")                 # :364-375
-MODELS = {"CMPC_model": (_lib.MODEL_CMPC, 0), "CMPCv5_BiLSTM_model": (_lib.MODEL_V5_BILSTM, 0), "CMPCv5_BiLSTM_HSV_model": (_lib.MODEL_V5_BILSTM, 1)}
+MODELS = {"CMPC_model": (_lib.MODEL_CMPC, 0), "CMPCv5_BiLSTM_model": (_lib.MODEL_V5_BILSTM, 0), "CMPCv5_BiLSTM_HSV_model": (_lib.MODEL_V5_BILSTM, 1),
+          "CMPC_video_mm_tgraph_allvec": (_lib.MODEL_VIDEO, 0)}        # CMPC_video/CMPC_video_mm_tgraph_allvec.py (trainval_video.py:10,35)
+FRAME_IDX = (0, 4, 8, 12, 15)                          # CMPC_video_mm_tgraph_allvec.py:70
 
 
 def tdt(dt: int):
@@ -46,6 +48,7 @@ class LSTM_model(object):
                  keep_prob_mlp=1.0, num_rnn_layers=1, optimizer='adam', weight_decay=0.0005, mode='eval',
                  conv5=False, glove_dim=300, emb_name='Gref', emb_dir='data',
                  batch_norm_decay=0.9997, freeze_bn=False, is_aug=False,      # CMPCv5_BiLSTM_model.py:42,47,49
+                 finetune=False, frames=16,                                   # CMPC_video_mm_tgraph_allvec.py:33,36
                  # --- extensions (not in the reference signature) ---
                  model="CMPC_model",         # which reference module this LSTM_model stands for (get_segmentation_model sets it)
                  aspp_depth=256, low_dim=48, aspp_rates=(6, 12, 18),          # hard-coded in CMPCv5_BiLSTM_model.py:196,208,225
@@ -67,6 +70,11 @@ class LSTM_model(object):
         self.model_name = model
         model_id, hsv = MODELS[model]
         self.v5 = model_id == _lib.MODEL_V5_BILSTM
+        self.video = model_id == _lib.MODEL_VIDEO
+        self.frames = frames
+        if self.video and (batch_size != 1 or frames <= max(FRAME_IDX) or finetune):
+            raise ValueError("CMPC_video_mm_tgraph_allvec: the graph is only valid for batch_size = 1 (vid:323-324,379), needs frames > 15 "
+                             "(sample indices 0, 4, 8, 12, 15; vid:70); finetune=True (backbone training) is not built")
         if freeze_bn or is_aug:
             raise NotImplementedError("freeze_bn / is_aug (CMPCv5_BiLSTM_model.py:83-84,528-529) are not built")
         if dtype == "bf16":
@@ -88,7 +96,7 @@ class LSTM_model(object):
                            lr_decay_step=lr_decay_step, weight_decay=weight_decay,
                            model=model_id, hsv=hsv, bn_train=int(self.v5 and mode == 'train'), bn_decay=batch_norm_decay,
                            c2_dim=4 * backbone_width, c2_h=-(-H // 4), c2_w=-(-W // 4), aspp_depth=aspp_depth, low_dim=low_dim,
-                           aspp_rates=tuple(aspp_rates))
+                           aspp_rates=tuple(aspp_rates), sample_frames=len(FRAME_IDX))
         for name, v in (("vf_dim", vf_dim), ("c4_dim", c4_dim), ("c3_dim", c3_dim)):
             if v % 64:
                 raise ValueError(f"{name}={v} must be a multiple of 64 (MFMA K tile)")
@@ -127,7 +135,7 @@ class LSTM_model(object):
     def _init_params(self, seed):
         """Reference initialisers by variable name (CMPC_model.py:412-417; slim's variance_scaling_initializer for `weights`), driven by the
         handle's own manifest so that both models share it."""
-        if not self.v5:
+        if not (self.v5 or self.video):
             return init_head_params(self.cfg, seed=seed)
         import math
         g = torch.Generator().manual_seed(seed)
@@ -255,6 +263,11 @@ class LSTM_model(object):
         if self.v5:
             for k in ("bilstm_fw", "bilstm_bw", "aspp_branches", "aspp_image", "aspp", "dec_cat", "dec_net2") + (("hsv",) if self.cfg.hsv else ()):
                 out[k] = t(k)
+        if self.video:
+            out["ac_lang"] = t("ac_lang")
+            for lv in _LEVELS:
+                for k in ("mm", "tg_pool", "tgraph", "temp_ctx"):
+                    out[f"{k}_{lv}"] = t(f"{k}_{lv}")
         if with_loss:
             s = t("scalars")
             out.update(loss_all=s[0], loss_c3=s[1], loss_c4=s[2], loss_c5=s[3], loss_last=s[4], mIoU=s[5])
@@ -299,6 +312,59 @@ class LSTM_model(object):
             if not self.v5:
                 out["up_c3"] = o["up_c3"].clone()
             return out
+
+    # ---- CMPC_video_mm_tgraph_allvec: feeds words (FRONT-padded), im (unused by the graph), target_fine, valid_idx, clip (vid:62-66) -------
+    def _video_feeds(self, words, valid_idx, clip):
+        """The graph drops the pad steps (vid:125-142): the same LSTM over the valid words only.  words [1, T] front-padded with
+        valid_idx[0, 0] pad words -> END-padded ids + seq_len for the handle; clip [1, frames, H, W, 3] -> the 5 sampled frames."""
+        T, H, W = self.num_steps, self.H, self.W
+        w = np.asarray(words.cpu() if torch.is_tensor(words) else words).astype(np.int64).reshape(1, T)
+        vi = int(np.asarray(valid_idx.cpu() if torch.is_tensor(valid_idx) else valid_idx).reshape(-1)[0])
+        if vi < 0 or vi >= T or np.any(w[0, :vi] != 0) or np.any(w[0, vi:] == 0):
+            raise ValueError("words must be front-padded with exactly valid_idx[0, 0] pad ids (util/text_processing.py:42-53)")
+        n = T - vi
+        we = np.zeros((1, T), dtype=np.int32)
+        we[0, :n] = w[0, vi:]
+        if tuple(clip.shape) != (1, self.frames, H, W, 3):
+            raise ValueError(f"clip must be [1,{self.frames},{H},{W},3], got {tuple(clip.shape)}")
+        fr = self._dev(clip, torch.float32)[0, list(FRAME_IDX)].contiguous()           # tf.gather(clip, [0, 4, 8, 12, 15], axis=1) (vid:70)
+        return torch.from_numpy(we), torch.tensor([n], dtype=torch.int32), fr
+
+    def head_video(self, feats, words_end, seq_len, target=None, after=None):
+        """build_graph() (vid:91-187) on the taps of the 5 sampled frames, feats = (c3, c4, c5) each [5, h, w, .]."""
+        return self.head(feats, words_end, seq_len, target, after=after)
+
+    @torch.no_grad()
+    def forward_video(self, words, im, valid_idx, clip):
+        """sess.run([pred, up, sigm], {words, im, valid_idx, clip}) (trainval_video.py:214-220)."""
+        with torch.cuda.device(self.device):
+            we, sl, fr = self._video_feeds(words, valid_idx, clip)
+            feats, ev = self.features_async(fr)
+            o = self.head(feats, we, sl, after=ev)
+            return {"pred": o["pred"].clone(), "up": o["up"].clone(), "sigm": o["sigm"].clone()}
+
+    def train_step_video(self, words, im, target_fine, valid_idx, clip):
+        """sess.run([train_step, cls_loss, learning_rate, pred, target], feed) (trainval_video.py:93-101)."""
+        if self.mode != 'train':
+            raise RuntimeError("model was built with mode='eval'")
+        with torch.cuda.device(self.device):
+            if len(self._inflight) >= self.MAX_STEPS_IN_FLIGHT:
+                self._inflight.pop(0).synchronize()
+            we, sl, fr = self._video_feeds(words, valid_idx, clip)
+            feats, ev = self.features_async(fr)
+            self.loss_and_grads(feats, we, target_fine, sl, after=ev)
+            sv = self.eng.tap("scalars").clone()
+            ost = self.opt_stream if self.opt_stream is not None else torch.cuda.current_stream(self.device)
+            for b in range(self.eng.n_buckets):
+                with torch.cuda.stream(ost):
+                    lr = self.eng.optimizer_bucket(b, 1.0)
+            done = torch.cuda.Event()
+            done.record(ost)
+            self._inflight.append(done)
+        scal = {k: sv[i] for i, k in enumerate(self._SCALARS)}
+        scal["mean_IOU"] = scal.pop("mIoU")
+        scal["learning_rate"] = lr
+        return self.eng.step, scal
 
     def predict(self, images, sentences, sequence_lenghts):
         """TF-serving signature of export_model_serving.py:57-71: images, sentences, sequence_lenghts -> masks."""

@@ -67,6 +67,7 @@ class HeadCfg:
     aspp_depth: int = 256
     low_dim: int = 48
     aspp_rates: tuple = (6, 12, 18)
+    sample_frames: int = 5      # CMPC_video_mm_tgraph_allvec.py:69
 
     @property
     def N(self):

@@ -365,9 +365,13 @@ typedef struct {
     int c2_dim, c2_h, c2_w;             /* res2b_relu tap (v5:88): channels (256) and map size (H/4 x W/4) */
     int aspp_depth, low_dim;            /* 256 (v5:208), 48 (v5:196) */
     int aspp_rates[3];                  /* 6, 12, 18: output_stride 16 (v5:153,225) */
+    int sample_frames;                  /* model VIDEO: frames of the clip that go through the graph (5: indices 0, 4, 8, 12, 15 of 16; CMPC_video_mm_tgraph_allvec.py:69-70) */
 } cmpc_cfg;
 #define CMPC_MODEL_CMPC 0
 #define CMPC_MODEL_V5_BILSTM 1
+#define CMPC_MODEL_VIDEO 2              /* CMPC_video/CMPC_video_mm_tgraph_allvec.py (BASELINE config 5): batch_size 1; feeds c3 / c4 / c5 are the taps of the
+                                           sample_frames frames, [sample_frames, vf_h, vf_w, .]; words END-padded with seq_len = number of words (the host turns
+                                           the reference's front padding + valid_idx around: the graph slices the pad steps away, vid:141-142) */
 /* fills *cfg with the reference's defaults (CMPC_model.py:15-40), f16 storage (the 16-bit mode that meets the 1e-4 mean-IoU bar), 3 lanes, device 0 */
 int cmpc_default_cfg(cmpc_cfg* cfg);
 /* the same for a given model: CMPC_MODEL_V5_BILSTM sets loss_w = 0.8, 0.1, 0.1, 0 (v5:541-542), bn_train 1, bn_decay 0.9997, c2_dim 256, c2_h = H / 4,
