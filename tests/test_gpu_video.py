@@ -85,9 +85,10 @@ def test_video_forward_backward_fp32_matches_oracle():
     worst = ("", 0.0)
     for name in grads:
         ref = ref_grad(case, grads, name)
-        if ("spa_graph_key" in name or "tg_vtrans" in name) and name.endswith("biases"):
-            # softmax over the nodes is invariant to a constant logit (b_k . q, b_v . lt): exact gradient 0, the oracle returns rounding noise
-            assert float(g[name].abs().max()) == 0.0 and float(ref.abs().max()) < 1e-5, name
+        if any(t in name for t in ("spa_graph_key", "tg_vtrans", "tg_key", "ctx_trans")) and name.endswith("biases"):
+            # each of these biases adds a constant to every logit of a softmax row (lt . b_v, q_i . b_k, mt_n . b_c): the exact gradient is 0
+            # and both sides return rounding noise
+            assert float(g[name].abs().max()) < 1e-5 and float(ref.abs().max()) < 1e-5, name
             continue
         tol = 3e-3 if (("spa_graph_trans2" in name or "mm_trans" in name) and name.endswith("biases")) else 5e-4
         err = U.rel_err(g[name], ref)
@@ -134,29 +135,39 @@ def test_video_driver_calls_and_f16():
 
 
 def test_config5_full_size_mean_iou_delta_vs_oracle():
-    """BASELINE.json config 5 at the reference's sizes: one 16-frame 320x320 clip, L = 20, C = 1000, M = 500, ResNet-101 on the 5 sampled
-    frames.  |mean-IoU(HIP) - mean-IoU(oracle)| <= 1e-4 in fp32 and f16 storage on identical inputs and weights."""
+    """BASELINE.json config 5 at the reference's sizes: 16-frame 320x320 clips, L = 20, C = 1000, M = 500, ResNet-101 on the 5 sampled
+    frames, batch 1.  The reference reports mean IoU over the evaluated clips (trainval_video.py:268-283); here 6 synthetic clips:
+    |mean-IoU(HIP) - mean-IoU(oracle)| <= 1e-4 in fp32 and f16 storage on identical inputs and weights (per-clip deltas printed)."""
     torch.set_num_threads(16)
     cfg = VD.Cfg(batch_size=1)
     hp, bp = VD.init_head_params(cfg), O.init_backbone_params(cfg)
-    words, clip, tgt = VD.synth_clip(cfg, seed=4)
-    vi = torch.tensor([[int((words[0] == 0).sum())]], dtype=torch.int32)
-    with torch.no_grad():
-        feats = VD.backbone_taps(bp, clip, cfg)
-        taps = VD.head_forward(hp, feats, words, cfg)
-        ref = VD.losses(hp, taps, tgt, cfg)
+    clips, refs = [], []
+    for seed in range(4, 10):
+        words, clip, tgt = VD.synth_clip(cfg, seed=seed)
+        vi = torch.tensor([[int((words[0] == 0).sum())]], dtype=torch.int32)
+        with torch.no_grad():
+            taps = VD.head_forward(hp, VD.backbone_taps(bp, clip, cfg), words, cfg)
+            refs.append((float(VD.losses(hp, taps, tgt, cfg)["mIoU"]), taps["up"]))
+        clips.append((words, vi, clip, tgt))
     P = U.pkg()
     res = {}
     for dtype in ("f32", "f16"):
         m = P.get_segmentation_model(NAME, batch_size=1, mode="train", dtype=dtype, head_params=hp, backbone_params=bp)
-        we, sl, fr = m._video_feeds(words, vi, clip)
-        with torch.no_grad():
-            o = m.head(m.features(fr), we, sl, tgt)
-        torch.cuda.synchronize()
-        up = o["up"].float().cpu()
-        res[dtype] = (abs(float(o["mIoU"]) - float(ref["mIoU"])), int(((up > 0) != (taps["up"] > 0)).sum()), U.rel_err(up, taps["up"]))
+        ious, flips, errs = [], 0, 0.0
+        for (words, vi, clip, tgt), (riou, rup) in zip(clips, refs):
+            we, sl, fr = m._video_feeds(words, vi, clip)
+            with torch.no_grad():
+                o = m.head(m.features(fr), we, sl, tgt)
+            torch.cuda.synchronize()
+            up = o["up"].float().cpu()
+            ious.append(float(o["mIoU"]))
+            flips += int(((up > 0) != (rup > 0)).sum())
+            errs = max(errs, U.rel_err(up, rup))
+        per_clip = [abs(a - r[0]) for a, r in zip(ious, refs)]
+        res[dtype] = (abs(float(np.mean(ious)) - float(np.mean([r[0] for r in refs]))), max(per_clip), flips, errs)
         del m, o
         torch.cuda.empty_cache()
-    print("config 5 parity:", {k: f"dIoU={v[0]:.2e} flipped_px={v[1]} up_rel_err={v[2]:.2e}" for k, v in res.items()}, "oracle mIoU", float(ref["mIoU"]))
-    assert res["f32"][0] <= 1e-4 and res["f32"][2] < 1e-3
+    print("config 5 parity:", {k: f"d(mean IoU)={v[0]:.2e} worst clip={v[1]:.2e} flipped_px={v[2]} up_rel_err={v[3]:.2e}" for k, v in res.items()},
+          "oracle mean IoU", float(np.mean([r[0] for r in refs])))
+    assert res["f32"][0] <= 1e-4 and res["f32"][1] <= 1e-4 and res["f32"][3] < 1e-3
     assert res["f16"][0] <= 1e-4

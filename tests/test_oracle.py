@@ -114,7 +114,8 @@ def test_oracle_reproduces_golden():
     words, im, sl, tgt = (torch.from_numpy(g[k]) for k in ("words", "im", "seq_len", "target"))
     feats = O.backbone_forward(bp, im, cfg)
     for i, n in enumerate(("c3", "c4", "c5")):
-        assert np.allclose(feats[i].numpy(), g["feat_" + n], rtol=1e-4, atol=1e-5)
+        # the fixture was written by this oracle in round 1; torch may pick another fp32 conv algorithm, so the bound is relative to the map's scale
+        assert np.abs(feats[i].numpy() - g["feat_" + n]).max() <= 1e-5 * np.abs(g["feat_" + n]).max()
     scal, grads, taps = O.grads_of(hp, feats, words, sl, tgt, cfg)
     for k in g.files:
         if k.startswith("tap/"):
