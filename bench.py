@@ -124,6 +124,42 @@ def config4_rate(pkg, dev, args, B=8):
     return out
 
 
+def config5_rate(pkg, dev, args):
+    """BASELINE config 5: CMPC_video_mm_tgraph_allvec, one 16-frame 320x320 clip per step (the reference graph is batch 1), L=20, ResNet-101
+    on the 5 sampled frames, f16 storage."""
+    m = pkg.get_segmentation_model("CMPC_video_mm_tgraph_allvec", batch_size=1, mode="train", dtype=args.dtype, device=str(dev))
+    g = torch.Generator().manual_seed(5)
+    words = torch.zeros(1, 20, dtype=torch.int64)
+    words[0, 20 - 9:] = torch.randint(1, m.cfg.vocab_size, (9,), generator=g)             # front-padded, as the reference driver feeds them
+    vi = torch.tensor([[11]], dtype=torch.int32)
+    clip = (torch.rand(1, 16, 320, 320, 3, generator=g) * 255 - 120).to(dev)
+    tg = (torch.rand(1, 320, 320, 1, generator=g) < 0.2).float().to(dev)
+    torch.cuda.synchronize()                                                              # words / valid_idx stay host arrays: they are feed_dict values in the reference driver
+    for _ in range(6 + args.warmup):
+        m.train_step_video(words, None, tg, vi, clip)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        _, scal = m.train_step_video(words, None, tg, vi, clip)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    for _ in range(2):
+        m.forward_video(words, None, vi, clip)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        m.forward_video(words, None, vi, clip)
+    torch.cuda.synchronize()
+    df = time.perf_counter() - t0
+    out = {"workload": f"CMPC_video_mm_tgraph_allvec: one 16-frame 320x320 clip (5 sampled frames through ResNet-101, frozen), L=20, batch 1, "
+                       f"{args.dtype} storage, random-init weights", "clips_per_sec": args.steps / dt, "ms_per_step": 1e3 * dt / args.steps,
+           "forward_only_clips_per_sec": args.steps / df, "forward_only_ms": 1e3 * df / args.steps, "final_loss": float(scal["loss_all"]),
+           "head_launches_per_step": m.eng.launch_count(), "grad_nonfinite": m.grad_nonfinite()}
+    del m
+    torch.cuda.empty_cache()
+    return out
+
+
 def stage_model(B, es=2, N=1600, T=20, C=1000, M=500, H=320, W=320, n_params=76055608):
     """Algorithmic work per train step of every launch name of CMPC_model (3 levels, 6 exchange modules, 3 ConvLSTM steps; SURVEY 8d's
     compulsory-traffic model: a stage reads its unique inputs once and writes its outputs once; a kernel that passes over its input
@@ -198,6 +234,7 @@ def main():
     ap.add_argument("--model", default="CMPC_model", choices=("CMPC_model", "CMPCv5_BiLSTM_model", "CMPCv5_BiLSTM_HSV_model"),
                     help="CMPC_model = BASELINE config 2 (the metric); the CMPCv5 models run BASELINE config 4 (512x512, L=25) as the line's workload")
     ap.add_argument("--no-config4", action="store_true", help="skip the BASELINE config 4 rate reported inside the default line")
+    ap.add_argument("--no-config5", action="store_true", help="skip the BASELINE config 5 (video) rate reported inside the default line")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -316,6 +353,11 @@ def main():
         model = None
         torch.cuda.empty_cache()
         cfg4 = config4_rate(pkg, dev, args)
+    cfg5 = None
+    if world == 1 and not v5 and not args.no_config5:
+        model = None
+        torch.cuda.empty_cache()
+        cfg5 = config5_rate(pkg, dev, args)
     tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
     if world > 1:
         torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
@@ -392,6 +434,8 @@ def main():
             out["alt_dtype"] = alt
         if cfg4 is not None:
             out["config4"] = cfg4
+        if cfg5 is not None:
+            out["config5"] = cfg5
         if world == 1 and not args.no_cpu_baseline:
             log("cpu baseline (oracle on host cores)")
             out["cpu_baseline"] = cpu_baseline(args)
