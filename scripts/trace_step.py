@@ -8,7 +8,7 @@ def short(n):
     n = n.split("(")[0]; n = n.replace("unsigned short", "bf16")
     return n[:44]
 ev = sorted((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), short(r["Kernel_Name"]), r.get("Stream_Id", r.get("Queue_Id", "?"))) for r in rows)
-ends = [e[1] for e in ev if e[2].startswith("adam_kernel")]
+ends = [e[0] for e in ev if e[2].startswith("embed_gather_kernel")]          # first launch of a step's forward pass
 lo, hi = ends[-back - 1], ends[-back]
 sel = [e for e in ev if lo <= e[0] < hi]
 print(f"step window {(hi-lo)/1e6:.3f} ms, {len(sel)} kernels")
