@@ -14,7 +14,7 @@ LIB_PATH = os.path.join(_HERE, "csrc", "libcmpc_hip.so")
 
 DT_F32, DT_BF16, DT_F16 = 0, 1, 2
 MODEL_CMPC, MODEL_V5_BILSTM, MODEL_VIDEO = 0, 1, 2
-ABI_VERSION = 2          # CMPC_ABI_VERSION of include/cmpc.h this binding was written against
+ABI_VERSION = 3          # CMPC_ABI_VERSION of include/cmpc.h this binding was written against
 ACT_NONE, ACT_RELU, ACT_TANH, ACT_SIGMOID = 0, 1, 2, 3
 
 
@@ -111,7 +111,7 @@ class EngineCfg(C.Structure):
 class Feeds(C.Structure):
     """cmpc_feeds"""
     _fields_ = [("words", C.c_void_p), ("seq_len", C.c_void_p), ("c3", C.c_void_p), ("c4", C.c_void_p), ("c5", C.c_void_p),
-                ("target_fine", C.c_void_p), ("feats_ready", C.c_void_p), ("c2", C.c_void_p), ("im", C.c_void_p)]
+                ("target_fine", C.c_void_p), ("feats_ready", C.c_void_p), ("c2", C.c_void_p), ("im", C.c_void_p), ("levels_done", C.c_void_p)]
 
 
 class Fetches(C.Structure):

@@ -268,7 +268,8 @@ struct cmpc_engine_s {
     char* ws = nullptr; size_t ws_bytes = 0, zf_bytes = 0, zb_bytes = 0;
     void* zero_page = nullptr;
     // streams / events
-    hipStream_t lane[3] = {nullptr, nullptr, nullptr};
+    hipStream_t lane[3] = {nullptr, nullptr, nullptr};       // the streams the three level / module chains run on (2 lanes: lane[2] = lane[0])
+    hipStream_t own_lane[3] = {nullptr, nullptr, nullptr};   // the streams this handle created
     std::vector<hipEvent_t> evpool; size_t evnext = 0;
     hipEvent_t ev_opt0 = nullptr, ev_opt1 = nullptr; bool opt_pending = false;
     // buffers
@@ -2002,7 +2003,7 @@ extern "C" int cmpc_destroy(cmpc_handle e) {
     for (void* p : {(void*)e->params, (void*)e->grads, (void*)e->adam_m, (void*)e->adam_v, (void*)e->arena, (void*)e->descs_dev,
                     (void*)e->tile_prefix_dev, (void*)e->tile_desc_dev, (void*)e->segs_dev, (void*)e->ws, (void*)e->bn_state})
         if (p) (void)hipFree(p);
-    for (hipStream_t s : e->lane) if (s) (void)hipStreamDestroy(s);
+    for (hipStream_t s : e->own_lane) if (s) (void)hipStreamDestroy(s);
     for (hipEvent_t ev : e->evpool) (void)hipEventDestroy(ev);
     if (e->ev_opt0) (void)hipEventDestroy(e->ev_opt0);
     if (e->ev_opt1) (void)hipEventDestroy(e->ev_opt1);
@@ -2025,7 +2026,7 @@ extern "C" int cmpc_create(const cmpc_cfg* c, cmpc_handle* out) {
         cmpc_set_error("create: need v_emb_dim >= 8, mlp_dim >= 8, glove_dim >= 1, parse_dim >= 4, vocab_size >= 1"); return CMPC_EINVAL;
     }
     if (pad64(c->v_emb_dim) > 2048 || pad64(c->mlp_dim) > 2048) { cmpc_set_error("create: v_emb_dim, mlp_dim <= 2048 (per-column registers of the map kernels)"); return CMPC_EINVAL; }
-    if (c->n_lanes != 1 && c->n_lanes != 3) { cmpc_set_error("create: n_lanes must be 1 or 3"); return CMPC_EINVAL; }
+    if (c->n_lanes < 1 || c->n_lanes > 3) { cmpc_set_error("create: n_lanes must be 1, 2 or 3"); return CMPC_EINVAL; }
     if (c->model != CMPC_MODEL_CMPC && c->model != CMPC_MODEL_V5_BILSTM && c->model != CMPC_MODEL_VIDEO) {
         cmpc_set_error("create: model must be CMPC_MODEL_CMPC (0), CMPC_MODEL_V5_BILSTM (1) or CMPC_MODEL_VIDEO (2)"); return CMPC_EINVAL;
     }
@@ -2140,7 +2141,8 @@ extern "C" int cmpc_create(const cmpc_cfg* c, cmpc_handle* out) {
         std::vector<float> on((size_t)e->B * e->N, 1.0f / (float)e->N);       // tf.reduce_mean over the map (v5:242)
         ECK(hipMemcpy(e->ones_n, on.data(), on.size() * sizeof(float), hipMemcpyHostToDevice));
     }
-    for (int i = 0; i < 3; ++i) ECK(hipStreamCreateWithFlags(&e->lane[i], hipStreamNonBlocking));
+    for (int i = 0; i < 3; ++i) { ECK(hipStreamCreateWithFlags(&e->own_lane[i], hipStreamNonBlocking)); e->lane[i] = e->own_lane[i]; }
+    if (c->n_lanes == 2) e->lane[2] = e->lane[0];
     e->evpool.resize(256);
     for (auto& ev : e->evpool) { ev = nullptr; ECK(hipEventCreateWithFlags(&ev, hipEventDisableTiming)); }
     ECK(hipEventCreateWithFlags(&e->ev_opt0, hipEventDisableTiming));
@@ -2351,8 +2353,9 @@ extern "C" int cmpc_phase_marks_read(cmpc_handle e, int index, const char** name
     return CMPC_OK;
 }
 extern "C" int cmpc_set_lanes(cmpc_handle e, int n_lanes) {
-    if (!e || (n_lanes != 1 && n_lanes != 3)) { cmpc_set_error("set_lanes: n_lanes must be 1 or 3"); return CMPC_EINVAL; }
+    if (!e || n_lanes < 1 || n_lanes > 3) { cmpc_set_error("set_lanes: n_lanes must be 1, 2 or 3"); return CMPC_EINVAL; }
     e->cfg.n_lanes = n_lanes;
+    e->lane[2] = n_lanes == 2 ? e->own_lane[0] : e->own_lane[2];
     return CMPC_OK;
 }
 extern "C" int cmpc_kernel_timing(cmpc_handle e, int enable) {
@@ -2461,6 +2464,7 @@ extern "C" int cmpc_forward(cmpc_handle e, const cmpc_feeds* f, const cmpc_fetch
     const char* lvm[3] = {"fwd:level_c5_done", "fwd:level_c4_done", "fwd:level_c3_done"};
     for (int i = 0; i < NL; ++i) { CK(e->vid ? level_fwd_video(e, st[i], i, f->target_fine) : level_fwd(e, st[i], i, f->target_fine)); CK(mark(e, lvm[i], st[i])); }
     CK(join_lanes(e, main));
+    if (f->levels_done) HCK(hipEventRecord((hipEvent_t)f->levels_done, main));
     // gated_exchange_fusion_lstm_2times (CMPC_model.py:261-293: modules c3, c4, c5 = lv[2], lv[1], lv[0], each reading the other two;
     // CMPCv5_BiLSTM_model.py:349-388: modules c4, c5 = lv[1], lv[0], each reading the other one)
     const void* fz[3] = {e->lv[NL - 1].F, e->lv[NL - 2].F, NL > 2 ? e->lv[0].F : nullptr};

@@ -101,7 +101,7 @@ class LSTM_model(object):
             if v % 64:
                 raise ValueError(f"{name}={v} must be a multiple of 64 (MFMA K tile)")
         if n_lanes is None:
-            n_lanes = 3 if int(os.environ.get("CMPC_STREAMS", "3")) > 1 else 1
+            n_lanes = min(3, max(1, int(os.environ.get("CMPC_STREAMS", "3"))))
         with torch.cuda.device(self.device):
             self.eng = Engine(self.cfg, self.dt, self.device, n_lanes=n_lanes)
             self.store = self.eng                         # parameter / gradient accessors (state_dict, grad_dict, p, g, step)
@@ -128,6 +128,8 @@ class LSTM_model(object):
         self.world, self.dp_on = 1, False
         self.last = {}
         self._inflight = []
+        self._prefetched = None            # (im tensor, feats, done event) of the batch whose backbone pass was enqueued during the previous step
+        self._levels_done = None
         self._bb_graph_on = os.environ.get("CMPC_BACKBONE_GRAPH", "1") != "0"
         self._bb = {"calls": 0, "next": 0, "graph": [None, None], "inp": [None, None], "out": [None, None]}
         self._keep = []                # feeds / taps of the steps in flight (the handle reads them asynchronously)
@@ -273,7 +275,7 @@ class LSTM_model(object):
             out.update(loss_all=s[0], loss_c3=s[1], loss_c4=s[2], loss_c5=s[3], loss_last=s[4], mIoU=s[5])
         return out
 
-    def head(self, feats, words, seq_len, target=None, after=None, im=None):
+    def head(self, feats, words, seq_len, target=None, after=None, im=None, levels_done=None):
         """build_graph() on given backbone taps (CMPC_model.py:89-142): one cmpc_forward call.  Returns the fetch dict
         (views into the handle's workspace: valid until the next call).  `after`: event that marks `feats` complete.
         feats = (c3, c4, c5), or (c2, c4, c5) for the CMPCv5_BiLSTM models, whose HSV variant also needs the image feed `im`."""
@@ -288,9 +290,9 @@ class LSTM_model(object):
                     raise ValueError("CMPCv5_BiLSTM_HSV_model needs the image feed (CMPCv5_BiLSTM_HSV_model.py:120-126)")
                 imd = self._dev(im, torch.float32)
             if self.v5:
-                self.eng.forward(w, sl, None, c4, c5, tg, feats_ready=after, c2=f0, im=imd)
+                self.eng.forward(w, sl, None, c4, c5, tg, feats_ready=after, c2=f0, im=imd, levels_done=levels_done)
             else:
-                self.eng.forward(w, sl, f0, c4, c5, tg, feats_ready=after)
+                self.eng.forward(w, sl, f0, c4, c5, tg, feats_ready=after, levels_done=levels_done)
             self._keep.append((w, sl, tg, f0, c4, c5, imd))
             del self._keep[:-3]
             return self._fetch_dict(tg is not None)
@@ -370,20 +372,32 @@ class LSTM_model(object):
         """TF-serving signature of export_model_serving.py:57-71: images, sentences, sequence_lenghts -> masks."""
         return self.forward(sentences, images, sequence_lenghts)["sigm"]
 
-    def loss_and_grads(self, feats, words, target_fine, seq_len, after=None, im=None):
+    def loss_and_grads(self, feats, words, target_fine, seq_len, after=None, im=None, between=None):
         """forward + backward of `cost` (CMPC_model.py:447) into the flat gradient buffer: cmpc_forward + cmpc_backward
         (L2 and the x2 bias multiplier are applied inside the Adam kernel)."""
-        o = self.head(feats, words, seq_len, target_fine, after=after, im=im)
+        ld = None
+        if between is not None:                  # work the caller wants enqueued behind the levels' forward (the next batch's backbone)
+            if self._levels_done is None:
+                self._levels_done = torch.cuda.Event()
+                self._levels_done.record()       # materialises the hipEvent_t the handle records
+            ld = self._levels_done
+        o = self.head(feats, words, seq_len, target_fine, after=after, im=im, levels_done=ld)
         with torch.cuda.device(self.device):
+            if between is not None:
+                between(ld)
             self.eng.backward()
         return o
 
     _SCALARS = ("loss_all", "loss_c3", "loss_c4", "loss_c5", "loss_last", "mIoU")
     MAX_STEPS_IN_FLIGHT = int(os.environ.get("CMPC_STEPS_IN_FLIGHT", "2"))
 
-    def train_step(self, words, im, target_fine, seq_len, ready=None):
+    def train_step(self, words, im, target_fine, seq_len, ready=None, next_im=None, next_ready=None):
         """sess.run([train, train_step, merged], feed) (trainval_model.py:98-107).
-        ready: optional torch.cuda.Event recorded once the (device-resident, prefetched) feeds were complete."""
+        ready: optional torch.cuda.Event recorded once the (device-resident, prefetched) feeds were complete.
+        next_im: the NEXT step's image batch, already resident on the device (a prefetching loader has it: util/data_reader_refvos.py:38-46),
+        next_ready its event.  The frozen backbone of that batch is then enqueued behind THIS step's levels' forward, where the step is a
+        serial chain of small launches (exchange modules, ConvLSTM, scores) until the levels' backward; the next call must pass the same
+        tensor as `im` and finds its taps ready.  Same arithmetic, same results: only the order on the device changes."""
         if self.mode != 'train':
             raise RuntimeError("model was built with mode='eval' (CMPC_model.py:85-86)")
         self._check_feeds(words, im, seq_len, target_fine)
@@ -395,8 +409,18 @@ class LSTM_model(object):
             if not torch.is_tensor(im):
                 ready = None                    # host feeds: the copy below is ordered on the caller's stream, which the backbone then waits for
             imd = self._dev(im, torch.float32)
-            feats, ev = self.features_async(imd, ready)
-            self.loss_and_grads(feats, words, target_fine, seq_len, after=ev, im=imd)
+            pf, self._prefetched = self._prefetched, None
+            if pf is not None and pf[0] is im:
+                feats, ev = pf[1], pf[2]
+            else:
+                feats, ev = self.features_async(imd, ready)
+            between = None
+            if next_im is not None and torch.is_tensor(next_im) and next_im.is_cuda and self.bb_stream is not None:
+                def between(levels_done, nxt=next_im, nready=next_ready):
+                    self.bb_stream.wait_event(levels_done)
+                    f2, e2 = self.features_async(nxt, nready if nready is not None else levels_done)
+                    self._prefetched = (nxt, f2, e2)
+            self.loss_and_grads(feats, words, target_fine, seq_len, after=ev, im=imd, between=between)
             sv = self.eng.tap("scalars").clone()
             # Optimizer, bucket by bucket in the order the backward pass finalises them (exchange modules + ConvLSTM, levels c5 / c4 /
             # c3, text encoder): every bucket's Adam + repack waits on the device for that bucket only, so all but the last run

@@ -29,7 +29,7 @@ const char* cmpc_last_error(void);
 /* Bumped whenever an exported signature or structure changes incompatibly; a binding must refuse a library whose version differs
  * (cmpc-refseg_amd/_lib.py does).  2: stat blocks (double[n][CMPC_STAT_PARTS][2]) replace double[B][2] sums, cmpc_mutan_fwd gained
  * pre_tanh, cmpc_adam_step gained `nonfinite`, cmpc_cfg gained `model` */
-#define CMPC_ABI_VERSION 2
+#define CMPC_ABI_VERSION 3
 int cmpc_abi_version(void);
 
 /* ---- GEMMs: every _conv 1x1 (CMPC_model.py:412-417), tf.matmul (:173,187,226,235,362,384,400)
@@ -416,6 +416,9 @@ typedef struct {
                                    is enqueued first and only the pyramid levels wait for it; NULL = ordered on `stream` */
     const void* c2;             /* model V5_BILSTM: res2b_relu [B, c2_h, c2_w, c2_dim] NHWC, cfg.dtype (v5:88); c3 is unused there (may be NULL) */
     const float* im;            /* model V5_BILSTM with hsv: the image feed itself [B, H, W, 3] f32, BGR minus mean (v5:80; hsv:120-126) */
+    void* levels_done;          /* optional hipEvent_t that cmpc_forward RECORDS once the pyramid levels' forward is complete: from there to the
+                                   levels' backward the step is a serial chain of small launches (exchange modules, ConvLSTM, scores), the
+                                   window a caller uses for independent heavy work -- the frozen backbone of the NEXT batch */
 } cmpc_feeds;
 typedef struct {                /* optional caller-owned device buffers the fetches are copied into (NULL = skip) */
     float* pred;                /* [B, vf_h, vf_w, 1] logits (CMPC_model.py:140) */

@@ -38,7 +38,7 @@ def test_library_exports_every_declared_symbol(pkg):
         assert sig is not None, f"{name} missing from the ctypes binding"
         assert len(sig) == nargs, f"{name}: header has {nargs} args, binding {len(sig)}"
     assert set(pkg._lib.SIGNATURES) | set(pkg._lib.COUNTS) <= set(protos)
-    assert lib.cmpc_abi_version() == pkg._lib.ABI_VERSION == 2
+    assert lib.cmpc_abi_version() == pkg._lib.ABI_VERSION == 3
     assert isinstance(lib.cmpc_last_error(), bytes)
     hdr = open(os.path.join(ROOT, "include", "cmpc.h")).read()
     assert int(re.search(r"#define CMPC_ABI_VERSION (\d+)", hdr).group(1)) == pkg._lib.ABI_VERSION     # the binding refuses any other library
@@ -176,7 +176,7 @@ def test_engine_rejects_bad_configs(pkg):
     lib.cmpc_default_cfg(ctypes.byref(c))
     h = ctypes.c_void_p()
     c.device = -1
-    for field, bad in (("vf_dim", 2000), ("rnn_size", 900), ("num_steps", 0), ("num_steps", 65), ("dtype", 7), ("n_lanes", 2), ("v_emb_dim", 4000)):
+    for field, bad in (("vf_dim", 2000), ("rnn_size", 900), ("num_steps", 0), ("num_steps", 65), ("dtype", 7), ("n_lanes", 4), ("v_emb_dim", 4000)):
         old = getattr(c, field)
         setattr(c, field, bad)
         assert lib.cmpc_create(ctypes.byref(c), ctypes.byref(h)) == -1, field
