@@ -1495,6 +1495,23 @@ int cmpc_gemm_tn_grouped_cached(const void* args_, int n, void* const* tables_de
         rsplit[i] = std::max(1, std::min(want, std::max(1, ex[i].R / (16 * br))));
         steps[i] = ((ex[i].R + rsplit[i] - 1) / rsplit[i] + br - 1) / br;
     }
+    // 3b. outliers: a reduction much longer than a slot's share of the launch is split further.  BASELINE config 4's decoder products reduce
+    //     over 131 072 rows beside 32 768-row ones: unsplit they are 2048-step items (2 ms each) in a launch whose balanced length is 0.8 ms.
+    //     A split part costs one fp32 slab (<= 64 KB per tile, written and folded once).  Launches whose items are all within 256 steps --
+    //     every bucket of configs 1-3 and 5 -- are not touched.
+    {
+        long total_steps = 0;
+        for (int i = 0; i < m; ++i)
+            total_steps += (long)((ex[i].Kv + 127) / 128) * ((ex[i].Nv + 127) / 128) * ex[i].nb * ex[i].nb2 * rsplit[i] * steps[i];
+        const long cap = std::max<long>(256, total_steps / slots / 2);
+        for (int i = 0; i < m; ++i) {
+            if (steps[i] <= cap) continue;
+            const int br = ex[i].dtype == DT_F32 ? TnCfg<float>::BR : TnCfg<bf16_t>::BR;
+            const long full = (ex[i].R + br - 1) / br;
+            const int r = (int)std::min<long>((full + cap - 1) / cap, std::max(1, ex[i].R / (16 * br)));
+            if (r > rsplit[i]) { rsplit[i] = r; steps[i] = ((ex[i].R + r - 1) / r + br - 1) / br; }
+        }
+    }
     struct Unit { std::vector<int> prods; bool slab; long len; };      // one table entry group: a chain stored directly, or ONE product in slab mode
     std::vector<Unit> units;
     struct Fold { int prod; float* slabs; long slab_size; int lds; };
