@@ -233,8 +233,8 @@ def main():
     ap.add_argument("--no-forward-only", action="store_true", help="skip the forward-only rate (profiling runs)")
     ap.add_argument("--model", default="CMPC_model", choices=("CMPC_model", "CMPCv5_BiLSTM_model", "CMPCv5_BiLSTM_HSV_model"),
                     help="CMPC_model = BASELINE config 2 (the metric); the CMPCv5 models run BASELINE config 4 (512x512, L=25) as the line's workload")
-    ap.add_argument("--no-prefetch", action="store_true", help="do not hand train_step the next batch (its backbone pass then starts with the step instead of "
-                    "behind the previous step's levels)")
+    ap.add_argument("--prefetch", action="store_true", help="hand train_step the next batch, whose backbone pass then runs behind this step's levels instead "
+                    "of at the start of its own step (measured SLOWER: 11.2 vs 10.5 ms, DESIGN 7; off by default)")
     ap.add_argument("--no-config4", action="store_true", help="skip the BASELINE config 4 rate reported inside the default line")
     ap.add_argument("--no-config5", action="store_true", help="skip the BASELINE config 5 (video) rate reported inside the default line")
     args = ap.parse_args()
@@ -281,9 +281,9 @@ def main():
     # the stem convolution and capture the two backbone graphs; they are taken here so that the W warm-up steps and the K
     # timed steps below run in steady state whatever W is.
     SETUP_STEPS = 6
-    # a prefetching loader (the reference's DataReader thread) has the next batch resident while the current one trains: train_step is told
-    # about it and enqueues its frozen-backbone pass inside the current step (same work per step, every step runs its own backbone pass)
-    nxt = {} if args.no_prefetch else {"next_im": im, "next_ready": ready}
+    # --prefetch: a prefetching loader (the reference's DataReader thread) has the next batch resident while the current one trains; train_step
+    # is told about it and enqueues its frozen-backbone pass inside the current step (same work per step, every step runs its own pass)
+    nxt = {"next_im": im, "next_ready": ready} if args.prefetch else {}
     for _ in range(SETUP_STEPS):
         model.train_step(words, im, target, seq_len, ready=ready, **nxt)
     torch.cuda.synchronize()

@@ -7,12 +7,12 @@ run() { # label, env..., -- bench args
   echo "$label: $out"
 }
 for rep in 1 2; do
-EXTRA="--no-prefetch" run "base  lanes3 q4" CMPC_STREAMS=3
-EXTRA=""              run "pref  lanes3 q4" CMPC_STREAMS=3
-EXTRA=""              run "pref  lanes2 q4" CMPC_STREAMS=2
-EXTRA="--no-prefetch" run "base  lanes2 q4" CMPC_STREAMS=2
-EXTRA=""              run "pref  lanes3 q8" CMPC_STREAMS=3 GPU_MAX_HW_QUEUES=8
-EXTRA=""              run "pref  lanes2 q8" CMPC_STREAMS=2 GPU_MAX_HW_QUEUES=8
-EXTRA="--no-prefetch" run "base  lanes2 q8" CMPC_STREAMS=2 GPU_MAX_HW_QUEUES=8
-EXTRA=""              run "pref  lanes2 q6" CMPC_STREAMS=2 GPU_MAX_HW_QUEUES=6
+EXTRA="" run "base  lanes3 q4" CMPC_STREAMS=3
+EXTRA="--prefetch"            run "pref  lanes3 q4" CMPC_STREAMS=3
+EXTRA="--prefetch"            run "pref  lanes2 q4" CMPC_STREAMS=2
+EXTRA="" run "base  lanes2 q4" CMPC_STREAMS=2
+EXTRA="--prefetch"            run "pref  lanes3 q8" CMPC_STREAMS=3 GPU_MAX_HW_QUEUES=8
+EXTRA="--prefetch"            run "pref  lanes2 q8" CMPC_STREAMS=2 GPU_MAX_HW_QUEUES=8
+EXTRA="" run "base  lanes2 q8" CMPC_STREAMS=2 GPU_MAX_HW_QUEUES=8
+EXTRA="--prefetch"            run "pref  lanes2 q6" CMPC_STREAMS=2 GPU_MAX_HW_QUEUES=6
 done

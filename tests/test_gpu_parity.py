@@ -351,7 +351,7 @@ def test_one_lane_equals_three_lanes(case):
     """The lane streams only reorder independent stages, and no sum depends on scheduling: the handle with n_lanes = 1 (everything
     on the caller's stream) and with 3 lanes gives bit-identical scalars and parameters after 3 steps with changing feeds."""
     ms = []
-    for lanes in (3, 1):
+    for lanes in (3, 1, 2):
         P = U.pkg()
         m = P.LSTM_model(head_params=case["hp"], backbone_params=case["bp"], n_lanes=lanes, **U.model_kwargs(case["cfg"], "f32"))
         scal = None
@@ -359,10 +359,32 @@ def test_one_lane_equals_three_lanes(case):
             w = case["words"] if step != 1 else torch.roll(torch.as_tensor(case["words"]), 1, 0)
             _, scal = m.train_step(w, case["im"], case["tgt"], case["sl"])
         ms.append((m.state_dict(), {k: float(v) for k, v in scal.items()}))
-    (sa, ca), (sb, cb) = ms
-    assert ca == cb
-    for n in sa:
-        assert torch.equal(sa[n], sb[n]), n
+    for (sb, cb) in ms[1:]:
+        assert ms[0][1] == cb
+        for n in ms[0][0]:
+            assert torch.equal(ms[0][0][n], sb[n]), n
+
+
+def test_next_batch_prefetch_changes_nothing(case):
+    """train_step(next_im=...) enqueues the NEXT batch's frozen-backbone pass behind this step's levels (cmpc_feeds.levels_done) and the next
+    call picks its taps up: same arithmetic in another order on the device -- parameters and scalars bit-identical to plain calls, also
+    when the announced batch is not the one that arrives (the prefetched taps are then dropped)."""
+    P = U.pkg()
+    dev = torch.device("cuda:0")
+    ims = [torch.as_tensor(case["im"]).to(dev), torch.flip(torch.as_tensor(case["im"]), dims=[0]).to(dev).contiguous(), torch.as_tensor(case["im"]).to(dev) * 0.5]
+    outs = []
+    for mode in ("plain", "prefetch", "wrong"):
+        m = P.LSTM_model(head_params=case["hp"], backbone_params=case["bp"], **U.model_kwargs(case["cfg"], "f32"))
+        for step in range(6):
+            im = ims[step % 3]
+            nxt = {"plain": None, "prefetch": ims[(step + 1) % 3], "wrong": ims[(step + 2) % 3]}[mode]
+            _, scal = m.train_step(case["words"], im, case["tgt"], case["sl"], next_im=nxt)
+        torch.cuda.synchronize()
+        outs.append((m.state_dict(), {k: float(v) for k, v in scal.items()}))
+    for (sb, cb) in outs[1:]:
+        assert outs[0][1] == cb
+        for n in outs[0][0]:
+            assert torch.equal(outs[0][0][n], sb[n]), n
 
 
 @pytest.mark.parametrize("dtype,full", [("f32", False), ("f16", False), ("f16", True)])
