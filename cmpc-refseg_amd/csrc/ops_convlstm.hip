@@ -139,7 +139,7 @@ __global__ __launch_bounds__(256) void clstm_b_kernel(T* __restrict__ Yg, const 
                     const float jn = (j[e] - mj) * rj * gj[kb][e] + bj[kb][e];
                     const float in = (i[e] - mi) * ri * gi[kb][e] + bi[kb][e];
                     const float fn = (f[e] - mf) * rf * gf[kb][e] + bf_[kb][e];
-                    const float fg = sigmoidf_(fn + 1.0f), ig = sigmoidf_(in), jt = tanhf(jn);
+                    const float fg = sigmoid_fast(fn + 1.0f), ig = sigmoid_fast(in), jt = cmpc_tanh(jn);
                     cp[e] = (c_prev ? c[e] * fg : 0.f) + ig * jt;
                     o[e] += wo[e] * cp[e];
                 } else { cp[e] = 0.f; o[e] = 0.f; }
@@ -185,7 +185,7 @@ __global__ __launch_bounds__(256) void clstm_c_kernel(const T* __restrict__ Yg, 
                 if (m < M) {
                     const float on = (o[e] - mo) * ro * go[kb][e] + bo[kb][e];
                     cn[e] = (cp[e] - mc) * rc * gc[kb][e] + bc[kb][e];
-                    hh[e] = sigmoidf_(on) * tanhf(cn[e]);
+                    hh[e] = sigmoid_fast(on) * cmpc_tanh(cn[e]);
                 } else { cn[e] = 0.f; hh[e] = 0.f; }
             }
             st8<T>(c_new + r * ld + c0, cn); st8<T>(h + r * ld + c0, hh);
@@ -230,7 +230,7 @@ __global__ __launch_bounds__(256) void clstm_bwd1_kernel(const T* __restrict__ d
                         const float xho = (o[e] - mo) * ro, xhc = (cp[e] - mc) * rc;
                         const float on = xho * go[k][e] + bo[k][e];
                         const float cn = xhc * gc[k][e] + bc[k][e];
-                        const float so = sigmoidf_(on), tc = tanhf(cn);
+                        const float so = sigmoid_fast(on), tc = cmpc_tanh(cn);
                         const float don = g[e] * tc * so * (1.f - so);
                         const float dcc = g[e] * so * (1.f - tc * tc) + (dc_new ? dcn[e] : 0.f);
                         ago[k][e] += don * xho; abo[k][e] += don; agc[k][e] += dcc * xhc; abc[k][e] += dcc;
@@ -310,7 +310,7 @@ __global__ __launch_bounds__(256) void clstm_bwd2_kernel(const T* __restrict__ Y
                         const float jn = xhj * gq[0][k][e] + bq[0][k][e];
                         const float in = xhi * gq[1][k][e] + bq[1][k][e];
                         const float fn = xhf * gq[2][k][e] + bq[2][k][e];
-                        const float fg = sigmoidf_(fn + 1.0f), ig = sigmoidf_(in), jt = tanhf(jn);
+                        const float fg = sigmoid_fast(fn + 1.0f), ig = sigmoid_fast(in), jt = cmpc_tanh(jn);
                         const float cpv = c_prev ? c[e] : 0.f;
                         const float dfn = dc * cpv * fg * (1.f - fg);
                         const float din = dc * jt * ig * (1.f - ig);
