@@ -12,6 +12,7 @@
 // one bf16 fragment (8 k-values) or four f32 k-values consumed by four MFMA steps.
 #include "cmpc_common.h"
 #include <algorithm>
+#include <queue>
 #include <vector>
 #include "../../include/cmpc.h"
 #include <stdlib.h>
@@ -1139,8 +1140,17 @@ __global__ void tn_desc_upload_kernel(const TnUploadArgs ua, TnGroupDesc* table)
     for (int i = threadIdx.x; i < ua.n * W; i += blockDim.x) dst[i] = src[i];
 }
 
-__global__ __launch_bounds__(256, 2) void gemm_tn_grouped_kernel(const TnGroupDesc* __restrict__ table, int ndesc, int total) {
-    for (int w = blockIdx.x; w < total; w += gridDim.x) {
+__global__ __launch_bounds__(256, 2) void gemm_tn_grouped_kernel(const TnGroupDesc* __restrict__ table, int ndesc, int total, int* __restrict__ next_item) {
+    // Items are dealt dynamically, longest first: a workgroup that finishes takes the next one (list scheduling).  The static deal s, s + grid, ...
+    // gave the slots that drew a long item in the first round another one in the second (620 tiles of 200 steps on 512 slots: 400 steps on
+    // slots 0..107 against an average of 242).  Which workgroup computes an item does not matter for the result: one writer per output / slab.
+    __shared__ int s_item;
+    for (;;) {
+        if (threadIdx.x == 0) s_item = atomicAdd(next_item, 1);
+        __syncthreads();
+        const int w = s_item;
+        __syncthreads();
+        if (w >= total) break;
         int lo = 0, hi = ndesc;                       // uniform binary search: scalar loads
         while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (table[mid].item_begin <= w) lo = mid; else hi = mid; }
         const TnGroupDesc& d = table[lo];
@@ -1495,21 +1505,75 @@ int cmpc_gemm_tn_grouped_cached(const void* args_, int n, void* const* tables_de
         rsplit[i] = std::max(1, std::min(want, std::max(1, ex[i].R / (16 * br))));
         steps[i] = ((ex[i].R + rsplit[i] - 1) / rsplit[i] + br - 1) / br;
     }
-    // 3b. outliers: a reduction much longer than a slot's share of the launch is split further.  BASELINE config 4's decoder products reduce
-    //     over 131 072 rows beside 32 768-row ones: unsplit they are 2048-step items (2 ms each) in a launch whose balanced length is 0.8 ms.
-    //     A split part costs one fp32 slab (<= 64 KB per tile, written and folded once).  Launches whose items are all within 256 steps --
-    //     every bucket of configs 1-3 and 5 -- are not touched.
-    {
-        long total_steps = 0;
-        for (int i = 0; i < m; ++i)
-            total_steps += (long)((ex[i].Kv + 127) / 128) * ((ex[i].Nv + 127) / 128) * ex[i].nb * ex[i].nb2 * rsplit[i] * steps[i];
-        const long cap = std::max<long>(256, total_steps / slots / 2);
-        for (int i = 0; i < m; ++i) {
-            if (steps[i] <= cap) continue;
-            const int br = ex[i].dtype == DT_F32 ? TnCfg<float>::BR : TnCfg<bf16_t>::BR;
-            const long full = (ex[i].R + br - 1) / br;
-            const int r = (int)std::min<long>((full + cap - 1) / cap, std::max(1, ex[i].R / (16 * br)));
-            if (r > rsplit[i]) { rsplit[i] = r; steps[i] = ((ex[i].R + r - 1) / r + br - 1) / br; }
+    // 3b. balance: the kernel deals the items (sorted by decreasing length) to whichever of its `slots` persistent workgroups is free first,
+    //     so the launch lasts as long as list scheduling makes it.  A level bucket of configs 1-3 is ~700 tiles of 200 steps on 512 slots: two
+    //     rounds, 400 steps, against an average of 280.  Splitting EVERY product costs a slab per tile and part (measured slower); here
+    //     the host simulates the schedule and doubles the split of one product at a time -- the one whose doubling shortens the launch most,
+    //     each part of a split product priced at SLAB_COST extra steps (slab traffic + its share of the fold) -- until nothing gains 2 % any
+    //     more.  This also covers config 4's outliers (131 072-row decoder reductions beside 32 768-row ones).
+    if (!getenv("CMPC_TN_NO_BALANCE")) {
+        constexpr long SLAB_COST = 6;
+        auto n_tiles = [&](int i) { return (long)((ex[i].Kv + 127) / 128) * ((ex[i].Nv + 127) / 128) * ex[i].nb * ex[i].nb2; };
+        auto brows = [&](int i) { return ex[i].dtype == DT_F32 ? TnCfg<float>::BR : TnCfg<bf16_t>::BR; };
+        auto steps_of = [&](int i, int r) { return (long)(((ex[i].R + r - 1) / r + brows(i) - 1) / brows(i)); };
+        // chains (several products accumulated by one workgroup per tile) are dealt as one item of the summed length and never split here
+        std::vector<int> chain_of(m, -1);          // members of SHORT chains stay unsplit (they are walked by one workgroup)
+        for (size_t c = 0; c < chains.size(); ++c) {
+            long len = 0; for (int i : chains[c]) len += steps_of(i, rsplit[i]);
+            if (chains[c].size() > 1 && len <= 64) for (int i : chains[c]) chain_of[i] = (int)c;
+        }
+        std::vector<std::pair<long, long>> items;       // (length, count)
+        auto makespan = [&](const std::vector<int>& rs) {
+            items.clear();
+            for (size_t c = 0; c < chains.size(); ++c) {
+                const auto& ch = chains[c];
+                long len = 0, parts = 0;
+                for (int i : ch) { len += steps_of(i, rs[i]); parts += rs[i]; }
+                // step 4 below: one workgroup per tile walks a short unsplit chain; every other product of a chain is a slab item of its own
+                if (ch.size() > 1 && parts == (long)ch.size() && len <= 64) { items.push_back({len, n_tiles(ch[0])}); continue; }
+                for (int i : ch) items.push_back({steps_of(i, rs[i]) + ((ch.size() > 1 || rs[i] > 1) ? SLAB_COST : 0), n_tiles(i) * rs[i]});
+            }
+            std::stable_sort(items.begin(), items.end(), [](const std::pair<long, long>& x, const std::pair<long, long>& y) { return x.first > y.first; });
+            // list scheduling as the kernel does it: the next item goes to the workgroup that is free first
+            std::priority_queue<long, std::vector<long>, std::greater<long>> free_at;
+            for (int k = 0; k < slots; ++k) free_at.push(0);
+            long last = 0;
+            for (const auto& it : items) for (long k = 0; k < it.second; ++k) { const long t = free_at.top() + it.first; free_at.pop(); free_at.push(t); last = std::max(last, t); }
+            return last;
+        };
+        // outliers first (no single doubling shortens a launch that holds twenty 2048-step products): reductions longer than half a slot's
+        // share of the launch, and than 256 steps, are cut to that length
+        {
+            long total_steps = 0;
+            for (int i = 0; i < m; ++i) total_steps += n_tiles(i) * rsplit[i] * steps_of(i, rsplit[i]);
+            const long cap = std::max<long>(256, total_steps / slots / 2);
+            for (int i = 0; i < m; ++i) {
+                if (chain_of[i] >= 0 || steps_of(i, rsplit[i]) <= cap) continue;
+                const long full = (ex[i].R + brows(i) - 1) / brows(i);
+                const int r = (int)std::min<long>((full + cap - 1) / cap, std::max(1, ex[i].R / (16 * brows(i))));
+                if (r > rsplit[i]) rsplit[i] = r;
+            }
+        }
+        long best = makespan(rsplit);
+        for (int iter = 0; iter < 64; ++iter) {
+            int pick = -1; long pick_ms = best;
+            for (int i = 0; i < m; ++i) {
+                if (chain_of[i] >= 0) continue;
+                const int r2 = rsplit[i] * 2;
+                if (r2 > std::max(1, ex[i].R / (4 * brows(i)))) continue;          // parts of at least 4 row blocks
+                std::vector<int> t = rsplit; t[i] = r2;
+                const long ms = makespan(t);
+                if (ms < pick_ms) { pick_ms = ms; pick = i; }
+            }
+            if (pick < 0 || pick_ms * 100 > best * 98) break;
+            rsplit[pick] *= 2; best = pick_ms;
+        }
+        for (int i = 0; i < m; ++i) steps[i] = steps_of(i, rsplit[i]);
+        if (getenv("CMPC_TN_PLAN_DUMP")) {
+            long tot = 0; for (int i = 0; i < m; ++i) tot += n_tiles(i) * rsplit[i] * steps[i];
+            fprintf(stderr, "[tn plan] %d products, %ld steps, ideal %ld per slot, most loaded slot %ld:", m, tot, tot / slots, best);
+            for (int i = 0; i < m; ++i) fprintf(stderr, " %ldx%dx%ld", n_tiles(i), rsplit[i], steps[i]);
+            fprintf(stderr, "\n");
         }
     }
     struct Unit { std::vector<int> prods; bool slab; long len; };      // one table entry group: a chain stored directly, or ONE product in slab mode
@@ -1534,9 +1598,9 @@ int cmpc_gemm_tn_grouped_cached(const void* args_, int n, void* const* tables_de
     }
     // one scratch block for every slab of this launch (+ the descriptor table when the caller keeps none): cmpc_ws hands out the same
     // per-stream block on every call outside a fold collection, so separate calls would alias
-    const size_t table_room = cached ? 0 : ((size_t)m * sizeof(TnGroupDesc) + 255) / 256 * 256;
-    char* scratch = nullptr;
-    if (slab_total + table_room > 0) { scratch = (char*)cmpc_ws(slab_total + table_room, st); if (!scratch) return CMPC_EHIP; }
+    const size_t table_room = 256 + (cached ? 0 : ((size_t)m * sizeof(TnGroupDesc) + 255) / 256 * 256);     // 256: the item counter
+    char* scratch = (char*)cmpc_ws(slab_total + table_room, st);
+    if (!scratch) return CMPC_EHIP;
     for (Fold& f : folds) f.slabs = (float*)(scratch + table_room + (size_t)(uintptr_t)f.slabs);
     std::vector<int> idx(units.size());
     for (size_t u = 0; u < units.size(); ++u) idx[u] = (int)u;
@@ -1573,7 +1637,7 @@ int cmpc_gemm_tn_grouped_cached(const void* args_, int n, void* const* tables_de
             if (shadows[k].size() == bytes && memcmp(shadows[k].data(), sorted.data(), bytes) == 0) { hit = true; table = (TnGroupDesc*)tables_dev[k]; }
         if (!hit) { const int k = *victim; *victim = (k + 1) % nslots; table = (TnGroupDesc*)tables_dev[k]; shadow = &shadows[k]; }
     } else {
-        table = (TnGroupDesc*)scratch;
+        table = (TnGroupDesc*)(scratch + 256);
     }
     if (!table) return CMPC_EHIP;
     if (!hit) {
@@ -1586,7 +1650,9 @@ int cmpc_gemm_tn_grouped_cached(const void* args_, int n, void* const* tables_de
         }
         if (shadow) shadow->assign((const char*)sorted.data(), (const char*)sorted.data() + bytes);
     }
-    hipLaunchKernelGGL(gemm_tn_grouped_kernel, dim3(std::min(items, slots)), dim3(256), 2 * 2 * TnCfg<bf16_t>::BR * 128 * 2, st, table, m, items);
+    int* next_item = (int*)scratch;                 // the launch's item counter: first bytes of its scratch block
+    if (hipMemsetAsync(next_item, 0, sizeof(int), st) != hipSuccess) { cmpc_set_error("gemm_tn_grouped: memset"); return CMPC_EHIP; }
+    hipLaunchKernelGGL(gemm_tn_grouped_kernel, dim3(std::min(items, slots)), dim3(256), 2 * 2 * TnCfg<bf16_t>::BR * 128 * 2, st, table, m, items, next_item);
     if (cmpc_check_launch("gemm_tn_grouped") != CMPC_OK) return CMPC_EHIP;
     // fixed-order sums of the slabs into the outputs (recorded into the caller's deferred-fold list when one is active and the
     // output is a gradient: then they run with the bias / LayerNorm folds in ONE launch; otherwise launched here)
