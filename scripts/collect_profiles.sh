@@ -14,6 +14,14 @@ python scripts/summarize_profile.py $O/stats $O/r03_bench_b8_f16_kernel_stats.cs
 python scripts/pmc_traffic.py $O/fetch $O/write gemm_nt_v $O/r03_gemm_nt_traffic.json
 python scripts/pmc_mfma.py $O/mfma $O/r03_mfma_busy.txt
 timeout -k 10 300 python scripts/phase_timeline.py > $O/r03_phase_timeline.txt 2>/dev/null
+# BASELINE configs 4 and 5: kernel stats of single-stream train steps
+cd /tmp
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats4 -- python3 $R/scripts/prof_step_v5.py 14 1 v5 > $O/stats4.log 2>&1 || exit 1
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats5 -- python3 $R/scripts/prof_step_v5.py 24 1 video > $O/stats5.log 2>&1 || exit 1
+cd $R
+python scripts/summarize_profile.py $O/stats4 $O/r03_config4_b8_f16_kernel_stats.csv 14
+python scripts/summarize_profile.py $O/stats5 $O/r03_config5_video_f16_kernel_stats.csv 24
+rm -rf $O/stats4 $O/stats5
 # phase trace of the 256 x 256 gemm_nt kernel (needs build/libcmpc_trace.so: scripts/build_trace_lib.sh, run before gpurun)
 if [ -f build/libcmpc_trace.so ]; then (export CMPC_LIB_PATH=$PWD/build/libcmpc_trace.so; for s in "12800 1024 1024" "12800 5120 1088" "12800 1024 5120"; do timeout -k 10 100 python scripts/v5_trace.py $s; done) > $O/r03_gemm_nt_v5_phase_trace.txt 2>/dev/null; fi
 rm -rf $O/stats $O/fetch $O/write $O/mfma
