@@ -28,7 +28,7 @@ extern "C" {
 const char* cmpc_last_error(void);
 /* Bumped whenever an exported signature or structure changes incompatibly; a binding must refuse a library whose version differs
  * (cmpc-refseg_amd/_lib.py does).  2: stat blocks (double[n][CMPC_STAT_PARTS][2]) replace double[B][2] sums, cmpc_mutan_fwd gained
- * pre_tanh, cmpc_adam_step gained `nonfinite`, cmpc_cfg gained `model` */
+ * pre_tanh, cmpc_adam_step gained `nonfinite`, cmpc_cfg gained `model`.  3: cmpc_feeds gained `levels_done`, n_lanes may be 2 */
 #define CMPC_ABI_VERSION 3
 int cmpc_abi_version(void);
 
