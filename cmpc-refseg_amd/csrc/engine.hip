@@ -274,6 +274,8 @@ struct cmpc_engine_s {
     hipEvent_t ev_opt0 = nullptr, ev_opt1 = nullptr; bool opt_pending = false;
     // buffers
     void* spatial = nullptr;
+    void* spatial1 = nullptr;        // the grid with a constant 1 in channel 8: A operand of the products whose row 8 is the bias gradient
+    bool mutan_bias_row = false;     // every vis_trans head's bias sits right behind its DW: its gradient is row C + 8 of the spatial-rows product
     float *wf, *wf_rstd, *mask;
     float *h1, *lg, *parse, *dlg, *dh1;
     float *vl, *vl_rstd, *nec, *nec_rstd, *dparse, *dwf, *dvl, *dnec;
@@ -651,6 +653,7 @@ void plan_workspace(E* e, Bump& zf, Bump& zb, Bump& g) {
     const int RL = e->vid ? e->RF : R, BL = e->vid ? e->Fr : B;        // rows / "samples" of the per-frame maps (lateral, Mutan) of the video model
     e->zero_page = zf.take(256);
     e->spatial = g.take((size_t)RL * 64 * es);
+    e->spatial1 = g.take((size_t)RL * 64 * es);
     // ---- text encoder / parser / language pools
     for (int d = 0; d < e->ndir; ++d) {
         LstmDir& D = e->ldir[d];
@@ -1344,11 +1347,14 @@ int level_bwd(E* e, hipStream_t st, int li, const float* target) {
       for (int hd = 0; hd < 5; ++hd) {
           const int64_t rel = poff(e, fmt("vis_trans_%s_head%d/DW", lv, hd + 1)) - base_w;
           ov.push_back({0, (int64_t)hd * Cp, rel}); os.push_back({0, (int64_t)hd * Cp, rel + (int64_t)C * C});
-          CK(colsum(st, dt, (char*)dP + (size_t)hd * Cp * es, R, 5 * Cp, Cp, C, gptr(e, fmt("vis_trans_%s_head%d/biases", lv, hd + 1))));
+          if (!e->mutan_bias_row) CK(colsum(st, dt, (char*)dP + (size_t)hd * Cp * es, R, 5 * Cp, Cp, C, gptr(e, fmt("vis_trans_%s_head%d/biases", lv, hd + 1))));
       }
       float* gwv = gptr(e, fmt("vis_trans_%s_head1/DW", lv));
       CK(gemm_tn(e, st, dt, L.X0, Cp, Cp, dP, 5 * Cp, Cp, gwv, C, R, C, C, ov, d));
-      CK(gemm_tn(e, st, dt, e->spatial, 64, 64, dP, 5 * Cp, Cp, gwv, C, R, 8, C, os, d));
+      // the grid rows of the five heads' DW; with the constant-1 channel the product's ninth row is the head's bias gradient (five column-sum
+      // passes over dP = 130 MB per level less)
+      if (e->mutan_bias_row) CK(gemm_tn(e, st, dt, e->spatial1, 64, 64, dP, 5 * Cp, Cp, gwv, C, R, 9, C, os, d));
+      else CK(gemm_tn(e, st, dt, e->spatial, 64, 64, dP, 5 * Cp, Cp, gwv, C, R, 8, C, os, d));
       GemmOpt o; o.n_valid = C;
       CK(gemm_nt(st, dt, {{dP, 5 * Cp, opp(e, fmt("mutan_%s.n", lv)), 5 * Cp, 5 * Cp}}, L.dX0, Cp, R, Cp, o));
       const int64_t base_l = poff(e, fmt("lang_trans_%s_head1/DW", lv));
@@ -1614,11 +1620,12 @@ int level_bwd_video(E* e, hipStream_t st, int li, const float* target) {
       for (int hd = 0; hd < 5; ++hd) {
           const int64_t rel = poff(e, fmt("vis_trans_%s_head%d/DW", lv, hd + 1)) - base_w;
           ov.push_back({0, (int64_t)hd * Cp, rel}); os.push_back({0, (int64_t)hd * Cp, rel + (int64_t)C * C});
-          CK(colsum(st, dt, (char*)dP + (size_t)hd * Cp * es, RF, 5 * Cp, Cp, C, gptr(e, fmt("vis_trans_%s_head%d/biases", lv, hd + 1))));
+          if (!e->mutan_bias_row) CK(colsum(st, dt, (char*)dP + (size_t)hd * Cp * es, RF, 5 * Cp, Cp, C, gptr(e, fmt("vis_trans_%s_head%d/biases", lv, hd + 1))));
       }
       float* gwv = gptr(e, fmt("vis_trans_%s_head1/DW", lv));
       CK(gemm_tn(e, st, dt, L.X0, Cp, Cp, dP, 5 * Cp, Cp, gwv, C, RF, C, C, ov, d));
-      CK(gemm_tn(e, st, dt, e->spatial, 64, 64, dP, 5 * Cp, Cp, gwv, C, RF, 8, C, os, d));
+      if (e->mutan_bias_row) CK(gemm_tn(e, st, dt, e->spatial1, 64, 64, dP, 5 * Cp, Cp, gwv, C, RF, 9, C, os, d));
+      else CK(gemm_tn(e, st, dt, e->spatial, 64, 64, dP, 5 * Cp, Cp, gwv, C, RF, 8, C, os, d));
       CK(gemm_nt(st, dt, {{dP, 5 * Cp, opp(e, fmt("mutan_%s.n", lv)), 5 * Cp, 5 * Cp}}, L.dX0, Cp, RF, Cp, oc));
       // the gates were tiled over the frames: their gradient is the sum over the frames
       hipLaunchKernelGGL(sum_rows_kernel, dim3((5 * Cp + 255) / 256), dim3(256), 0, st, L.dg, L.g1 /* reused: d gates [5 Cp] */, Fr, 5 * Cp, 0);
@@ -2131,7 +2138,18 @@ extern "C" int cmpc_create(const cmpc_cfg* c, cmpc_handle* out) {
         if (e->dt == DT_F32) ECK(hipMemcpy(e->spatial, tmp, (size_t)reps * e->N * 64 * sizeof(float), hipMemcpyDeviceToDevice));
         else if (cmpc_cast(DT_F32, tmp, e->dt, e->spatial, (int64_t)reps * e->N * 64, nullptr) != CMPC_OK) { (void)hipFree(tmp); return fail(CMPC_EHIP); }
         ECK(hipDeviceSynchronize());
+        // the same grid with a constant 1 in channel 8: out += A^T D then carries sum_rows(D) in row 8 (the bias gradient of a convolution
+        // whose last input channels are the grid and whose bias follows its DW in the parameter layout)
+        for (size_t i = 0; i < (size_t)e->N; ++i) sp[i * 64 + 8] = 1.0f;
+        for (int b = 0; b < reps; ++b) ECK(hipMemcpy(tmp + (size_t)b * e->N * 64, sp.data(), sp.size() * sizeof(float), hipMemcpyHostToDevice));
+        if (e->dt == DT_F32) ECK(hipMemcpy(e->spatial1, tmp, (size_t)reps * e->N * 64 * sizeof(float), hipMemcpyDeviceToDevice));
+        else if (cmpc_cast(DT_F32, tmp, e->dt, e->spatial1, (int64_t)reps * e->N * 64, nullptr) != CMPC_OK) { (void)hipFree(tmp); return fail(CMPC_EHIP); }
+        ECK(hipDeviceSynchronize());
         (void)hipFree(tmp);
+        e->mutan_bias_row = !getenv("CMPC_NO_BIAS_ROW");
+        for (int i = 0; i < e->nlev && e->mutan_bias_row; ++i)
+            for (int hd = 1; hd <= 5; ++hd)
+                if (poff(e, fmt("vis_trans_%s_head%d/biases", lvn(e, i), hd)) != poff(e, fmt("vis_trans_%s_head%d/DW", lvn(e, i), hd)) + (int64_t)(e->C + 8) * e->C) e->mutan_bias_row = false;
     }
     if (e->vid) {
         std::vector<float> on(64, 1.0f);
