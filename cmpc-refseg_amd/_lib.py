@@ -153,7 +153,7 @@ SIGNATURES = {
     "cmpc_l2norm_all_fwd": [_P, _P, _P, _I, _P],
     "cmpc_l2norm_all_bwd": [_P, _P, _P, _P, _I, _P],
     "cmpc_exchange_combine_fwd": [_I, _P, _P, _P, _P, _P, _I, _P, _P, _I, _I, _I, _I, _P],
-    "cmpc_exchange_combine_bwd": [_I, _P, _P, _P, _P, _P, _P, _P, _I, _P, _I, _P, _P, _P, _P, _I, _I, _I, _I, _P],
+    "cmpc_exchange_combine_bwd": [_I, _P, _P, _P, _P, _P, _P, _P, _I, _P, _I, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
     "cmpc_convlstm_a": [_I, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
     "cmpc_convlstm_b": [_I, _P, _P, _P, C.POINTER(ConvLstmLn), _P, _P, _I, _I, _I, _I, _P],
     "cmpc_convlstm_c": [_I, _P, _P, C.POINTER(ConvLstmLn), _P, _P, _P, _I, _I, _I, _I, _P],

@@ -1693,11 +1693,11 @@ int exchange_bwd(E* e, hipStream_t st, int xi, const void* dout, const void* fea
     const int nbr = f2 ? 2 : 1;
     TnOpt d; d.defer = true;
     CK(cmpc_exchange_combine_bwd(dt, dout, X.out, X.rstd, X.r[0], nbr == 2 ? X.r[1] : nullptr, X.g[0], nbr == 2 ? X.g[1] : nullptr, Mp, X.dfeat, 0,
-                                 X.dp[0], nbr == 2 ? X.dp[1] : nullptr, X.dg[0], nbr == 2 ? X.dg[1] : nullptr, B, N, Mp, M, st));
+                                 X.dp[0], nbr == 2 ? X.dp[1] : nullptr, X.dg[0], nbr == 2 ? X.dg[1] : nullptr,
+                                 gptr(e, fmt("trans_feat_%s_f1/biases", lv)), nbr == 2 ? gptr(e, fmt("trans_feat_%s_f2/biases", lv)) : nullptr, B, N, Mp, M, st));
     const void* fx[2] = {f1, f2}; const char* fn[2] = {"f1", "f2"};
     NtJob dj[2];
     for (int i = 0; i < nbr; ++i) {
-        CK(colsum(st, dt, X.dp[i], R, Mp, Mp, M, gptr(e, fmt("trans_feat_%s_%s/biases", lv, fn[i]))));
         CK(gemm_tn(e, st, dt, fx[i], Mp, Mp, X.dp[i], Mp, Mp, gptr(e, fmt("trans_feat_%s_%s/DW", lv, fn[i])), M, R, M, M, OFF0, d));
         GemmOpt o; o.n_valid = M;
         dj[i] = NtJob{Seg{X.dp[i], Mp, opp(e, fmt("tfeat_%s_%s.n", lv, fn[i])), Mp, Mp}, X.dfs[i], Mp, o};

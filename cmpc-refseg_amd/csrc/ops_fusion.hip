@@ -426,14 +426,15 @@ __global__ __launch_bounds__(256) void exch_combine_bwd_kernel(const T* __restri
                                                               const float* __restrict__ g1, const float* __restrict__ g2, int ld_g,
                                                               T* __restrict__ dfeat, int accumulate, T* __restrict__ dp1, T* __restrict__ dp2,
                                                               float* part, int N, int ld, int C) {
-    extern __shared__ float lds[];     // [WPB][2*ld]
+    extern __shared__ float lds[];     // [WPB][4*ld]
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, b = blockIdx.y;
     const bool two = r2 != nullptr;
     float a1[MB][8], a2[MB][8], gv1[MB][8], gv2[MB][8];
+    float s1c[MB][8], s2c[MB][8];       // column sums of dp1 / dp2 as stored: the trans_feat convolutions' bias gradients (no second pass over the maps)
 #pragma unroll
     for (int k = 0; k < MB; ++k) {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) { a1[k][e] = 0.f; a2[k][e] = 0.f; gv2[k][e] = 0.f; }
+        for (int e = 0; e < 8; ++e) { a1[k][e] = 0.f; a2[k][e] = 0.f; gv2[k][e] = 0.f; s1c[k][e] = 0.f; s2c[k][e] = 0.f; }
         const int c0 = k * 512 + lane * 8;
         if (c0 < ld) { ld8<float>(g1 + (long)b * ld_g + c0, gv1[k]); if (two) ld8<float>(g2 + (long)b * ld_g + c0, gv2[k]); }
     }
@@ -468,6 +469,7 @@ __global__ __launch_bounds__(256) void exch_combine_bwd_kernel(const T* __restri
                     o1[e] = (cc < C && x1[e] > 0.f) ? dE * gv1[k][e] : 0.f;
                     o2[e] = (cc < C && x2[e] > 0.f) ? dE * gv2[k][e] : 0.f;
                     df[e] = accumulate ? df[e] + dE : dE;
+                    s1c[k][e] += stored_value<T>(o1[e]); s2c[k][e] += stored_value<T>(o2[e]);
                 }
                 st8<T>(dp1 + base + c0, o1); if (two) st8<T>(dp2 + base + c0, o2); st8<T>(dfeat + base + c0, df);
             }
@@ -479,17 +481,22 @@ __global__ __launch_bounds__(256) void exch_combine_bwd_kernel(const T* __restri
         const int c0 = k * 512 + lane * 8;
         if (c0 < ld) {
 #pragma unroll
-            for (int e = 0; e < 8; ++e) { lds[(w * 2) * ld + c0 + e] = a1[k][e]; lds[(w * 2 + 1) * ld + c0 + e] = a2[k][e]; }
+            for (int e = 0; e < 8; ++e) {
+                lds[(w * 4) * ld + c0 + e] = a1[k][e]; lds[(w * 4 + 1) * ld + c0 + e] = a2[k][e];
+                lds[(w * 4 + 2) * ld + c0 + e] = s1c[k][e]; lds[(w * 4 + 3) * ld + c0 + e] = s2c[k][e];
+            }
         }
     }
     __syncthreads();
-    float* pr = part + ((long)b * gridDim.x + blockIdx.x) * 2 * ld;                 // partial rows [dg1 | dg2]
+    float* pr = part + ((long)b * gridDim.x + blockIdx.x) * 4 * ld;                 // partial rows [dg1 | dg2 | db1 | db2]
     for (int c = threadIdx.x; c < ld; c += 256) {
-        float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-        for (int ww = 0; ww < WPB; ++ww) { s1 += lds[(ww * 2) * ld + c]; s2 += lds[(ww * 2 + 1) * ld + c]; }
-        pr[c] = (c < C) ? s1 : 0.f;
-        pr[ld + c] = (c < C) ? s2 : 0.f;
+        for (int q = 0; q < 4; ++q) {
+            float sq = 0.f;
+#pragma unroll
+            for (int ww = 0; ww < WPB; ++ww) sq += lds[(ww * 4 + q) * ld + c];
+            pr[q * ld + c] = (c < C) ? sq : 0.f;
+        }
     }
 }
 
@@ -723,16 +730,19 @@ extern "C" int cmpc_exchange_combine_fwd(int dt, const void* feat, const void* r
 
 extern "C" int cmpc_exchange_combine_bwd(int dt, const void* dout, const void* out, const float* rstd, const void* r1, const void* r2,
                                          const float* g1, const float* g2, int ld_g, void* dfeat, int accumulate_dfeat,
-                                         void* dp1, void* dp2, float* dg1, float* dg2, int B, int N, int ld, int C, void* stream) {
+                                         void* dp1, void* dp2, float* dg1, float* dg2, float* db1, float* db2, int B, int N, int ld, int C, void* stream) {
     cmpc_op_scope op_("exchange_combine_bwd");
     if (!map_ok("exchange_combine_bwd", ld, C, dt)) return CMPC_EINVAL;
     const int gx = rows_grid(N, 64);
-    float* part = (float*)cmpc_ws((size_t)B * gx * 2 * ld * sizeof(float), ST);
+    float* part = (float*)cmpc_ws((size_t)B * gx * 4 * ld * sizeof(float), ST);
     if (!part) return CMPC_EHIP;
-    CMPC_DISPATCH_DT(dt, hipLaunchKernelGGL((exch_combine_bwd_kernel<T>), dim3(gx, B), dim3(256), WPB * 2 * ld * sizeof(float), ST,
+    CMPC_DISPATCH_DT(dt, hipLaunchKernelGGL((exch_combine_bwd_kernel<T>), dim3(gx, B), dim3(256), WPB * 4 * ld * sizeof(float), ST,
                                              (const T*)dout, (const T*)out, rstd, (const T*)r1, (const T*)r2, g1, g2, ld_g,
                                              (T*)dfeat, accumulate_dfeat, (T*)dp1, (T*)dp2, part, N, ld, C));
-    if (cmpc_reduce_parts_f32(part, 2L * ld, B, gx, 1, ld, C, dg1, ld_g, 0, 1, ST)) return CMPC_EHIP;
-    if (r2 && cmpc_reduce_parts_f32(part + ld, 2L * ld, B, gx, 1, ld, C, dg2, ld_g, 0, 1, ST)) return CMPC_EHIP;
+    if (cmpc_reduce_parts_f32(part, 4L * ld, B, gx, 1, ld, C, dg1, ld_g, 0, 1, ST)) return CMPC_EHIP;
+    if (r2 && cmpc_reduce_parts_f32(part + ld, 4L * ld, B, gx, 1, ld, C, dg2, ld_g, 0, 1, ST)) return CMPC_EHIP;
+    // db1 / db2 [C] += column sums of dp1 / dp2 over every row of the batch (gradient targets: folded with the bucket's other folds)
+    if (db1 && cmpc_reduce_parts_f32(part + 2 * ld, 4L * ld, 1, B * gx, 1, ld, C, db1, 0, 0, 1, ST)) return CMPC_EHIP;
+    if (r2 && db2 && cmpc_reduce_parts_f32(part + 3 * ld, 4L * ld, 1, B * gx, 1, ld, C, db2, 0, 0, 1, ST)) return CMPC_EHIP;
     return cmpc_check_launch("exchange_combine_bwd");
 }

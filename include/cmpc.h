@@ -180,10 +180,11 @@ int cmpc_l2norm_all_bwd(const float* dy, const float* y, const float* rstd1, flo
 /* out = l2norm_rows(feat + r1*g1[b] + r2*g2[b])  (:256-258,272); r2 = g2 = NULL: one gated branch (CMPCv5_BiLSTM_model.py:343-346; dp2 / dg2 unused) */
 int cmpc_exchange_combine_fwd(int dt, const void* feat, const void* r1, const void* r2, const float* g1, const float* g2,
                               int ld_g, void* out, float* rstd, int B, int N, int ld, int C, void* stream);
-/* dfeat (+)= dE; dp1 = dE*g1*[r1>0]; dp2 likewise; dg1/dg2 [B][ld_g] += sum_n dE*r  */
+/* dfeat (+)= dE; dp1 = dE*g1*[r1>0]; dp2 likewise; dg1/dg2 [B][ld_g] += sum_n dE*r; db1/db2 [C] (optional) += column sums of dp1/dp2
+ * over all B*N rows (the bias gradients of the trans_feat convolutions that produced r1/r2) */
 int cmpc_exchange_combine_bwd(int dt, const void* dout, const void* out, const float* rstd, const void* r1, const void* r2,
                               const float* g1, const float* g2, int ld_g, void* dfeat, int accumulate_dfeat,
-                              void* dp1, void* dp2, float* dg1, float* dg2, int B, int N, int ld, int C, void* stream);
+                              void* dp1, void* dp2, float* dg1, float* dg2, float* db1, float* db2, int B, int N, int ld, int C, void* stream);
 
 /* ---- ConvLSTMCell.call (util/cell.py:36-79), one time step; Yg [R, 4*ld] = [x|h].kernel with
  *      gate blocks j,i,f,o; peepholes W_c* are [N, M] fp32 (row stride M); LayerNorm vectors
