@@ -223,6 +223,7 @@ struct LevelBuf {          // one pyramid level (c5 / c4 / c3), forward then bac
     float *score, *up, *loss; int* iu;
     // backward
     void *dfus, *dpre, *dX1, *dX2, *dU, *dG, *dY, *Z, *dZ, *dZt, *dA0_t, *dX0, *dV;
+    void* dfeat = nullptr;  // cfg.conv5: d cost / d (backbone tap) [R, cin]
     float *dscore, *dsb, *dvl, *Zf, *dgw_w, *dZf, *dZtf, *dgw_v, *dA0, *dpr, *gsc2, *dPT, *dk0s, *dWd, *dwf, *dg;
     double* bs;
 };
@@ -529,7 +530,7 @@ void plan_operands(E* e) {
         Segs ks = {{0, cins[i], 0}};
         const bool hx = e->v5 && e->cfg.hsv;
         if (hx) ks.push_back({cins[i], 3, pad64(cins[i])});
-        linear(e, fmt("lat_%s", lvn(e, i)), fmt("%s_lateral/DW", lvn(e, i)), V, cins[i] + (hx ? 3 : 0), C, pad64(cins[i]) + (hx ? 64 : 0), Cp, true, false, ks);
+        linear(e, fmt("lat_%s", lvn(e, i)), fmt("%s_lateral/DW", lvn(e, i)), V, cins[i] + (hx ? 3 : 0), C, pad64(cins[i]) + (hx ? 64 : 0), Cp, true, e->cfg.conv5 != 0, ks);
     }
     for (int li = 0; li < e->nlev; ++li) {
         const char* lv = lvn(e, li);
@@ -744,6 +745,7 @@ void plan_workspace(E* e, Bump& zf, Bump& zb, Bump& g) {
         L.dWd = (float*)g.take((size_t)B * Tp * Cp * F); L.dwf = (float*)g.take((size_t)B * T * Cp * F);
         L.dg = (float*)zb.take((size_t)BL * 5 * Cp * F);
         L.dX0 = g.take((size_t)RL * Cp * es); L.dV = g.take((size_t)RL * Cp * es);
+        if (e->cfg.conv5) L.dfeat = g.take((size_t)RL * L.cin * es);
         if (e->vid) {
             const int Fr = e->Fr, mid = Fr / 2;
             L.X1m = (char*)L.X1 + (size_t)mid * N * Cp * es; L.X0m = (char*)L.X0 + (size_t)mid * N * Cp * es;
@@ -774,6 +776,7 @@ void plan_workspace(E* e, Bump& zf, Bump& zb, Bump& g) {
             tap(e, fmt("temp_ctx_%s", n), L.CTX, vd, {N, Cp});
         }
         tap(e, fmt("lat_%s", n), L.X0, vd, {RL, Cp}); tap(e, fmt("vis_la_sp_%s", n), L.X1, vd, {RL, Cp});
+        if (e->cfg.conv5) tap(e, fmt("d%s", n), L.dfeat, vd, {RL, L.cin});
         tap(e, fmt("spa_graph_%s", n), L.X2, vd, {R, Cp}); tap(e, fmt("fusion_%s", n), L.F, vd, {R, Mp});
         tap(e, fmt("gw_w_%s", n), L.gw_w, 0, {B, N, Tp}); tap(e, fmt("gw_v_%s", n), L.gw_v, 0, {B, N, Tp});
         tap(e, fmt("score_%s", n), L.score, 0, {B, e->h, e->w, 1}); tap(e, fmt("up_%s", n), L.up, 0, {B, H, W, 1});
@@ -1372,6 +1375,10 @@ int level_bwd(E* e, hipStream_t st, int li, const float* target) {
     if (!e->v5) CK(colsum(st, dt, L.dV, R, Cp, Cp, C, gptr(e, fmt("%s_lateral/biases", lv))));
     else CK(colsum(st, dt, L.dV, R, Cp, Cp, C, gptr(e, fmt("%s_lateral/biases", lv)), L.X0t, L.dV, ACT_TANH));
     float* glw = gptr(e, fmt("%s_lateral/DW", lv));
+    if (e->cfg.conv5) {      // conv5=True: the tap's own gradient, for the caller's backbone backward (CMPC_model.py:427-430)
+        GemmOpt o; o.n_valid = L.cin;
+        CK(gemm_nt(st, dt, {{L.dV, Cp, opp(e, fmt("lat_%s.n", lv)), Cp, Cp}}, L.dfeat, L.cin, R, L.cin, o));
+    }
     if (e->v5 && e->cfg.hsv) CK(gemm_tn(e, st, dt, e->hsv, 64, 64, L.dV, Cp, Cp, glw + (size_t)L.cin * C, C, R, 3, C, OFF0, d));
     return gemm_tn(e, st, dt, L.feat, L.cin, L.cin, L.dV, Cp, Cp, glw, C, R, L.cin, C, OFF0, d);
 }
@@ -1994,6 +2001,7 @@ extern "C" int cmpc_default_cfg(cmpc_cfg* c) {
 extern "C" int cmpc_default_cfg_model(cmpc_cfg* c, int model, int hsv) {
     if (!c || (model != CMPC_MODEL_CMPC && model != CMPC_MODEL_V5_BILSTM && model != CMPC_MODEL_VIDEO)) { cmpc_set_error("default_cfg_model: bad argument"); return CMPC_EINVAL; }
     c->sample_frames = 5;                             // CMPC_video_mm_tgraph_allvec.py:69
+    c->conv5 = 0;
     c->model = model; c->hsv = (model == CMPC_MODEL_V5_BILSTM && hsv) ? 1 : 0;
     c->bn_decay = 0.9997f; c->c2_dim = 256; c->c2_h = c->H / 4; c->c2_w = c->W / 4; c->aspp_depth = 256; c->low_dim = 48;
     c->aspp_rates[0] = 6; c->aspp_rates[1] = 12; c->aspp_rates[2] = 18;
@@ -2034,6 +2042,7 @@ extern "C" int cmpc_create(const cmpc_cfg* c, cmpc_handle* out) {
     }
     if (pad64(c->v_emb_dim) > 2048 || pad64(c->mlp_dim) > 2048) { cmpc_set_error("create: v_emb_dim, mlp_dim <= 2048 (per-column registers of the map kernels)"); return CMPC_EINVAL; }
     if (c->n_lanes < 1 || c->n_lanes > 3) { cmpc_set_error("create: n_lanes must be 1, 2 or 3"); return CMPC_EINVAL; }
+    if (c->conv5 && c->model != CMPC_MODEL_CMPC) { cmpc_set_error("create: conv5 (backbone tap gradients) is CMPC_model's option (CMPC_model.py:427-430)"); return CMPC_EINVAL; }
     if (c->model != CMPC_MODEL_CMPC && c->model != CMPC_MODEL_V5_BILSTM && c->model != CMPC_MODEL_VIDEO) {
         cmpc_set_error("create: model must be CMPC_MODEL_CMPC (0), CMPC_MODEL_V5_BILSTM (1) or CMPC_MODEL_VIDEO (2)"); return CMPC_EINVAL;
     }

@@ -59,8 +59,7 @@ class LSTM_model(object):
         # (freeze_bn, is_aug: trainval_model.py:40).
         if optimizer != 'adam':
             raise ValueError("Unknown optimizer type %s!" % optimizer)          # CMPC_model.py:458
-        if conv5:
-            raise NotImplementedError("conv5=True (backbone fine-tuning, CMPC_model.py:427-430) is out of scope")
+        self.conv5 = bool(conv5)
         if keep_prob_rnn != 1.0 or keep_prob_emb != 1.0 or keep_prob_mlp != 1.0 or num_rnn_layers != 1:
             raise NotImplementedError("dropout / stacked LSTM are unused by the reference graph")
         if dtype not in ("bf16", "f16", "f32"):
@@ -96,7 +95,7 @@ class LSTM_model(object):
                            lr_decay_step=lr_decay_step, weight_decay=weight_decay,
                            model=model_id, hsv=hsv, bn_train=int(self.v5 and mode == 'train'), bn_decay=batch_norm_decay,
                            c2_dim=4 * backbone_width, c2_h=-(-H // 4), c2_w=-(-W // 4), aspp_depth=aspp_depth, low_dim=low_dim,
-                           aspp_rates=tuple(aspp_rates), sample_frames=len(FRAME_IDX))
+                           aspp_rates=tuple(aspp_rates), sample_frames=len(FRAME_IDX), conv5=int(self.conv5))
         for name, v in (("vf_dim", vf_dim), ("c4_dim", c4_dim), ("c3_dim", c3_dim)):
             if v % 64:
                 raise ValueError(f"{name}={v} must be a multiple of 64 (MFMA K tile)")
@@ -121,10 +120,17 @@ class LSTM_model(object):
             if self.v5:
                 self.backbone.taps_wanted = ("2b", 4, 5)      # res2b_relu, res4b22_relu, res5c_relu (CMPCv5_BiLSTM_model.py:86-88)
             # the frozen backbone's variables under their TensorFlow names (deeplab_resnet/model.py): kept for checkpoints
-            self.backbone_vars = dict(backbone_params if backbone_params is not None else
+            self._backbone_vars = dict(backbone_params if backbone_params is not None else
                                       bb.init_params(backbone_width, backbone_blocks, stem_gamma=1.0 / 256.0 if self.v5 else 1.0))
-            self.backbone.load_tf(self.backbone_vars)
+            self.backbone.load_tf(self._backbone_vars)
             self.backbone = self.backbone.to(self.device).to(tdt(self.dt)).to(memory_format=torch.channels_last).eval()
+            self.bb_trainer = None
+            if self.conv5:
+                # conv5=True (CMPC_model.py:427-430): the res3 / res4 / res5 convolution weights train with the head
+                if self.v5 or self.video:
+                    raise NotImplementedError("conv5=True is CMPC_model's option (CMPC_model.py:427-430)")
+                from .backbone_train import BackboneTrainer
+                self.bb_trainer = BackboneTrainer(self.backbone, self._backbone_vars, self.device, weight_decay)
         self.world, self.dp_on = 1, False
         self.last = {}
         self._inflight = []
@@ -160,15 +166,38 @@ class LSTM_model(object):
             out[name] = t.float()
         return out
 
-    # non-trainable variables for checkpoints (checkpoint.py): the batch-norm moving statistics of the v5 graph
+    @property
+    def backbone_vars(self):
+        """The backbone's variables under their TensorFlow names (checkpoints); with conv5=True the trained res3-res5 weights are current."""
+        if getattr(self, "bb_trainer", None) is not None:
+            self._backbone_vars.update(self.bb_trainer.named_weights())
+        return self._backbone_vars
+
+    @backbone_vars.setter
+    def backbone_vars(self, named):
+        self._backbone_vars = dict(named)
+
+    # variables for checkpoints besides the head's (checkpoint.py): the batch-norm moving statistics of the v5 graph; with conv5=True the
+    # Adam slots of the trained backbone weights (slot names by the same TF1 rule as the head's: parity-unpinned)
     def extra_vars(self):
-        return self.eng.get_state()
+        out = dict(self.eng.get_state())
+        if getattr(self, "bb_trainer", None) is not None:
+            for k, v in self.bb_trainer.named_slots().items():
+                out["text_objseg/" + k] = v
+        return out
 
     def extra_var_names(self):
-        return tuple(self.eng.state_index)
+        names = tuple(self.eng.state_index)
+        if getattr(self, "bb_trainer", None) is not None:
+            names += tuple("text_objseg/" + k for k in self.bb_trainer.named_slots())
+        return names
 
     def load_extra_vars(self, named):
-        self.eng.set_state(named)
+        state = {k: v for k, v in named.items() if k in self.eng.state_index}
+        if state:
+            self.eng.set_state(state)
+        if getattr(self, "bb_trainer", None) is not None:
+            self.bb_trainer.load_slots({k[len("text_objseg/"):]: v for k, v in named.items() if k.startswith("text_objseg/res")})
 
     def set_lanes(self, n: int):
         """n = 3: levels / exchange modules on the handle's three lane streams, backbone and optimizer on side streams;
@@ -409,6 +438,8 @@ class LSTM_model(object):
             if not torch.is_tensor(im):
                 ready = None                    # host feeds: the copy below is ordered on the caller's stream, which the backbone then waits for
             imd = self._dev(im, torch.float32)
+            if self.bb_trainer is not None:
+                return self._train_step_conv5(words, imd, target_fine, seq_len)
             pf, self._prefetched = self._prefetched, None
             if pf is not None and pf[0] is im:
                 feats, ev = pf[1], pf[2]
@@ -445,6 +476,30 @@ class LSTM_model(object):
         self.last = scal
         return self.eng.step, scal
 
+    def _train_step_conv5(self, words, imd, target_fine, seq_len):
+        """conv5=True (CMPC_model.py:427-430): backbone forward with its activations kept, head forward / backward (which also returns
+        d cost / d c5, c4, c3), backbone backward, one TF-Adam step over the head and the res3-res5 convolution weights.  Everything on the
+        caller's stream (no side streams: the optional mode is not the benchmarked one)."""
+        if self.dp_on:
+            raise NotImplementedError("conv5=True with data-parallel training: the backbone gradients are not exchanged")
+        B, h, w = self.batch_size, self.cfg.vf_h, self.cfg.vf_w
+        feats = self.bb_trainer.forward(imd)
+        self.loss_and_grads(feats, words, target_fine, seq_len, im=imd)
+        sv = self.eng.tap("scalars").clone()
+        dt = {5: self.eng.tap("dc5").view(B, h, w, -1), 4: self.eng.tap("dc4").view(B, h, w, -1), 3: self.eng.tap("dc3").view(B, h, w, -1)}
+        self.bb_trainer.backward(dt)
+        step0 = self.eng.step
+        for b in range(self.eng.n_buckets):
+            lr = self.eng.optimizer_bucket(b, 1.0)
+        t = float(step0 + 1)
+        lr_t = lr * (1.0 - 0.999 ** t) ** 0.5 / (1.0 - 0.9 ** t)
+        self.bb_trainer.adam(lr_t, 1.0 / self.eng.loss_scale)
+        scal = {k: sv[i] for i, k in enumerate(self._SCALARS)}
+        scal["mean_IOU"] = scal.pop("mIoU")
+        scal["learning_rate"] = lr
+        self.last = scal
+        return self.eng.step, scal
+
     def grad_nonfinite(self) -> int:
         """Gradient elements the LAST optimizer step skipped because they were inf / nan (f16 storage overflow; synchronises).  Non-zero =
         lower the loss scale; parameter and Adam moments of those elements were left untouched (cmpc_adam_step)."""
@@ -466,8 +521,10 @@ class LSTM_model(object):
         captured backbone graphs stay valid (weights are updated in place)."""
         with torch.cuda.device(self.device):
             torch.cuda.synchronize(self.device)
-            self.backbone_vars = dict(named)
-            self.backbone.load_tf(self.backbone_vars)
+            self._backbone_vars = dict(named)
+            self.backbone.load_tf(self._backbone_vars)
+            if getattr(self, "bb_trainer", None) is not None:
+                self.bb_trainer.load(self._backbone_vars)
             torch.cuda.synchronize(self.device)
 
     def enable_data_parallel(self):

@@ -637,6 +637,46 @@ def train_step(p, opt: TFAdam, step, feats, words, seq_len, target_fine, cfg: Cf
     return scal
 
 
+def conv5_trainable(bp):
+    """Backbone variables train_op() adds with conv5=True (CMPC_model.py:427-430): names starting with res3 / res4 / res5, i.e. the
+    convolution weights only (the batch-norm variables are named bn...)."""
+    return [k for k in bp if k.startswith(("res3", "res4", "res5"))]
+
+
+def grads_of_conv5(p, bp, im, words, seq_len, target_fine, cfg: Cfg):
+    """compute_gradients with conv5=True: d cost / d (head parameters, res3-res5 convolution weights); the L2 term also covers the trained
+    backbone weights (reg_var_list: name[-9:-2] == 'weights', CMPC_model.py:433).  Returns (scalars, head grads, backbone grads)."""
+    leaves = {k: v.detach().clone().requires_grad_(True) for k, v in p.items()}
+    names_b = conv5_trainable(bp)
+    bl = dict(bp)
+    for n in names_b:
+        bl[n] = bp[n].detach().clone().requires_grad_(True)
+    feats = backbone_forward(bl, im, cfg)
+    taps = head_forward(leaves, feats, words, seq_len, cfg)
+    ls = losses(leaves, taps, target_fine, cfg)
+    cost = ls["cost"] + cfg.weight_decay * sum(0.5 * (bl[n] ** 2).sum() for n in names_b)
+    names = list(leaves)
+    gs = torch.autograd.grad(cost, [leaves[n] for n in names] + [bl[n] for n in names_b], allow_unused=True)
+    flags = {n: f for n, _, _, f in head_param_specs(cfg)}
+    grads = {}
+    for n, g in zip(names, gs[:len(names)]):
+        g = torch.zeros_like(leaves[n]) if g is None else g
+        grads[n] = (g * 2.0 if "x2" in flags[n] else g).detach()
+    gb = {n: g.detach() for n, g in zip(names_b, gs[len(names):])}
+    return {k: float(v.detach()) for k, v in ls.items()}, grads, gb
+
+
+def train_step_conv5(p, bp, opt: TFAdam, opt_b: TFAdam, step, im, words, seq_len, target_fine, cfg: Cfg):
+    """One train step with conv5=True: head parameters and res3-res5 weights updated in place (two TFAdam objects sharing the step)."""
+    scal, grads, gb = grads_of_conv5(p, bp, im, words, seq_len, target_fine, cfg)
+    lr = poly_lr(step, cfg)
+    with torch.no_grad():
+        opt.step(p, grads, lr)
+        opt_b.step({n: bp[n] for n in gb}, gb, lr)
+    scal["lr"] = lr
+    return scal
+
+
 # ----------------------------------------------------------------------------------------
 # Synthetic inputs (SURVEY.md 8d)
 # ----------------------------------------------------------------------------------------
