@@ -166,6 +166,9 @@ class Saver:
     def restore(self, model, path: str, strict: bool = True):
         if os.path.exists(path + ".index"):
             vs = tf_bundle.read_bundle(path)
+        elif tf_bundle.is_v1_checkpoint(path):
+            # a V1 (single-file) TensorFlow checkpoint: what `deeplab_resnet_init.ckpt` is (trainval_model.py:50)
+            vs = tf_bundle.read_v1_checkpoint(path)
         else:
             with np.load(path, allow_pickle=False) as z:
                 vs = {k.replace("|", "/"): z[k] for k in z.files}

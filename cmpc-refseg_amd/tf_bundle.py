@@ -368,6 +368,163 @@ def write_bundle(prefix: str, variables: Dict[str, np.ndarray], block_size: int 
         fh.write(_write_table(entries, block_size))
 
 
+# ---- V1 checkpoints: tf.train.Saver(write_version=V1), one file written by TensorSliceWriter --------------------------------------
+# The file IS a sorted string table (same block / footer format as the V2 index above).  Entry "" holds a SavedTensorSlices message whose
+# `meta` (field 1) lists every tensor: SavedSliceMeta {name = 1, shape = 2 (TensorShapeProto), type = 3, slice = 4}.  Every other entry
+# holds a SavedTensorSlices whose `data` (field 2) is a SavedSlice {name = 1, slice = 2 (TensorSliceProto: repeated Extent {start = 1,
+# length = 2}; an extent with neither is the whole dimension), data = 3 (TensorProto with the VALUES in its typed repeated field: float_val
+# = 5, double_val = 6, int_val = 7, int64_val = 10, bool_val = 11, half_val = 13; or tensor_content = 4)}
+# (tensorflow/core/util/saved_tensor_slice.proto, tensor_slice_writer.{h,cc}).  The entry keys (OrderedCode of name + slice) are not
+# needed for reading.  This is the format of `deeplab_resnet_init.ckpt` (trainval_model.py:50); restated from the published format --
+# no V1 file written by TensorFlow exists here: PARITY UNPINNED.
+def is_v1_checkpoint(path: str) -> bool:
+    if not os.path.isfile(path) or os.path.getsize(path) < 48:
+        return False
+    with open(path, "rb") as fh:
+        fh.seek(-8, os.SEEK_END)
+        return struct.unpack("<Q", fh.read(8))[0] == MAGIC
+
+
+def _shape_of(b: bytes) -> Tuple[int, ...]:
+    shape = []
+    for f2, _, d in _fields(b):
+        if f2 == 2:
+            sz = 0
+            for f3, _, y in _fields(d):
+                if f3 == 1: sz = _signed64(y)
+            shape.append(sz)
+    return tuple(shape)
+
+
+def _extents(b: bytes, shape: Tuple[int, ...]):
+    """TensorSliceProto -> [(start, length)] per dimension."""
+    ext = []
+    for f, _, e in _fields(b):
+        if f != 1:
+            continue
+        start, length = 0, None
+        for f2, _, y in _fields(e):
+            if f2 == 1: start = _signed64(y)
+            elif f2 == 2: length = _signed64(y)
+        d = len(ext)
+        ext.append((start, (shape[d] - start) if length is None or length < 0 else length))
+    while len(ext) < len(shape):
+        ext.append((0, shape[len(ext)]))
+    return ext
+
+
+_V1_FIELD = {5: (np.float32, 5, "<f4"), 6: (np.float64, 1, "<f8")}        # packed fixed-width fields of TensorProto: field -> (dtype, wire, fmt)
+
+
+def _tensor_values(b: bytes, dtype: np.dtype) -> np.ndarray:
+    """The values of a TensorProto written by TensorSliceWriter::SaveData (typed repeated field) or as tensor_content."""
+    parts: List[np.ndarray] = []
+    for f, wt, x in _fields(b):
+        if f == 4 and wt == 2:                                  # tensor_content
+            parts.append(np.frombuffer(x, dtype=dtype))
+        elif f in _V1_FIELD and np.dtype(_V1_FIELD[f][0]) == dtype:
+            parts.append(np.frombuffer(x, dtype=_V1_FIELD[f][2]) if wt == 2 else np.array([struct.unpack("<f" if f == 5 else "<d", struct.pack("<I" if f == 5 else "<Q", x))[0]], dtype))
+        elif f in (7, 10, 11, 13) and wt in (0, 2):             # int_val / int64_val / bool_val / half_val: varints (packed or not)
+            vals = []
+            if wt == 0:
+                vals.append(x)
+            else:
+                pos = 0
+                while pos < len(x):
+                    v, pos = _get_varint(x, pos)
+                    vals.append(v)
+            if f == 13:
+                parts.append(np.array(vals, dtype=np.uint16).view(np.float16))
+            else:
+                parts.append(np.array([_signed64(v) for v in vals], dtype=np.int64).astype(dtype))
+    return np.concatenate(parts) if parts else np.zeros(0, dtype)
+
+
+def read_v1_checkpoint(path: str, names: Optional[Iterable[str]] = None, verify: bool = True) -> Dict[str, np.ndarray]:
+    with open(path, "rb") as fh:
+        f = fh.read()
+    want = None if names is None else set(names)
+    meta: Dict[str, Tuple[np.dtype, Tuple[int, ...]]] = {}
+    out: Dict[str, np.ndarray] = {}
+    filled: Dict[str, int] = {}
+    for k, v in _table_entries(f, verify):
+        for fno, _, x in _fields(v):
+            if fno == 1:                                        # SavedTensorSliceMeta
+                for f1, _, t in _fields(x):
+                    if f1 != 1:
+                        continue
+                    name, shape, dt = "", (), 1
+                    for f2, _, y in _fields(t):
+                        if f2 == 1: name = y.decode()
+                        elif f2 == 2: shape = _shape_of(y)
+                        elif f2 == 3: dt = y
+                    if dt not in _DT:
+                        raise ValueError(f"{name}: unsupported dtype enum {dt}")
+                    meta[name] = (np.dtype(_DT[dt]), shape)
+            elif fno == 2:                                      # SavedSlice
+                name, sl, data = "", b"", b""
+                for f1, _, y in _fields(x):
+                    if f1 == 1: name = y.decode()
+                    elif f1 == 2: sl = y
+                    elif f1 == 3: data = y
+                if name not in meta:
+                    raise ValueError(f"V1 checkpoint: data entry for {name!r} before / without its metadata")
+                if want is not None and name not in want:
+                    continue
+                dtype, shape = meta[name]
+                ext = _extents(sl, shape)
+                vals = _tensor_values(data, dtype)
+                n = int(np.prod([l for _, l in ext], dtype=np.int64)) if ext else 1
+                if vals.size != n:
+                    raise ValueError(f"{name}: slice holds {vals.size} values, its extents say {n}")
+                if name not in out:
+                    out[name] = np.zeros(shape, dtype)
+                    filled[name] = 0
+                out[name][tuple(slice(s, s + l) for s, l in ext)] = vals.reshape([l for _, l in ext])
+                filled[name] += n
+    for name, (dtype, shape) in meta.items():
+        if want is not None and name not in want:
+            continue
+        total = int(np.prod(shape, dtype=np.int64)) if shape else 1
+        if filled.get(name, 0) != total:
+            raise ValueError(f"{name}: {filled.get(name, 0)} of {total} values present")
+    if want is not None and want - set(out):
+        raise KeyError(f"checkpoint {path} lacks {sorted(want - set(out))[:3]}")
+    return out
+
+
+def _ordered_num(v: int) -> bytes:          # OrderedCode::WriteNumIncreasing
+    b = v.to_bytes(8, "big").lstrip(b"\0")
+    return bytes([len(b)]) + b
+
+
+def _ordered_str(s: bytes) -> bytes:        # OrderedCode::WriteString
+    return s.replace(b"\0", b"\0\xff").replace(b"\xff", b"\xff\0") + b"\0\x01"
+
+
+def write_v1_checkpoint(path: str, variables: Dict[str, np.ndarray], block_size: int = 262144) -> None:
+    """A V1 checkpoint of whole (unsliced) float32 / float64 / int32 / int64 tensors, as TensorSliceWriter lays it out."""
+    metas, entries = [], []
+    for name in sorted(variables):
+        a = np.asarray(variables[name])
+        a = a if a.flags.c_contiguous else a.copy()                       # (np.ascontiguousarray would turn a scalar into shape (1,))
+        if a.dtype not in _DT_OF:
+            raise ValueError(f"{name}: unsupported dtype {a.dtype}")
+        shp = _msg(*[_f_bytes(2, _f_varint(1, d)) for d in a.shape])
+        full = _msg(*[_f_bytes(1, b"") for _ in a.shape])                  # every extent the whole dimension
+        metas.append(_f_bytes(1, _msg(_f_bytes(1, name.encode()), _f_bytes(2, shp), _f_varint(3, _DT_OF[a.dtype]), _f_bytes(4, full))))
+        if a.dtype == np.float32: vals = _f_bytes(5, a.astype("<f4").tobytes())
+        elif a.dtype == np.float64: vals = _f_bytes(6, a.astype("<f8").tobytes())
+        else: vals = _f_bytes(7 if a.dtype == np.int32 else 10, b"".join(_put_varint(int(x) & ((1 << 64) - 1)) for x in a.reshape(-1)))
+        # key: OrderedCode(0, name, rank, then (start, length) = (0, -1) per dimension as single-byte signed numbers 0x80, 0x7f)
+        key = _ordered_num(0) + _ordered_str(name.encode()) + _ordered_num(a.ndim) + b"\x80\x7f" * a.ndim
+        entries.append((key, _f_bytes(2, _msg(_f_bytes(1, name.encode()), _f_bytes(2, full), _f_bytes(3, vals)))))
+    entries.sort(key=lambda kv: kv[0])
+    table = [(b"", _f_bytes(1, _msg(*metas)))] + entries
+    with open(path, "wb") as fh:
+        fh.write(_write_table(table, block_size))
+
+
 def write_checkpoint_state(directory: str, latest: str, all_paths: Iterable[str]) -> None:
     """The `checkpoint` text file tf.train.Saver keeps beside its snapshots (tf.train.latest_checkpoint reads it)."""
     with open(os.path.join(directory, "checkpoint"), "w") as fh:

@@ -156,3 +156,75 @@ def test_saver_writes_and_reads_tensorflow_checkpoints(tmp_path):
         assert float(model.backbone_vars["conv1/weights"].sum()) == 7 * 7 * 3 * 4
     finally:
         torch.cuda.synchronize, torch.cuda.device = orig, orig_dev
+
+
+def test_v1_checkpoint_known_answer_and_round_trip(tmp_path):
+    """V1 (single-file, TensorSliceWriter) checkpoints -- the format of deeplab_resnet_init.ckpt (trainval_model.py:50).  A byte-level known
+    answer assembled by hand from saved_tensor_slice.proto (one float32 [2] tensor "v" = (1, 2)), a multi-block round trip of several
+    dtypes incl. a scalar, a hand-built SLICED tensor (two SavedSlice entries with explicit extents) and corruption detection.  No V1 file
+    written by TensorFlow exists here: parity unpinned."""
+    p = str(tmp_path / "m.ckpt")
+    TB.write_v1_checkpoint(p, {"v": np.array([1.0, 2.0], np.float32)})
+    raw = open(p, "rb").read()
+    meta = bytes([0x0A, 0x11,                                                  # SavedTensorSlices.meta (len 17)
+                  0x0A, 0x0F,                                                  #   tensor (SavedSliceMeta, len 15)
+                  0x0A, 0x01]) + b"v" + bytes([0x12, 0x04, 0x12, 0x02, 0x08, 0x02,   # name "v"; shape{dim{size=2}}
+                  0x18, 0x01,                                                  #   type DT_FLOAT
+                  0x22, 0x02, 0x0A, 0x00])                                     #   slice{extent{}}  (the whole dimension)
+    data = bytes([0x12, 0x13,                                                  # SavedTensorSlices.data (SavedSlice, len 19)
+                  0x0A, 0x01]) + b"v" + bytes([0x12, 0x02, 0x0A, 0x00,         # name; slice{extent{}}
+                  0x1A, 0x0A, 0x2A, 0x08]) + struct.pack("<2f", 1.0, 2.0)      # data{float_val (packed) = 1, 2}
+    key = bytes([0x00]) + b"v" + bytes([0x00, 0x01]) + bytes([0x01, 0x01]) + bytes([0x80, 0x7F])    # OrderedCode: 0, "v", rank 1, start 0, length -1
+    block = (bytes([0, 0, len(meta)]) + meta + bytes([0, len(key), len(data)]) + key + data + struct.pack("<II", 0, 1))
+    assert raw[: len(block)] == block and raw[len(block)] == 0
+    assert TB.is_v1_checkpoint(p) and not TB.is_v1_checkpoint(__file__)
+    r = TB.read_v1_checkpoint(p)
+    assert list(r) == ["v"] and r["v"].dtype == np.float32 and np.array_equal(r["v"], [1.0, 2.0])
+    rng = np.random.default_rng(1)
+    vs = {"conv1/weights": rng.standard_normal((7, 7, 3, 64)).astype(np.float32), "bn_conv1/moving_variance": rng.random(64).astype(np.float32),
+          "global_step": np.asarray(7, np.int32), "counts": (np.arange(12, dtype=np.int64).reshape(3, 4) - 6), "dbl": rng.standard_normal((3, 2))}
+    TB.write_v1_checkpoint(p, vs, block_size=1024)
+    r = TB.read_v1_checkpoint(p)
+    assert set(r) == set(vs)
+    for k in vs:
+        assert r[k].dtype == vs[k].dtype and r[k].shape == vs[k].shape and np.array_equal(r[k], vs[k]), k
+    assert list(TB.read_v1_checkpoint(p, names=["global_step"])) == ["global_step"]
+    with pytest.raises(KeyError):
+        TB.read_v1_checkpoint(p, names=["nope"])
+    # a partitioned tensor: rows [0,2) and [2,3) of a [3,2] float tensor as two SavedSlice entries
+    full = np.arange(6, dtype=np.float32).reshape(3, 2)
+    shp = TB._msg(TB._f_bytes(2, TB._f_varint(1, 3)), TB._f_bytes(2, TB._f_varint(1, 2)))
+    def ext(start, length): return TB._f_bytes(1, TB._msg(TB._f_varint(1, start), TB._f_varint(2, length)))
+    s1, s2 = TB._msg(ext(0, 2), TB._f_bytes(1, b"")), TB._msg(ext(2, 1), TB._f_bytes(1, b""))
+    metab = TB._f_bytes(1, TB._f_bytes(1, TB._msg(TB._f_bytes(1, b"p"), TB._f_bytes(2, shp), TB._f_varint(3, 1), TB._f_bytes(4, s1), TB._f_bytes(4, s2))))
+    def sl(s, vals): return TB._f_bytes(2, TB._msg(TB._f_bytes(1, b"p"), TB._f_bytes(2, s), TB._f_bytes(3, TB._f_bytes(5, vals.astype("<f4").tobytes()))))
+    open(p, "wb").write(TB._write_table([(b"", metab), (b"\x00p\x00\x01a", sl(s1, full[:2])), (b"\x00p\x00\x01b", sl(s2, full[2:]))], 4096))
+    assert np.array_equal(TB.read_v1_checkpoint(p)["p"], full)
+    open(p, "wb").write(TB._write_table([(b"", metab), (b"\x00p\x00\x01a", sl(s1, full[:2]))], 4096))
+    with pytest.raises(ValueError):
+        TB.read_v1_checkpoint(p)                                               # a slice is missing
+    TB.write_v1_checkpoint(p, vs, block_size=1024)
+    b = bytearray(open(p, "rb").read()); b[100] ^= 0x40; open(p, "wb").write(bytes(b))
+    with pytest.raises(ValueError):
+        TB.read_v1_checkpoint(p)                                               # block checksum
+
+
+def test_saver_restores_backbone_from_v1_checkpoint(tmp_path):
+    """trainval_model.py:50-54: Saver(var_list = backbone variables).restore(sess, deeplab_resnet_init.ckpt) -- a V1 file."""
+    import contextlib
+    import torch
+    calls = {}
+    bb = {"conv1/weights": np.ones((7, 7, 3, 8), np.float32), "bn_conv1/gamma": np.full(8, 2.0, np.float32)}
+    eng = types.SimpleNamespace(index={}, pack=lambda: None, step=0)
+    model = types.SimpleNamespace(eng=eng, device=torch.device("cpu"), backbone_vars={k: torch.zeros(v.shape) for k, v in bb.items()},
+                                  load_backbone=lambda named: calls.setdefault("bb", named))
+    p = str(tmp_path / "deeplab_resnet_init.ckpt")
+    TB.write_v1_checkpoint(p, dict(bb, **{"fc1_voc12_c0/weights": np.zeros((3, 3, 8, 21), np.float32)}))
+    orig, orig_dev = torch.cuda.synchronize, torch.cuda.device
+    torch.cuda.synchronize = lambda *a, **k: None
+    torch.cuda.device = lambda d: contextlib.nullcontext()
+    try:
+        CK.Saver(var_filter=CK.is_backbone_var).restore(model, p)
+    finally:
+        torch.cuda.synchronize, torch.cuda.device = orig, orig_dev
+    assert set(calls["bb"]) >= set(bb) and all(np.array_equal(np.asarray(calls["bb"][k]), bb[k]) for k in bb)
