@@ -233,6 +233,7 @@ def main():
     ap.add_argument("--no-forward-only", action="store_true", help="skip the forward-only rate (profiling runs)")
     ap.add_argument("--model", default="CMPC_model", choices=("CMPC_model", "CMPCv5_BiLSTM_model", "CMPCv5_BiLSTM_HSV_model"),
                     help="CMPC_model = BASELINE config 2 (the metric); the CMPCv5 models run BASELINE config 4 (512x512, L=25) as the line's workload")
+    ap.add_argument("--prefetch-gate", default="fwd", choices=("fwd", "bwd"), help="with --prefetch: the next batch's backbone starts behind this step's levels' forward / backward")
     ap.add_argument("--prefetch", action="store_true", help="hand train_step the next batch, whose backbone pass then runs behind this step's levels instead "
                     "of at the start of its own step (measured SLOWER: 11.2 vs 10.5 ms, DESIGN 7; off by default)")
     ap.add_argument("--no-config4", action="store_true", help="skip the BASELINE config 4 rate reported inside the default line")
@@ -283,7 +284,7 @@ def main():
     SETUP_STEPS = 6
     # --prefetch: a prefetching loader (the reference's DataReader thread) has the next batch resident while the current one trains; train_step
     # is told about it and enqueues its frozen-backbone pass inside the current step (same work per step, every step runs its own pass)
-    nxt = {"next_im": im, "next_ready": ready} if args.prefetch else {}
+    nxt = {"next_im": im, "next_ready": ready, "next_gate": args.prefetch_gate} if args.prefetch else {}
     for _ in range(SETUP_STEPS):
         model.train_step(words, im, target, seq_len, ready=ready, **nxt)
     torch.cuda.synchronize()

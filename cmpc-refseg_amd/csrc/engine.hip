@@ -273,6 +273,7 @@ struct cmpc_engine_s {
     hipStream_t own_lane[3] = {nullptr, nullptr, nullptr};   // the streams this handle created
     std::vector<hipEvent_t> evpool; size_t evnext = 0;
     hipEvent_t ev_opt0 = nullptr, ev_opt1 = nullptr; bool opt_pending = false;
+    hipEvent_t user_bwd_levels = nullptr;     // caller's event, recorded when the levels' backward is complete (cmpc_set_bwd_levels_event)
     // buffers
     void* spatial = nullptr;
     void* spatial1 = nullptr;        // the grid with a constant 1 in channel 8: A operand of the products whose row 8 is the bias gradient
@@ -2538,6 +2539,14 @@ extern "C" int cmpc_forward(cmpc_handle e, const cmpc_feeds* f, const cmpc_fetch
 #include <chrono>
 static double host_now() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 #define HOSTPROF(tag) do { if (hp) { const double t_ = host_now(); fprintf(stderr, "[host] %-14s %7.3f ms\n", tag, t_ - hp_t); hp_t = t_; } } while (0)
+// event (hipEvent_t, caller-owned; NULL = none) that every later cmpc_backward records once the pyramid levels' backward is complete: what
+// follows is the grouped weight-gradient launch of the levels beside the text encoder's backward (room for independent work of the caller)
+extern "C" int cmpc_set_bwd_levels_event(cmpc_handle e, void* event) {
+    if (!e) { cmpc_set_error("set_bwd_levels_event: null handle"); return CMPC_EINVAL; }
+    e->user_bwd_levels = (hipEvent_t)event;
+    return CMPC_OK;
+}
+
 extern "C" int cmpc_backward(cmpc_handle e, void* stream) {
     if (!e) { cmpc_set_error("backward: null handle"); return CMPC_EINVAL; }
     static const bool hp = getenv("CMPC_HOST_PROFILE") != nullptr;
@@ -2629,6 +2638,7 @@ extern "C" int cmpc_backward(cmpc_handle e, void* stream) {
         CK(mark(e, lvb[i], st[i]));
     }
     CK(join_lanes(e, main));
+    if (e->user_bwd_levels) HCK(hipEventRecord(e->user_bwd_levels, main));
     HOSTPROF("levels");
     // Every weight-gradient product queued so far (levels, exchanges, ConvLSTM: ~1.7 ms of MFMA work) has its operands complete:
     // issue it on lane 0 now, beside the text encoder's backward (a serial chain of ~60 small launches on `main` that leaves

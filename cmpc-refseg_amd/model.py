@@ -14,6 +14,7 @@ backbone.py, replayed from a captured HIP graph) runs on a side stream beside th
 """
 from __future__ import annotations
 
+import ctypes
 import os
 import warnings
 from typing import Dict, Optional
@@ -420,7 +421,7 @@ class LSTM_model(object):
     _SCALARS = ("loss_all", "loss_c3", "loss_c4", "loss_c5", "loss_last", "mIoU")
     MAX_STEPS_IN_FLIGHT = int(os.environ.get("CMPC_STEPS_IN_FLIGHT", "2"))
 
-    def train_step(self, words, im, target_fine, seq_len, ready=None, next_im=None, next_ready=None):
+    def train_step(self, words, im, target_fine, seq_len, ready=None, next_im=None, next_ready=None, next_gate="fwd"):
         """sess.run([train, train_step, merged], feed) (trainval_model.py:98-107).
         ready: optional torch.cuda.Event recorded once the (device-resident, prefetched) feeds were complete.
         next_im: the NEXT step's image batch, already resident on the device (a prefetching loader has it: util/data_reader_refvos.py:38-46),
@@ -446,12 +447,21 @@ class LSTM_model(object):
             else:
                 feats, ev = self.features_async(imd, ready)
             between = None
-            if next_im is not None and torch.is_tensor(next_im) and next_im.is_cuda and self.bb_stream is not None:
+            pre = next_im is not None and torch.is_tensor(next_im) and next_im.is_cuda and self.bb_stream is not None
+            if pre and next_gate == "fwd":
                 def between(levels_done, nxt=next_im, nready=next_ready):
                     self.bb_stream.wait_event(levels_done)
                     f2, e2 = self.features_async(nxt, nready if nready is not None else levels_done)
                     self._prefetched = (nxt, f2, e2)
+            if pre and next_gate == "bwd" and getattr(self, "_bwd_levels", None) is None:
+                self._bwd_levels = torch.cuda.Event()
+                self._bwd_levels.record()
+                _lib.call("cmpc_set_bwd_levels_event", self.eng.h, ctypes.c_void_p(self._bwd_levels.cuda_event))
             self.loss_and_grads(feats, words, target_fine, seq_len, after=ev, im=imd, between=between)
+            if pre and next_gate == "bwd":          # behind the levels' backward: beside the grouped dW launch and the text encoder's backward
+                self.bb_stream.wait_event(self._bwd_levels)
+                f2, e2 = self.features_async(next_im, next_ready if next_ready is not None else self._bwd_levels)
+                self._prefetched = (next_im, f2, e2)
             sv = self.eng.tap("scalars").clone()
             # Optimizer, bucket by bucket in the order the backward pass finalises them (exchange modules + ConvLSTM, levels c5 / c4 /
             # c3, text encoder): every bucket's Adam + repack waits on the device for that bucket only, so all but the last run

@@ -436,6 +436,8 @@ int cmpc_forward(cmpc_handle h, const cmpc_feeds* feeds, const cmpc_fetches* fet
 /* tf.gradients(cost) of the last cmpc_forward (which must have had target_fine) into the flat gradient buffer:
  * d cls_loss_all / d theta; the L2 term (:433,446) and the x2 on biases (:462-475) are applied by the optimizer. */
 int cmpc_backward(cmpc_handle h, void* stream);
+/* event (hipEvent_t, caller-owned; NULL = none) that every later cmpc_backward records once the pyramid levels' backward is complete */
+int cmpc_set_bwd_levels_event(cmpc_handle h, void* event);
 /* Gradient buckets for a data-parallel caller (one process per GPU; the reference has no distributed code).  The flat
  * gradient buffer becomes final in cmpc_grad_bucket_count() pieces, in this order, while cmpc_backward is still running:
  * the exchange modules + ConvLSTM + final score, the pyramid levels c5, c4, c3, the text encoder + parser.  Bucket b covers
