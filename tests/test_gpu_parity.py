@@ -511,6 +511,42 @@ def test_edge_cases_min_length_and_padding():
     assert abs(float(o["loss_all"].detach()) - scal["loss_all"]) <= 1e-5 * abs(scal["loss_all"])
 
 
+@pytest.mark.parametrize("B,T,h,w,C,M", [(1, 1, 5, 5, 24, 16), (5, 9, 7, 7, 72, 40), (2, 24, 6, 9, 40, 24), (3, 33, 4, 11, 136, 72)])
+def test_odd_shapes_match_oracle(B, T, h, w, C, M):
+    """Shapes nothing else exercises: batch 1 with a one-word sentence, an odd node count (7 x 7), a non-square map (6 x 9, 4 x 11), channel
+    counts that are not multiples of 64 / 8, T at and beyond the streaming low-rank kernel's limit (24, 33): every tap, the losses and every
+    gradient in fp32 against the oracle."""
+    cfg = O.Cfg(batch_size=B, num_steps=T, vf_h=h, vf_w=w, H=h * 8, W=w * 8, vf_dim=256, c4_dim=128, c3_dim=64, vocab_size=50, v_emb_dim=C, mlp_dim=M,
+                rnn_size=C, glove_dim=12, parse_dim=20, backbone_width=8, backbone_blocks=(1, 1, 2, 1))
+    hp, bp = O.init_head_params(cfg), O.init_backbone_params(cfg)
+    words, im, sl, tgt = O.synth_batch(cfg, seed=B + T)
+    feats = O.backbone_forward(bp, im, cfg)
+    scal, grads, taps = O.grads_of(hp, feats, words, sl, tgt, cfg)
+    P = U.pkg()
+    m = P.LSTM_model(head_params=hp, backbone_params=bp, **U.model_kwargs(cfg, "f32"))
+    o = m.loss_and_grads([f.to(m.device) for f in feats], words, tgt, sl)
+    torch.cuda.synchronize()
+    pt = U.product_taps_as_oracle(o, cfg)
+    for k in taps:
+        if k in pt:
+            assert U.rel_err(pt[k], taps[k]) < 3e-5, k
+    assert abs(float(o["loss_all"].detach()) - scal["loss_all"]) <= 2e-5 * abs(scal["loss_all"])
+    g = m.store.grad_dict()
+    flags = {k: f for k, _, _, f in O.head_param_specs(cfg)}
+    for n in grads:
+        ref = grads[n] / (2.0 if "x2" in flags[n] else 1.0)
+        if "reg" in flags[n]:
+            ref = ref - cfg.weight_decay * hp[n]
+        if ("spa_graph_key" in n and n.endswith("biases")):
+            continue                                   # exact gradient 0 (softmax over the nodes is invariant to a constant logit)
+        if float(ref.abs().max()) < 1e-7:              # structurally zero here (e.g. T = 1: the softmax over the words is constant): noise on both sides
+            assert float(g[n].abs().max()) < 1e-6, n
+            continue
+        # the text encoder's gradients pass through T steps of back-propagation in fp32 on both sides: their rounding noise grows with T
+        tol = 3e-3 if ((("spa_graph_trans2" in n) and n.endswith("biases")) or n == "text_objseg/Variable" or "lstm" in n.lower()) else 5e-4
+        assert U.rel_err(g[n], ref) < tol, (n, U.rel_err(g[n], ref))
+
+
 def test_full_size_properties():
     """B=2 at the real sizes (320x320, C=1000, M=500, T=20): size-independent invariants of the path."""
     P = U.pkg()
