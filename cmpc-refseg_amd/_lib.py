@@ -209,6 +209,7 @@ SIGNATURES = {
     "cmpc_forward": [_P, C.POINTER(Feeds), C.POINTER(Fetches), _P],
     "cmpc_backward": [_P, _P],
     "cmpc_set_bwd_levels_event": [_P, _P],
+    "cmpc_debug_check_guards": [_P],
     "cmpc_optimizer_step": [_P, _F, _P, C.POINTER(C.c_double)],
     "cmpc_optimizer_bucket": [_P, _I, _F, _P, C.POINTER(C.c_double)],
     "cmpc_tap": [_P, C.c_char_p, _PP, C.POINTER(_I), C.POINTER(_I), C.POINTER(_L * 4)],

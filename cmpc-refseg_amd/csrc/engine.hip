@@ -203,9 +203,17 @@ struct GemmOpt {
 struct Seg { const void* A; int lda; const void* Bt; int ldb; int K; int64_t sA = 0; int64_t sB = 0; };
 
 // bump allocator: first pass (base == nullptr) measures, second pass assigns
+// CMPC_WS_GUARD=<bytes> (debugging): every allocation is followed by a guard of that many bytes that nothing may write; cmpc_debug_check_guards
+// reports the allocations whose guard is no longer zero (an out-of-bounds write of the kernel that owns the buffer in front of it)
+static size_t g_ws_guard = getenv("CMPC_WS_GUARD") ? (size_t)atol(getenv("CMPC_WS_GUARD")) : 0;
 struct Bump {
     char* base = nullptr; size_t off = 0;
-    void* take(size_t bytes) { void* p = base ? base + off : nullptr; off += up256(bytes); return p; }
+    std::vector<std::pair<char*, size_t>>* log = nullptr;      // (guard address, size of the allocation in front of it)
+    void* take(size_t bytes) {
+        void* p = base ? base + off : nullptr; off += up256(bytes);
+        if (g_ws_guard) { if (base && log) log->push_back({base + off, bytes}); off += up256(g_ws_guard); }
+        return p;
+    }
 };
 
 struct LevelBuf {          // one pyramid level (c5 / c4 / c3), forward then backward
@@ -273,6 +281,7 @@ struct cmpc_engine_s {
     hipStream_t own_lane[3] = {nullptr, nullptr, nullptr};   // the streams this handle created
     std::vector<hipEvent_t> evpool; size_t evnext = 0;
     hipEvent_t ev_opt0 = nullptr, ev_opt1 = nullptr; bool opt_pending = false;
+    std::vector<std::pair<char*, size_t>> guards;
     hipEvent_t user_bwd_levels = nullptr;     // caller's event, recorded when the levels' backward is complete (cmpc_set_bwd_levels_event)
     // buffers
     void* spatial = nullptr;
@@ -2129,6 +2138,7 @@ extern "C" int cmpc_create(const cmpc_cfg* c, cmpc_handle* out) {
         e->zf_bytes = zf.off; e->zb_bytes = zb.off; e->ws_bytes = zf.off + zb.off + g.off;
         ECK(hipMalloc(&e->ws, e->ws_bytes)); ECK(hipMemset(e->ws, 0, e->ws_bytes));
         Bump zf2, zb2, g2; zf2.base = e->ws; zb2.base = e->ws + e->zf_bytes; g2.base = e->ws + e->zf_bytes + e->zb_bytes;
+        zf2.log = zb2.log = g2.log = &e->guards;
         plan_workspace(e, zf2, zb2, g2);
     }
     {   // spatial grid [B*N, 64]: generate_spatial_batch (util/processing_tools.py:5-17), float64 arithmetic, float32 values
@@ -2541,6 +2551,21 @@ static double host_now() { return std::chrono::duration<double, std::milli>(std:
 #define HOSTPROF(tag) do { if (hp) { const double t_ = host_now(); fprintf(stderr, "[host] %-14s %7.3f ms\n", tag, t_ - hp_t); hp_t = t_; } } while (0)
 // event (hipEvent_t, caller-owned; NULL = none) that every later cmpc_backward records once the pyramid levels' backward is complete: what
 // follows is the grouped weight-gradient launch of the levels beside the text encoder's backward (room for independent work of the caller)
+extern "C" int cmpc_debug_check_guards(cmpc_handle e) {
+    if (!e) return -1;
+    (void)hipDeviceSynchronize();
+    int bad = 0;
+    std::vector<unsigned char> buf(g_ws_guard);
+    for (size_t i = 0; i < e->guards.size(); ++i) {
+        if (hipMemcpy(buf.data(), e->guards[i].first, g_ws_guard, hipMemcpyDeviceToHost) != hipSuccess) return -1;
+        for (size_t k = 0; k < g_ws_guard; ++k)
+            if (buf[k]) { fprintf(stderr, "[guard] allocation #%zu (%zu bytes, ws offset %zu): byte +%zu past its end is 0x%02x\n", i, e->guards[i].second,
+                                  (size_t)(e->guards[i].first - e->ws) - ((e->guards[i].second + 255) / 256 * 256), k + ((e->guards[i].second + 255) / 256 * 256 - e->guards[i].second), buf[k]); ++bad; break; }
+    }
+    fprintf(stderr, "[guard] %zu allocations checked, %d violated\n", e->guards.size(), bad);
+    return bad;
+}
+
 extern "C" int cmpc_set_bwd_levels_event(cmpc_handle e, void* event) {
     if (!e) { cmpc_set_error("set_bwd_levels_event: null handle"); return CMPC_EINVAL; }
     e->user_bwd_levels = (hipEvent_t)event;

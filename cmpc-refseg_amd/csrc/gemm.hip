@@ -1145,10 +1145,10 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_grouped_kernel(const TnGroupDe
     // gave the slots that drew a long item in the first round another one in the second (620 tiles of 200 steps on 512 slots: 400 steps on
     // slots 0..107 against an average of 242).  Which workgroup computes an item does not matter for the result: one writer per output / slab.
     __shared__ int s_item;
-    for (;;) {
-        if (threadIdx.x == 0) s_item = atomicAdd(next_item, 1);
+    for (int w_static = blockIdx.x;; w_static += gridDim.x) {
+        if (next_item && threadIdx.x == 0) s_item = atomicAdd(next_item, 1);
         __syncthreads();
-        const int w = s_item;
+        const int w = next_item ? s_item : w_static;          // next_item == NULL: the static deal s, s + grid, ... (A/B switch CMPC_TN_STATIC)
         __syncthreads();
         if (w >= total) break;
         int lo = 0, hi = ndesc;                       // uniform binary search: scalar loads
@@ -1650,8 +1650,9 @@ int cmpc_gemm_tn_grouped_cached(const void* args_, int n, void* const* tables_de
         }
         if (shadow) shadow->assign((const char*)sorted.data(), (const char*)sorted.data() + bytes);
     }
-    int* next_item = (int*)scratch;                 // the launch's item counter: first bytes of its scratch block
-    if (hipMemsetAsync(next_item, 0, sizeof(int), st) != hipSuccess) { cmpc_set_error("gemm_tn_grouped: memset"); return CMPC_EHIP; }
+    static const bool static_deal = getenv("CMPC_TN_STATIC") != nullptr;
+    int* next_item = static_deal ? nullptr : (int*)scratch;                 // the launch's item counter: first bytes of its scratch block
+    if (next_item && hipMemsetAsync(next_item, 0, sizeof(int), st) != hipSuccess) { cmpc_set_error("gemm_tn_grouped: memset"); return CMPC_EHIP; }
     hipLaunchKernelGGL(gemm_tn_grouped_kernel, dim3(std::min(items, slots)), dim3(256), 2 * 2 * TnCfg<bf16_t>::BR * 128 * 2, st, table, m, items, next_item);
     if (cmpc_check_launch("gemm_tn_grouped") != CMPC_OK) return CMPC_EHIP;
     // fixed-order sums of the slabs into the outputs (recorded into the caller's deferred-fold list when one is active and the

@@ -438,6 +438,8 @@ int cmpc_forward(cmpc_handle h, const cmpc_feeds* feeds, const cmpc_fetches* fet
 int cmpc_backward(cmpc_handle h, void* stream);
 /* event (hipEvent_t, caller-owned; NULL = none) that every later cmpc_backward records once the pyramid levels' backward is complete */
 int cmpc_set_bwd_levels_event(cmpc_handle h, void* event);
+/* debugging (CMPC_WS_GUARD=<bytes> at create): number of workspace allocations whose trailing guard was written; details on stderr */
+int cmpc_debug_check_guards(cmpc_handle h);
 /* Gradient buckets for a data-parallel caller (one process per GPU; the reference has no distributed code).  The flat
  * gradient buffer becomes final in cmpc_grad_bucket_count() pieces, in this order, while cmpc_backward is still running:
  * the exchange modules + ConvLSTM + final score, the pyramid levels c5, c4, c3, the text encoder + parser.  Bucket b covers
