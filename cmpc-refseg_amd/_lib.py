@@ -104,7 +104,7 @@ class EngineCfg(C.Structure):
         ("weight_decay", C.c_float), ("loss_w", C.c_float * 4),
         ("dtype", C.c_int), ("loss_scale", C.c_float), ("n_lanes", C.c_int), ("device", C.c_int),
         ("model", C.c_int), ("hsv", C.c_int), ("bn_train", C.c_int), ("bn_decay", C.c_float),
-        ("c2_dim", C.c_int), ("c2_h", C.c_int), ("c2_w", C.c_int), ("aspp_depth", C.c_int), ("low_dim", C.c_int), ("aspp_rates", C.c_int * 3), ("sample_frames", C.c_int), ("conv5", C.c_int),
+        ("c2_dim", C.c_int), ("c2_h", C.c_int), ("c2_w", C.c_int), ("aspp_depth", C.c_int), ("low_dim", C.c_int), ("aspp_rates", C.c_int * 3), ("sample_frames", C.c_int), ("freeze_bn", C.c_int), ("conv5", C.c_int),
     ]
 
 

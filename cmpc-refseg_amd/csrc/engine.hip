@@ -635,8 +635,12 @@ int upload_tables(E* e) {
     HCK(hipMalloc(&e->tile_desc_dev, sizeof(int) * tdesc.size()));
     HCK(hipMemcpy(e->tile_desc_dev, tdesc.data(), sizeof(int) * tdesc.size(), hipMemcpyHostToDevice));
     std::vector<cmpc_adam_seg> segs;                       // <= 8192 elements each, inside one parameter
-    for (const ParamSpec& s : e->specs)
-        for (int64_t o = 0; o < s.count; o += 8192) segs.push_back(cmpc_adam_seg{s.off + o, (int)std::min<int64_t>(8192, s.count - o), s.wd, s.gmult});
+    for (const ParamSpec& s : e->specs) {
+        // freeze_bn (v5:528-529): 'beta' / 'gamma' variables are not in the optimizer's list -> zero gradient, zero moments, no update
+        const bool frozen = e->cfg.freeze_bn && (s.name.find("beta") != std::string::npos || s.name.find("gamma") != std::string::npos);
+        for (int64_t o = 0; o < s.count; o += 8192)
+            segs.push_back(cmpc_adam_seg{s.off + o, (int)std::min<int64_t>(8192, s.count - o), frozen ? 0.f : s.wd, frozen ? 0.f : s.gmult});
+    }
     e->nseg = (int)segs.size();
     e->segs_host = segs; e->tile_prefix_host = pref;
     HCK(hipMalloc(&e->segs_dev, sizeof(cmpc_adam_seg) * segs.size()));
@@ -2011,7 +2015,7 @@ extern "C" int cmpc_default_cfg(cmpc_cfg* c) {
 extern "C" int cmpc_default_cfg_model(cmpc_cfg* c, int model, int hsv) {
     if (!c || (model != CMPC_MODEL_CMPC && model != CMPC_MODEL_V5_BILSTM && model != CMPC_MODEL_VIDEO)) { cmpc_set_error("default_cfg_model: bad argument"); return CMPC_EINVAL; }
     c->sample_frames = 5;                             // CMPC_video_mm_tgraph_allvec.py:69
-    c->conv5 = 0;
+    c->conv5 = 0; c->freeze_bn = 0;
     c->model = model; c->hsv = (model == CMPC_MODEL_V5_BILSTM && hsv) ? 1 : 0;
     c->bn_decay = 0.9997f; c->c2_dim = 256; c->c2_h = c->H / 4; c->c2_w = c->W / 4; c->aspp_depth = 256; c->low_dim = 48;
     c->aspp_rates[0] = 6; c->aspp_rates[1] = 12; c->aspp_rates[2] = 18;

@@ -53,6 +53,7 @@ class Engine:
         if cfg.model == _lib.MODEL_VIDEO:
             c.sample_frames = int(cfg.sample_frames)
         c.conv5 = int(getattr(cfg, "conv5", 0))
+        c.freeze_bn = int(getattr(cfg, "freeze_bn", 0))
         if loss_w is not None:
             for i, w in enumerate(loss_w):
                 c.loss_w[i] = w

@@ -75,8 +75,13 @@ class LSTM_model(object):
         if self.video and (batch_size != 1 or frames <= max(FRAME_IDX) or finetune):
             raise ValueError("CMPC_video_mm_tgraph_allvec: the graph is only valid for batch_size = 1 (vid:323-324,379), needs frames > 15 "
                              "(sample indices 0, 4, 8, 12, 15; vid:70); finetune=True (backbone training) is not built")
-        if freeze_bn or is_aug:
-            raise NotImplementedError("freeze_bn / is_aug (CMPCv5_BiLSTM_model.py:83-84,528-529) are not built")
+        if (freeze_bn or is_aug) and not self.v5:
+            freeze_bn = is_aug = False                 # CMPC_model never accepted them (trainval_model.py:40 passes them to every model)
+        # is_aug (v5:83-84): tf.image.random_brightness(im, 0.2, seed=42) in train mode -- ONE uniform delta in [-0.2, 0.2) per step, added to
+        # the whole image batch.  TensorFlow's random stream cannot be reproduced without TensorFlow: a seeded NumPy generator stands in
+        # (same distribution, same determinism; parity-unpinned)
+        self.is_aug = bool(is_aug) and mode == 'train'
+        self._aug_rng = np.random.default_rng(42)
         if dtype == "bf16":
             # diagnostic mode: same kernels and rate as f16, but 8-bit significands miss BASELINE's 1e-4 mean-IoU bar on some inputs
             # (measured up to 1.6e-4).  The default, f16 storage, meets it.
@@ -96,7 +101,7 @@ class LSTM_model(object):
                            lr_decay_step=lr_decay_step, weight_decay=weight_decay,
                            model=model_id, hsv=hsv, bn_train=int(self.v5 and mode == 'train'), bn_decay=batch_norm_decay,
                            c2_dim=4 * backbone_width, c2_h=-(-H // 4), c2_w=-(-W // 4), aspp_depth=aspp_depth, low_dim=low_dim,
-                           aspp_rates=tuple(aspp_rates), sample_frames=len(FRAME_IDX), conv5=int(self.conv5))
+                           aspp_rates=tuple(aspp_rates), sample_frames=len(FRAME_IDX), conv5=int(self.conv5), freeze_bn=int(bool(freeze_bn)))
         for name, v in (("vf_dim", vf_dim), ("c4_dim", c4_dim), ("c3_dim", c3_dim)):
             if v % 64:
                 raise ValueError(f"{name}={v} must be a multiple of 64 (MFMA K tile)")
@@ -439,6 +444,9 @@ class LSTM_model(object):
             if not torch.is_tensor(im):
                 ready = None                    # host feeds: the copy below is ordered on the caller's stream, which the backbone then waits for
             imd = self._dev(im, torch.float32)
+            if self.is_aug:                       # v5:83-84: the augmented image replaces self.im for the backbone AND the HSV branch
+                imd = imd + float(self._aug_rng.uniform(-0.2, 0.2))
+                im = imd
             if self.bb_trainer is not None:
                 return self._train_step_conv5(words, imd, target_fine, seq_len)
             pf, self._prefetched = self._prefetched, None

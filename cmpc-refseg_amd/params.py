@@ -68,6 +68,7 @@ class HeadCfg:
     low_dim: int = 48
     aspp_rates: tuple = (6, 12, 18)
     sample_frames: int = 5      # CMPC_video_mm_tgraph_allvec.py:69
+    freeze_bn: int = 0          # CMPCv5_BiLSTM_model.py:528-529
     conv5: int = 0              # CMPC_model.py:427-430: res3-res5 convolution weights trained (the handle then also returns d cost / d taps)
 
     @property

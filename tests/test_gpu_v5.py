@@ -289,3 +289,40 @@ def test_config4_f16_mean_iou_delta_over_seeds():
     print("config 4 f16 dIoU over 6 seeds:", ["%.2e" % d for d in deltas], "max %.2e mean %.2e" % (max(deltas), sum(deltas) / len(deltas)))
     assert max(deltas) <= 1e-4
 
+
+
+def test_freeze_bn_and_is_aug():
+    """The two options the driver passes to the CMPCv5 models (trainval_model.py:40).  freeze_bn (v5:528-529): every variable whose name contains
+    'beta' or 'gamma' -- batch-norm AND layer-norm -- stays untouched by a train step, every other parameter moves exactly as without the
+    option.  is_aug (v5:83-84): one uniform brightness delta in [-0.2, 0.2) per train step on the whole batch (seeded; TensorFlow's own random
+    stream is not reproducible here: parity-unpinned), none in eval mode."""
+    case = make_case(hsv=False)
+    cfg = case["cfg"]
+    P = U.pkg()
+    kw = model_kwargs(cfg, "f32", "train")
+    outs = {}
+    for fz in (False, True):
+        m = P.get_segmentation_model(_name(cfg), head_params=case["hp"], backbone_params=case["bp"], freeze_bn=fz, **kw)
+        m.train_step(case["words"], case["im"], case["tgt"], case["sl"])
+        torch.cuda.synchronize()
+        outs[fz] = m.state_dict()
+    frozen = [n for n in outs[True] if "beta" in n or "gamma" in n]
+    assert len(frozen) >= 20 and any("BatchNorm" in n for n in frozen) and any("_ln_" in n for n in frozen)
+    for n in outs[True]:
+        if n in frozen:
+            assert torch.equal(outs[True][n], case["hp"][n].float()), n
+            assert not torch.equal(outs[False][n], case["hp"][n].float()) or float(case["hp"][n].abs().max()) == 0, n
+        else:
+            assert torch.equal(outs[True][n], outs[False][n]), n
+    # is_aug: the delta sequence is the seeded generator's, the loss differs from the un-augmented step's, eval mode draws nothing
+    import numpy as np
+    m0 = P.get_segmentation_model(_name(cfg), head_params=case["hp"], backbone_params=case["bp"], **kw)
+    m1 = P.get_segmentation_model(_name(cfg), head_params=case["hp"], backbone_params=case["bp"], is_aug=True, **kw)
+    l0 = float(m0.train_step(case["words"], case["im"], case["tgt"], case["sl"])[1]["loss_all"])
+    l1 = float(m1.train_step(case["words"], case["im"], case["tgt"], case["sl"])[1]["loss_all"])
+    d = float(np.random.default_rng(42).uniform(-0.2, 0.2))
+    m2 = P.get_segmentation_model(_name(cfg), head_params=case["hp"], backbone_params=case["bp"], **kw)
+    l2 = float(m2.train_step(case["words"], torch.as_tensor(case["im"]) + d, case["tgt"], case["sl"])[1]["loss_all"])
+    assert l1 == l2 and l1 != l0
+    me = P.get_segmentation_model(_name(cfg), head_params=case["hp"], backbone_params=case["bp"], is_aug=True, **dict(kw, mode="eval"))
+    assert me.is_aug is False
