@@ -1666,6 +1666,10 @@ int level_bwd_video(E* e, hipStream_t st, int li, const float* target) {
     CK(add_n(st, dt, (char*)L.dX0 + (size_t)(Fr / 2) * N * Cp * es, {L.dX0f}, true, (long)N * Cp));
     CK(cmpc_l2norm_rows_bwd(dt, L.dX0, L.X0, L.lat_rstd, L.dV, RF, Cp, C, 0, st));
     CK(colsum(st, dt, L.dV, RF, Cp, Cp, C, gptr(e, fmt("%s_lateral/biases", lv))));
+    if (e->cfg.conv5) {      // finetune=True (vid:554-557): the tap's own gradient, for the caller's backbone backward
+        GemmOpt o; o.n_valid = L.cin;
+        CK(gemm_nt(st, dt, {{L.dV, Cp, opp(e, fmt("lat_%s.n", lv)), Cp, Cp}}, L.dfeat, L.cin, RF, L.cin, o));
+    }
     return gemm_tn(e, st, dt, L.feat, L.cin, L.cin, L.dV, Cp, Cp, gptr(e, fmt("%s_lateral/DW", lv)), C, RF, L.cin, C, OFF0, d);
 }
 
@@ -2056,7 +2060,6 @@ extern "C" int cmpc_create(const cmpc_cfg* c, cmpc_handle* out) {
     }
     if (pad64(c->v_emb_dim) > 2048 || pad64(c->mlp_dim) > 2048) { cmpc_set_error("create: v_emb_dim, mlp_dim <= 2048 (per-column registers of the map kernels)"); return CMPC_EINVAL; }
     if (c->n_lanes < 1 || c->n_lanes > 3) { cmpc_set_error("create: n_lanes must be 1, 2 or 3"); return CMPC_EINVAL; }
-    if (c->conv5 && c->model != CMPC_MODEL_CMPC) { cmpc_set_error("create: conv5 (backbone tap gradients) is CMPC_model's option (CMPC_model.py:427-430)"); return CMPC_EINVAL; }
     if (c->model != CMPC_MODEL_CMPC && c->model != CMPC_MODEL_V5_BILSTM && c->model != CMPC_MODEL_VIDEO) {
         cmpc_set_error("create: model must be CMPC_MODEL_CMPC (0), CMPC_MODEL_V5_BILSTM (1) or CMPC_MODEL_VIDEO (2)"); return CMPC_EINVAL;
     }

@@ -60,7 +60,7 @@ class LSTM_model(object):
         # (freeze_bn, is_aug: trainval_model.py:40).
         if optimizer != 'adam':
             raise ValueError("Unknown optimizer type %s!" % optimizer)          # CMPC_model.py:458
-        self.conv5 = bool(conv5)
+        self.conv5 = bool(conv5) or bool(finetune)        # the video model calls the same option `finetune` (vid:33,554-557)
         if keep_prob_rnn != 1.0 or keep_prob_emb != 1.0 or keep_prob_mlp != 1.0 or num_rnn_layers != 1:
             raise NotImplementedError("dropout / stacked LSTM are unused by the reference graph")
         if dtype not in ("bf16", "f16", "f32"):
@@ -72,9 +72,9 @@ class LSTM_model(object):
         self.v5 = model_id == _lib.MODEL_V5_BILSTM
         self.video = model_id == _lib.MODEL_VIDEO
         self.frames = frames
-        if self.video and (batch_size != 1 or frames <= max(FRAME_IDX) or finetune):
-            raise ValueError("CMPC_video_mm_tgraph_allvec: the graph is only valid for batch_size = 1 (vid:323-324,379), needs frames > 15 "
-                             "(sample indices 0, 4, 8, 12, 15; vid:70); finetune=True (backbone training) is not built")
+        if self.video and (batch_size != 1 or frames <= max(FRAME_IDX)):
+            raise ValueError("CMPC_video_mm_tgraph_allvec: the graph is only valid for batch_size = 1 (vid:323-324,379) and needs frames > 15 "
+                             "(sample indices 0, 4, 8, 12, 15; vid:70)")
         if (freeze_bn or is_aug) and not self.v5:
             freeze_bn = is_aug = False                 # CMPC_model never accepted them (trainval_model.py:40 passes them to every model)
         # is_aug (v5:83-84): tf.image.random_brightness(im, 0.2, seed=42) in train mode -- ONE uniform delta in [-0.2, 0.2) per step, added to
@@ -133,8 +133,6 @@ class LSTM_model(object):
             self.bb_trainer = None
             if self.conv5:
                 # conv5=True (CMPC_model.py:427-430): the res3 / res4 / res5 convolution weights train with the head
-                if self.v5 or self.video:
-                    raise NotImplementedError("conv5=True is CMPC_model's option (CMPC_model.py:427-430)")
                 from .backbone_train import BackboneTrainer
                 self.bb_trainer = BackboneTrainer(self.backbone, self._backbone_vars, self.device, weight_decay)
         self.world, self.dp_on = 1, False
@@ -388,6 +386,8 @@ class LSTM_model(object):
             if len(self._inflight) >= self.MAX_STEPS_IN_FLIGHT:
                 self._inflight.pop(0).synchronize()
             we, sl, fr = self._video_feeds(words, valid_idx, clip)
+            if self.bb_trainer is not None:
+                return self._train_step_conv5(we, fr, target_fine, sl)
             feats, ev = self.features_async(fr)
             self.loss_and_grads(feats, we, target_fine, sl, after=ev)
             sv = self.eng.tap("scalars").clone()
@@ -495,16 +495,20 @@ class LSTM_model(object):
         return self.eng.step, scal
 
     def _train_step_conv5(self, words, imd, target_fine, seq_len):
-        """conv5=True (CMPC_model.py:427-430): backbone forward with its activations kept, head forward / backward (which also returns
-        d cost / d c5, c4, c3), backbone backward, one TF-Adam step over the head and the res3-res5 convolution weights.  Everything on the
-        caller's stream (no side streams: the optional mode is not the benchmarked one)."""
+        """conv5=True (CMPC_model.py:427-430, v5:521-525; finetune=True of the video model, vid:554-557): backbone forward with its
+        activations kept, head forward / backward (which also returns d cost / d taps), backbone backward, one TF-Adam step over the head and
+        the res3-res5 convolution weights.  Everything on the caller's stream (no side streams: the optional mode is not the benchmarked
+        one).  imd: the image batch -- for the video model the 5 sampled frames."""
         if self.dp_on:
             raise NotImplementedError("conv5=True with data-parallel training: the backbone gradients are not exchanged")
-        B, h, w = self.batch_size, self.cfg.vf_h, self.cfg.vf_w
+        h, w = self.cfg.vf_h, self.cfg.vf_w
+        nb = imd.shape[0]
         feats = self.bb_trainer.forward(imd)
-        self.loss_and_grads(feats, words, target_fine, seq_len, im=imd)
+        self.loss_and_grads(feats, words, target_fine, seq_len, im=imd if (self.v5 and self.cfg.hsv) else None)
         sv = self.eng.tap("scalars").clone()
-        dt = {5: self.eng.tap("dc5").view(B, h, w, -1), 4: self.eng.tap("dc4").view(B, h, w, -1), 3: self.eng.tap("dc3").view(B, h, w, -1)}
+        dt = {5: self.eng.tap("dc5").view(nb, h, w, -1), 4: self.eng.tap("dc4").view(nb, h, w, -1)}
+        if not self.v5:
+            dt[3] = self.eng.tap("dc3").view(nb, h, w, -1)
         self.bb_trainer.backward(dt)
         step0 = self.eng.step
         for b in range(self.eng.n_buckets):

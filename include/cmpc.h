@@ -369,7 +369,8 @@ typedef struct {
     int sample_frames;                  /* model VIDEO: frames of the clip that go through the graph (5: indices 0, 4, 8, 12, 15 of 16; CMPC_video_mm_tgraph_allvec.py:69-70) */
     int freeze_bn;                      /* model V5_BILSTM: freeze_bn=True (v5:528-529): variables whose name contains 'beta' or 'gamma' (batch-norm AND layer-norm
                                            scales / offsets) are left out of the optimizer's variable list: their Adam segments get a zero gradient multiplier */
-    int conv5;                          /* model CMPC: conv5=True (CMPC_model.py:427-430: res3 / res4 / res5 convolution weights are trained too): cmpc_backward also
+    int conv5;                          /* conv5=True (CMPC_model.py:427-430, v5:521-525; the video model's finetune=True, vid:554-557: res3 / res4 / res5 convolution
+                                           weights are trained too): cmpc_backward also
                                            produces the gradients of the three backbone taps, d cost / d c5, c4, c3 (taps "dc5", "dc4", "dc3": [B*N, cin], cfg.dtype),
                                            which the caller's backbone backward consumes; 0 = the backbone is frozen and no such gradient is formed */
 } cmpc_cfg;

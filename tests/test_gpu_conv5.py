@@ -114,3 +114,83 @@ def test_conv5_full_size_f16_steps():
     moved = [n for n in before if not torch.equal(torch.as_tensor(after[n]), before[n])]
     assert sorted(moved) == sorted(n for n in before if n.startswith(("res3", "res4", "res5")))
     assert len(moved) == 3 * 30 + 3            # 30 bottlenecks x (2a, 2b, 2c) + one branch1 per stage
+
+
+def _backbone_grad_check(m, gb, bp, wd, tol=3e-4):
+    tr = m.bb_trainer
+    assert sorted(L["name"] for L in tr.layers) == sorted(gb)
+    worst = ("", 0.0)
+    for L in tr.layers:
+        g = tr.view(tr.grads, L).cpu() / m.eng.loss_scale
+        ref = gb[L["name"]] - wd * bp[L["name"]]
+        err = U.rel_err(g, ref)
+        worst = max(worst, (L["name"], err), key=lambda kv: kv[1])
+        if err >= tol:
+            print("  backbone gradient", L["name"], "error %.2e" % err)
+    assert worst[1] < tol, worst
+    return worst
+
+
+def test_conv5_v5_model_gradients_fp32():
+    """conv5=True of the CMPCv5_BiLSTM graph (v5:521-525): taps res2b (frozen side), res4b22, res5c; tanh laterals with the HSV K-segment."""
+    import tests.test_gpu_v5 as T5
+    from oracle import cmpc_v5_torch as V
+    torch.set_num_threads(8)
+    cfg = V.Cfg(batch_size=4, num_steps=6, vf_h=8, vf_w=8, H=64, W=64, vf_dim=1024, c4_dim=512, c3_dim=256, vocab_size=50, v_emb_dim=40, mlp_dim=24,
+                rnn_size=40, glove_dim=12, parse_dim=20, backbone_width=32, backbone_blocks=(2, 1, 2, 1), hsv=True, aspp_depth=16, low_dim=8,
+                aspp_rates=(1, 3, 6), train_mode=True)
+    hp, bp, bn = V.init_head_params(cfg), V.init_backbone_params(cfg), V.init_bn_state(cfg)
+    words, im, sl, tgt = O.synth_batch(cfg, seed=3)
+    im_t = torch.as_tensor(im)
+    names_b = O.conv5_trainable(bp)
+    # the oracle in float64: the image-level batch-norm of the ASPP (moments over the B samples of a 1x1 map) is ill-conditioned at small B and
+    # every backbone gradient passes through it -- fp32 autograd differs from itself by percents there (tests/test_gpu_v5.py has the same note)
+    D = lambda d: {k: v.double() for k, v in d.items()}
+    bl = D(bp)
+    for n in names_b:
+        bl[n] = bl[n].detach().clone().requires_grad_(True)
+    hp64, bn64, im64 = D(hp), D(bn), im_t.double()
+    taps = V.head_forward(hp64, bn64, V.backbone_taps(bl, im64, cfg), words, sl, cfg, im=im64, new_state={})
+    cost = V.losses(hp64, taps, torch.as_tensor(tgt).double(), cfg)["cost"] + cfg.weight_decay * sum(0.5 * (bl[n] ** 2).sum() for n in names_b)
+    gb = {n: g.float() for n, g in zip(names_b, torch.autograd.grad(cost, [bl[n] for n in names_b]))}
+    P = U.pkg()
+    m = P.get_segmentation_model("CMPCv5_BiLSTM_HSV_model", head_params=hp, backbone_params=bp, conv5=True, **T5.model_kwargs(cfg, "f32", "train"))
+    m.load_extra_vars({k: v.numpy() for k, v in bn.items()})
+    imd = im_t.to(m.device)
+    feats = m.bb_trainer.forward(imd)
+    m.loss_and_grads(feats, words, tgt, sl, im=imd)
+    h, w = cfg.vf_h, cfg.vf_w
+    m.bb_trainer.backward({5: m.eng.tap("dc5").view(4, h, w, -1), 4: m.eng.tap("dc4").view(4, h, w, -1)})
+    torch.cuda.synchronize()
+    print("conv5 (CMPCv5_BiLSTM_HSV) worst backbone gradient error:", _backbone_grad_check(m, gb, bp, cfg.weight_decay, tol=2e-3))
+    s, sc = m.train_step(words, im, tgt, sl)
+    assert s == 1 and np.isfinite(float(sc["loss_all"]))
+
+
+def test_finetune_video_model_gradients_fp32():
+    """finetune=True of CMPC_video_mm_tgraph_allvec (vid:554-557): the 5 sampled frames' taps get gradients from the per-frame laterals."""
+    from oracle import cmpc_video_torch as VD
+    torch.set_num_threads(8)
+    cfg = VD.Cfg(batch_size=1, num_steps=6, vf_h=8, vf_w=8, H=64, W=64, vf_dim=1024, c4_dim=512, c3_dim=256, vocab_size=50, v_emb_dim=40, mlp_dim=24,
+                 rnn_size=40, glove_dim=12, parse_dim=20, backbone_width=32, backbone_blocks=(1, 2, 2, 1))
+    hp, bp = VD.init_head_params(cfg), O.init_backbone_params(cfg)
+    words, clip, tgt = VD.synth_clip(cfg, seed=1)
+    vi = torch.tensor([[int((words[0] == 0).sum())]], dtype=torch.int32)
+    names_b = O.conv5_trainable(bp)
+    bl = dict(bp)
+    for n in names_b:
+        bl[n] = bp[n].detach().clone().requires_grad_(True)
+    taps = VD.head_forward(hp, VD.backbone_taps(bl, clip, cfg), words, cfg)
+    cost = VD.losses(hp, taps, tgt, cfg)["cost"] + cfg.weight_decay * sum(0.5 * (bl[n] ** 2).sum() for n in names_b)
+    gb = dict(zip(names_b, torch.autograd.grad(cost, [bl[n] for n in names_b])))
+    P = U.pkg()
+    m = P.get_segmentation_model("CMPC_video_mm_tgraph_allvec", head_params=hp, backbone_params=bp, finetune=True, frames=cfg.frames, **U.model_kwargs(cfg, "f32"))
+    we, sl, fr = m._video_feeds(words, vi, clip)
+    feats = m.bb_trainer.forward(fr)
+    m.loss_and_grads(feats, we, tgt, sl)
+    h, w, Fr = cfg.vf_h, cfg.vf_w, cfg.sample_frames
+    m.bb_trainer.backward({5: m.eng.tap("dc5").view(Fr, h, w, -1), 4: m.eng.tap("dc4").view(Fr, h, w, -1), 3: m.eng.tap("dc3").view(Fr, h, w, -1)})
+    torch.cuda.synchronize()
+    print("finetune (CMPC_video) worst backbone gradient error:", _backbone_grad_check(m, gb, bp, cfg.weight_decay))
+    s, sc = m.train_step_video(words, None, tgt, vi, clip)
+    assert s == 1 and np.isfinite(float(sc["loss_all"]))
