@@ -499,8 +499,6 @@ class LSTM_model(object):
         activations kept, head forward / backward (which also returns d cost / d taps), backbone backward, one TF-Adam step over the head and
         the res3-res5 convolution weights.  Everything on the caller's stream (no side streams: the optional mode is not the benchmarked
         one).  imd: the image batch -- for the video model the 5 sampled frames."""
-        if self.dp_on:
-            raise NotImplementedError("conv5=True with data-parallel training: the backbone gradients are not exchanged")
         h, w = self.cfg.vf_h, self.cfg.vf_w
         nb = imd.shape[0]
         feats = self.bb_trainer.forward(imd)
@@ -511,11 +509,20 @@ class LSTM_model(object):
             dt[3] = self.eng.tap("dc3").view(nb, h, w, -1)
         self.bb_trainer.backward(dt)
         step0 = self.eng.step
+        cur = torch.cuda.current_stream(self.device)
+        gscale = 1.0 / self.world
+        buckets = self.eng.grad_buckets() if self.dp_on else None
         for b in range(self.eng.n_buckets):
-            lr = self.eng.optimizer_bucket(b, 1.0)
+            if self.dp_on:                      # data-parallel: the head's buckets as in train_step, then the backbone's gradient buffer
+                dist.allreduce_bucket_(self.eng, b, buckets[b], self.comm_stream)
+                cur.wait_stream(self.comm_stream)
+            lr = self.eng.optimizer_bucket(b, gscale)
+        if self.dp_on:
+            for o in range(0, self.bb_trainer.total, 16 << 20):
+                torch.distributed.all_reduce(self.bb_trainer.grads[o: o + (16 << 20)])
         t = float(step0 + 1)
         lr_t = lr * (1.0 - 0.999 ** t) ** 0.5 / (1.0 - 0.9 ** t)
-        self.bb_trainer.adam(lr_t, 1.0 / self.eng.loss_scale)
+        self.bb_trainer.adam(lr_t, gscale / self.eng.loss_scale)
         scal = {k: sv[i] for i, k in enumerate(self._SCALARS)}
         scal["mean_IOU"] = scal.pop("mIoU")
         scal["learning_rate"] = lr
@@ -561,6 +568,9 @@ class LSTM_model(object):
                 torch.cuda.synchronize(self.device)
                 dist.broadcast_params_(self.eng.params, 0)
                 self.eng.pack()
+                if getattr(self, "bb_trainer", None) is not None:        # conv5: the trained backbone weights start from rank 0's as well
+                    dist.broadcast_params_(self.bb_trainer.params, 0)
+                    self.bb_trainer.refold()
         return self.world
 
 

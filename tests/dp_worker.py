@@ -24,7 +24,15 @@ def main():
         world, rank, _ = D.init_from_env(backend, device=torch.device("cuda:0"))
         assert D.is_initialized()
     P = U.pkg()
-    if case == "tiny_f32":
+    if case == "conv5_f32":                        # conv5=True: backbone gradients are exchanged too (width-32 backbone: the library's conv path)
+        cfg = O.Cfg(batch_size=2, num_steps=6, vf_h=8, vf_w=8, H=64, W=64, vf_dim=1024, c4_dim=512, c3_dim=256, vocab_size=50, v_emb_dim=40, mlp_dim=24,
+                    rnn_size=40, glove_dim=12, parse_dim=20, backbone_width=32, backbone_blocks=(1, 2, 2, 1))
+        hp, bp = O.init_head_params(cfg, seed=100 + rank), O.init_backbone_params(cfg, seed=4321)
+        for n in O.conv5_trainable(bp):                # same frozen part on every rank (one checkpoint), different TRAINED weights: rank 0's must win
+            bp[n] = bp[n] * (1.0 + 0.05 * rank)
+        m = P.LSTM_model(head_params=hp, backbone_params=bp, conv5=True, **U.model_kwargs(cfg, "f32"))
+        words, im, sl, tgt = O.synth_batch(cfg, seed=rank)
+    elif case == "tiny_f32":
         cfg = U.tiny_cfg()
         hp, bp = O.init_head_params(cfg, seed=100 + rank), O.init_backbone_params(cfg)     # different weights: rank 0's must win
         m = P.LSTM_model(head_params=hp, backbone_params=bp, **U.model_kwargs(cfg, "f32"))
@@ -41,8 +49,10 @@ def main():
         _, scal = m.train_step(words, im, tgt, sl)
         losses.append(float(scal["loss_all"]))
     torch.cuda.synchronize()
-    if case == "tiny_f32":
-        sd = m.state_dict()
+    if case in ("tiny_f32", "conv5_f32"):
+        sd = dict(m.state_dict())
+        if case == "conv5_f32":
+            sd.update({"bb/" + k: v for k, v in m.bb_trainer.named_weights().items()})
         np.savez(out, losses=np.asarray(losses), **{k.replace("/", "|"): v.numpy() for k, v in sd.items()})
     else:
         np.savez(out, losses=np.asarray(losses), params=m.eng.params.cpu().numpy(), nonfinite=m.eng.tap("grad_nonfinite").cpu().numpy())

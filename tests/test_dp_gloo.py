@@ -202,3 +202,46 @@ def test_product_data_parallel_two_ranks_full_size_f16(tmp_path):
             assert abs(scal["loss_all"] - got) <= 1e-2 * abs(scal["loss_all"]), (step, r, scal["loss_all"], got)
         with torch.no_grad():
             opt.step(hp, {n: (gs[0][n] + gs[1][n]) / 2 for n in hp}, O.poly_lr(step, cfg))
+
+
+@pytest.mark.gpu
+def test_conv5_data_parallel_two_ranks_one_gpu(tmp_path):
+    """conv5=True under world_size 2 (gloo, both ranks on the test box's GPU): rank 0's head AND backbone weights are broadcast, the head's
+    buckets and the backbone's gradient buffer are all-reduced, 1/world in both Adam calls.  Replicas bit-identical after 3 steps on
+    different shards and equal to the oracle's emulation (average of the shards' gradients, TF-Adam over head + res3-res5 weights)."""
+    import subprocess
+    import numpy as np
+    port = _free_port()
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(r), WORLD_SIZE="2", LOCAL_RANK="0", HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "dp_worker.py"), str(tmp_path / f"rank{r}.npz"), "gloo", "conv5_f32"], env=env, cwd=ROOT))
+    for p in procs:
+        assert p.wait(timeout=600) == 0
+    a, b = (np.load(tmp_path / f"rank{r}.npz") for r in range(2))
+    for k in a.files:
+        if k != "losses":
+            assert np.array_equal(a[k], b[k]), k
+    sys.path.insert(0, ROOT)
+    from tests.util import O
+    torch.set_num_threads(8)
+    cfg = O.Cfg(batch_size=2, num_steps=6, vf_h=8, vf_w=8, H=64, W=64, vf_dim=1024, c4_dim=512, c3_dim=256, vocab_size=50, v_emb_dim=40, mlp_dim=24,
+                rnn_size=40, glove_dim=12, parse_dim=20, backbone_width=32, backbone_blocks=(1, 2, 2, 1))
+    hp, bp = O.init_head_params(cfg, seed=100), O.init_backbone_params(cfg, seed=4321)
+    names_b = O.conv5_trainable(bp)
+    opt, opt_b = O.TFAdam(hp), O.TFAdam({n: bp[n] for n in names_b})
+    shards = [O.synth_batch(cfg, seed=r) for r in range(2)]
+    for step in range(3):
+        gh, gbb = [], []
+        for r, (words, im, sl, tgt) in enumerate(shards):
+            scal, g1, g2 = O.grads_of_conv5(hp, bp, torch.as_tensor(im), words, sl, tgt, cfg)
+            gh.append(g1); gbb.append(g2)
+            assert abs(scal["loss_all"] - float((a, b)[r]["losses"][step])) <= 3e-4 * abs(scal["loss_all"]), (step, r)
+        with torch.no_grad():
+            lr = O.poly_lr(step, cfg)
+            opt.step(hp, {n: (gh[0][n] + gh[1][n]) / 2 for n in hp}, lr)
+            opt_b.step({n: bp[n] for n in names_b}, {n: (gbb[0][n] + gbb[1][n]) / 2 for n in names_b}, lr)
+    for n in names_b:
+        d = np.abs(a["bb|" + n.replace("/", "|")] - bp[n].numpy()).reshape(-1)
+        assert np.quantile(d[:200000], 0.99) <= 0.6 * cfg.start_lr and d.max() <= 6.5 * cfg.start_lr, (n, float(d.max()))
+
