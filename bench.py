@@ -391,12 +391,16 @@ def main():
             peak = 2500.0 if args.dtype != "f32" else 157.3          # dense 16-bit MFMA peak (f16 = bf16 rate), fp32 MFMA peak
             # HBM-side bytes per launch from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE on this
             # same command, scripts/pmc_traffic.py); bench.py cannot run the profiler on itself
-            traffic = None
+            traffic, traffic_src = None, None
             tp = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r03_gemm_nt_traffic.json")
             if args.dtype != "f32" and B == 8 and os.path.exists(tp):
-                traffic = json.load(open(tp))["hbm_bytes_per_launch"]
+                import hashlib
+                raw = open(tp, "rb").read()
+                traffic = json.loads(raw)["hbm_bytes_per_launch"]
+                # not measured in this run: which committed profile the number comes from (content hash, so a stale file is visible)
+                traffic_src = "profiles/r03_gemm_nt_traffic.json sha1 " + hashlib.sha1(raw).hexdigest()[:12] + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of scripts/collect_profiles.sh)"
             out["roofline"] = {"bound": "mfma", "achieved": f / t / 1e12, "peak": peak, "unit": "TFLOP/s",
-                               "frac": f / t / 1e12 / peak, "traffic": traffic,
+                               "frac": f / t / 1e12 / peak, "traffic": traffic, "traffic_source": traffic_src,
                                "algorithmic_bytes_per_launch": by / n,
                                "kernel": "gemm_nt_v5/v4/v3_kernel<%s> (every 1x1-conv / dX product of the head)" % args.dtype,
                                "measured": "hipEvent pairs around every launch (cmpc_kernel_timing, on the launch stream) over the same K steps re-run on ONE stream (in the timed region the lane streams overlap, so a start->end interval there also contains other streams' kernels)",
