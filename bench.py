@@ -219,8 +219,8 @@ def log(msg):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=50)        # warm-up 10, time 50
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--batch", type=int, default=8, help="images per GPU")
     ap.add_argument("--dtype", default="f16", choices=("f16", "bf16", "f32"),
                     help="storage of maps / visual GEMM operands. f16 and bf16 run the same MFMA pipelines at the same rate; f16 (default) is "
