@@ -111,7 +111,7 @@ class EngineCfg(C.Structure):
 class Feeds(C.Structure):
     """cmpc_feeds"""
     _fields_ = [("words", C.c_void_p), ("seq_len", C.c_void_p), ("c3", C.c_void_p), ("c4", C.c_void_p), ("c5", C.c_void_p),
-                ("target_fine", C.c_void_p), ("feats_ready", C.c_void_p), ("c2", C.c_void_p), ("im", C.c_void_p), ("levels_done", C.c_void_p)]
+                ("target_fine", C.c_void_p), ("feats_ready", C.c_void_p), ("c2", C.c_void_p), ("im", C.c_void_p), ("feats_ready_lv", C.c_void_p * 3), ("levels_done", C.c_void_p)]
 
 
 class Fetches(C.Structure):

@@ -189,6 +189,27 @@ class DeepLabResNet(nn.Module):
             blk.b.load(p, f"res{n}_branch2b", f"bn{n}_branch2b")
             blk.c.load(p, f"res{n}_branch2c", f"bn{n}_branch2c")
 
+    @torch.no_grad()
+    def forward_segment(self, x, seg):
+        """One of three segments of forward(): 0 = stem + pool + res2 + res3 (takes the image, NHWC), 1 = res4, 2 = res5 (take the previous
+        segment's running map).  Returns (running map, {tap: NHWC tensor} for the wanted taps this segment produces): c3 / res2b are complete
+        a fifth of the way into the backbone, c4 after res4 -- a caller that captures the segments separately can hand each tap to its
+        consumer when it is ready."""
+        if seg == 0:
+            x = x.permute(0, 3, 1, 2).to(self.stem.weight.dtype).contiguous(memory_format=torch.channels_last)
+            x = self.stem(x)
+            pt, pb = _same_pad(x.shape[2], 3, 2, 1)
+            pl, pr = _same_pad(x.shape[3], 3, 2, 1)
+            x = F.max_pool2d(F.pad(x, (pl, pr, pt, pb), value=float("-inf")), 3, 2)
+        stages = ((2, 3), (4,), (5,))[seg]
+        taps = {}
+        for blk, (stage, suf, *_r) in zip(self.blocks, self.layout):
+            if stage in stages:
+                x = blk(x)
+                taps[stage] = x
+                taps[f"{stage}{suf}"] = x
+        return x, {s_: taps[s_].permute(0, 2, 3, 1).contiguous() for s_ in self.taps_wanted if s_ in taps}
+
     taps_wanted = (3, 4, 5)     # stages (int) or block names ("2b" = res2b_relu, CMPCv5_BiLSTM_model.py:88) returned by forward, in this order
 
     @torch.no_grad()

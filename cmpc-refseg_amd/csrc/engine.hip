@@ -2496,7 +2496,10 @@ extern "C" int cmpc_forward(cmpc_handle e, const cmpc_feeds* f, const cmpc_fetch
     hipStream_t st[3];
     CK(fork_lanes(e, main, st));
     for (int i = 0; i < NL; ++i) { CK(e->vid ? level_lang_fwd_video(e, st[i], i) : level_lang_fwd(e, st[i], i)); CK(exchange_lang_fwd(e, st[i], i)); CK(exchange_lang_fwd(e, st[i], NX + i)); }
-    if (f->feats_ready) for (int i = 0; i < (e->cfg.n_lanes > 1 ? 3 : 1); ++i) HCK(hipStreamWaitEvent(st[i], (hipEvent_t)f->feats_ready, 0));
+    for (int i = 0; i < 3; ++i) {           // every lane waits for its own tap when the caller says when each is complete, else for all of them
+        void* ev = f->feats_ready_lv[i] ? f->feats_ready_lv[i] : f->feats_ready;
+        if (ev) HCK(hipStreamWaitEvent(st[i], (hipEvent_t)ev, 0));       // one lane: st[0..2] are the caller's stream, which then waits for all three
+    }
     CK(mark(e, "fwd:feats_ready", st[0]));
     if (e->v5) {
         // hsv:120-126 (the image feed only) before the levels that read it; the decoder's low-level branch (backbone only) on the idle third lane

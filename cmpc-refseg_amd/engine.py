@@ -161,7 +161,7 @@ class Engine:
 
     # ---- the three per-step calls --------------------------------------------------------------
     def forward(self, words, seq_len, c3, c4, c5, target=None, feats_ready: Optional[torch.cuda.Event] = None, fetches=None, c2=None, im=None,
-                levels_done: Optional[torch.cuda.Event] = None):
+                levels_done: Optional[torch.cuda.Event] = None, feats_ready_lv=None):
         f = Feeds()
         f.words, f.seq_len = words.data_ptr(), seq_len.data_ptr()
         f.c3, f.c4, f.c5 = (c3.data_ptr() if c3 is not None else None), c4.data_ptr(), c5.data_ptr()
@@ -170,6 +170,9 @@ class Engine:
         f.target_fine = target.data_ptr() if target is not None else None
         f.feats_ready = feats_ready.cuda_event if feats_ready is not None else None
         f.levels_done = levels_done.cuda_event if levels_done is not None else None
+        if feats_ready_lv is not None:
+            for i, ev in enumerate(feats_ready_lv):
+                f.feats_ready_lv[i] = ev.cuda_event if ev is not None else None
         fe = None
         if fetches is not None:
             fe = Fetches()

@@ -142,6 +142,8 @@ class LSTM_model(object):
         self._levels_done = None
         self._bb_graph_on = os.environ.get("CMPC_BACKBONE_GRAPH", "1") != "0"
         self._bb = {"calls": 0, "next": 0, "graph": [None, None], "inp": [None, None], "out": [None, None]}
+        self._bb_staged = os.environ.get("CMPC_BB_STAGED", "0") != "0"     # three graphs (..res3 | res4 | res5) with an event behind each
+        self._tap_events = None
         self._keep = []                # feeds / taps of the steps in flight (the handle reads them asynchronously)
 
     def _init_params(self, seed):
@@ -250,6 +252,7 @@ class LSTM_model(object):
             st.wait_stream(main)
         feats = None
         with torch.cuda.stream(st):
+            self._tap_events = None
             if self._bb_graph_on and not torch.cuda.is_current_stream_capturing():
                 feats = self._backbone_graphed(im, st)
             if feats is None:
@@ -276,12 +279,35 @@ class LSTM_model(object):
             inp = torch.empty_like(im)
             inp.copy_(im)
             torch.cuda.synchronize(self.device)
-            g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g, stream=st):
-                out = self.backbone(inp)
-            s["graph"][k], s["inp"][k], s["out"][k] = g, inp, out
+            if self._bb_staged:
+                gs, x, taps = [], inp, {}
+                for seg in range(3):
+                    g = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(g, stream=st):
+                        x, t = self.backbone.forward_segment(x, seg)
+                    taps.update(t)
+                    gs.append(g)
+                    torch.cuda.synchronize(self.device)
+                s["graph"][k], s["inp"][k], s["out"][k] = gs, inp, tuple(taps[t] for t in self.backbone.taps_wanted)
+            else:
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, stream=st):
+                    out = self.backbone(inp)
+                s["graph"][k], s["inp"][k], s["out"][k] = g, inp, out
         s["inp"][k].copy_(im, non_blocking=True)
-        s["graph"][k].replay()
+        if isinstance(s["graph"][k], list):          # staged: an event behind every segment, so that a level starts when ITS tap is complete
+            evs = []
+            for g in s["graph"][k]:
+                g.replay()
+                ev = torch.cuda.Event()
+                ev.record(st)
+                evs.append(ev)
+            want = self.backbone.taps_wanted
+            seg_of = lambda t: 0 if (t == 3 or (isinstance(t, str) and t[0] in "23")) else (1 if t == 4 else 2)
+            # per pyramid level (c5, c4, third slot = c3 or the res2b tap): the event of the segment that produces it
+            self._tap_events = [evs[seg_of(want[2])], evs[seg_of(want[1])], evs[seg_of(want[0])]]
+        else:
+            s["graph"][k].replay()
         return s["out"][k]
 
     # ------------------------------------------------------------------------------------------
@@ -323,9 +349,9 @@ class LSTM_model(object):
                     raise ValueError("CMPCv5_BiLSTM_HSV_model needs the image feed (CMPCv5_BiLSTM_HSV_model.py:120-126)")
                 imd = self._dev(im, torch.float32)
             if self.v5:
-                self.eng.forward(w, sl, None, c4, c5, tg, feats_ready=after, c2=f0, im=imd, levels_done=levels_done)
+                self.eng.forward(w, sl, None, c4, c5, tg, feats_ready=after, c2=f0, im=imd, levels_done=levels_done, feats_ready_lv=self._tap_events if after is not None else None)
             else:
-                self.eng.forward(w, sl, f0, c4, c5, tg, feats_ready=after, levels_done=levels_done)
+                self.eng.forward(w, sl, f0, c4, c5, tg, feats_ready=after, levels_done=levels_done, feats_ready_lv=self._tap_events if after is not None else None)
             self._keep.append((w, sl, tg, f0, c4, c5, imd))
             del self._keep[:-3]
             return self._fetch_dict(tg is not None)

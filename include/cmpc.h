@@ -423,6 +423,9 @@ typedef struct {
                                    is enqueued first and only the pyramid levels wait for it; NULL = ordered on `stream` */
     const void* c2;             /* model V5_BILSTM: res2b_relu [B, c2_h, c2_w, c2_dim] NHWC, cfg.dtype (v5:88); c3 is unused there (may be NULL) */
     const float* im;            /* model V5_BILSTM with hsv: the image feed itself [B, H, W, 3] f32, BGR minus mean (v5:80; hsv:120-126) */
+    void* feats_ready_lv[3];    /* optional, per pyramid level (c5, c4, c3 -- for V5_BILSTM slot 2 is the res2b tap): hipEvent_t recorded once THAT tap is
+                                   complete; a level's lane then waits for its own tap only (c3 leaves the backbone after res3, c4 after res4), NULL
+                                   entries fall back to feats_ready */
     void* levels_done;          /* optional hipEvent_t that cmpc_forward RECORDS once the pyramid levels' forward is complete: from there to the
                                    levels' backward the step is a serial chain of small launches (exchange modules, ConvLSTM, scores), the
                                    window a caller uses for independent heavy work -- the frozen backbone of the NEXT batch */
