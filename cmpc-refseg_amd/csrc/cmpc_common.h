@@ -30,6 +30,7 @@ void cmpc_trace_producer();
 // Library-owned scratch for per-workgroup partial sums: one growing buffer PER STREAM (up to 64
 // streams), so stage operators running on different streams never share partial rows.
 void* cmpc_ws(size_t bytes, hipStream_t st);
+void cmpc_ws_release(hipStream_t st);      // before destroying a stream the library created: frees its workspace slot
 // out[o*ld_out + seg*out_seg + c] (+)= sum_{i<ninner} part[(o*ninner+i)*part_stride + seg*seg_ld + c], c < seg_C   (one writer per element)
 int cmpc_reduce_parts_f32(const float* part, long part_stride, int nouter, int ninner, int nseg, int seg_ld, int seg_C,
                           float* out, long ld_out, long out_seg, int accumulate, hipStream_t st);

@@ -2036,7 +2036,7 @@ extern "C" int cmpc_destroy(cmpc_handle e) {
     for (void* p : {(void*)e->params, (void*)e->grads, (void*)e->adam_m, (void*)e->adam_v, (void*)e->arena, (void*)e->descs_dev,
                     (void*)e->tile_prefix_dev, (void*)e->tile_desc_dev, (void*)e->segs_dev, (void*)e->ws, (void*)e->bn_state})
         if (p) (void)hipFree(p);
-    for (hipStream_t s : e->own_lane) if (s) (void)hipStreamDestroy(s);
+    for (hipStream_t s : e->own_lane) if (s) { cmpc_ws_release(s); (void)hipStreamDestroy(s); }
     for (hipEvent_t ev : e->evpool) (void)hipEventDestroy(ev);
     if (e->ev_opt0) (void)hipEventDestroy(e->ev_opt0);
     if (e->ev_opt1) (void)hipEventDestroy(e->ev_opt1);

@@ -80,21 +80,27 @@ extern "C" int cmpc_launch_trace_read(int index, const char** name, double* ms, 
 extern "C" const char* cmpc_last_error(void) { return g_err; }
 
 struct WsSlot { hipStream_t st; void* p; size_t bytes; bool used; };
-static WsSlot g_ws[64];
+static WsSlot g_ws[256];
 static thread_local cmpc_fold_ctx* t_fold = nullptr;
 void cmpc_fold_begin(cmpc_fold_ctx* ctx) { t_fold = ctx; if (ctx) { ctx->off = 0; ctx->n = 0; } }
+// a stream that is about to be destroyed gives its slot (and block) back: a process that creates handle after handle would otherwise run out
+// of the 64 slots (3 lane streams per handle)
+static std::mutex g_ws_mu;
+void cmpc_ws_release(hipStream_t st) {
+    std::lock_guard<std::mutex> lock(g_ws_mu);
+    for (auto& w : g_ws) if (w.used && w.st == st) { if (w.p) (void)hipFree(w.p); w.p = nullptr; w.bytes = 0; w.used = false; w.st = nullptr; }
+}
 void* cmpc_ws(size_t bytes, hipStream_t st) {
     if (t_fold) {                       // collecting deferred folds: partial rows must survive until cmpc_fold_flush
         const size_t need = (bytes + 255) / 256 * 256;
         if (t_fold->off + need <= t_fold->cap) { void* p = t_fold->arena + t_fold->off; t_fold->off += need; return p; }
     }
-    static std::mutex mu;                   // the slot table is shared by every handle / host thread of the process
-    std::lock_guard<std::mutex> lock(mu);
+    std::lock_guard<std::mutex> lock(g_ws_mu);          // the slot table is shared by every handle / host thread of the process
     WsSlot* slot = nullptr;
     for (auto& w : g_ws) if (w.used && w.st == st) { slot = &w; break; }
     if (!slot) {
         for (auto& w : g_ws) if (!w.used) { slot = &w; w.used = true; w.st = st; w.p = nullptr; w.bytes = 0; break; }
-        if (!slot) { cmpc_set_error("workspace: more than 64 streams in use"); return nullptr; }
+        if (!slot) { cmpc_set_error("workspace: more than 256 streams in use"); return nullptr; }
     }
     if (bytes > slot->bytes) {
         // growth only happens while shapes are first seen (never inside a steady-state step).  It cannot happen
