@@ -311,6 +311,7 @@ struct cmpc_engine_s {
     float *score, *up, *sigm, *loss; int* iu; float *dscore; void* dfused;
     float* scalars; int* nonfinite;      // nonfinite[b]: gradient elements of bucket b the last optimizer step skipped (inf / nan)
     bool have_target = false;
+    bool bwd_zeroed = false;      // the backward pass's accumulate-into buffers and the gradient buffer were cleared by the last cmpc_forward
     const int32_t* seq_len_feed = nullptr; const float* target_feed = nullptr;      // caller-owned feeds the backward pass re-reads
     hipStream_t last_main = nullptr; long l0 = 0;
     // Gradient buckets: contiguous ranges of the flat gradient buffer in the order they become final during cmpc_backward
@@ -2495,6 +2496,14 @@ extern "C" int cmpc_forward(cmpc_handle e, const cmpc_feeds* f, const cmpc_fetch
     // the lanes, while the backbone (caller's side stream) is still running; each lane then waits for the visual features itself.
     hipStream_t st[3];
     CK(fork_lanes(e, main, st));
+    if (f->target_fine && e->cfg.n_lanes > 1) {
+        // a training step: the backward pass's two clears (its accumulate-into region and the 304 MB gradient buffer, 40-60 us at the head of
+        // cmpc_backward's serial chain) are issued here, on a lane, under the backbone -- nothing of the forward pass touches either, and the
+        // previous step's optimizer (the last reader of the gradients) is complete: params_ready(.., 1) above
+        HCK(hipMemsetAsync(e->ws + e->zf_bytes, 0, e->zb_bytes, st[2]));
+        HCK(hipMemsetAsync(e->grads, 0, (size_t)e->total * sizeof(float), st[2]));
+        e->bwd_zeroed = true;
+    }
     for (int i = 0; i < NL; ++i) { CK(e->vid ? level_lang_fwd_video(e, st[i], i) : level_lang_fwd(e, st[i], i)); CK(exchange_lang_fwd(e, st[i], i)); CK(exchange_lang_fwd(e, st[i], NX + i)); }
     for (int i = 0; i < 3; ++i) {           // every lane waits for its own tap when the caller says when each is complete, else for all of them
         void* ev = f->feats_ready_lv[i] ? f->feats_ready_lv[i] : f->feats_ready;
@@ -2595,8 +2604,11 @@ extern "C" int cmpc_backward(cmpc_handle e, void* stream) {
     const long nmap = (long)e->R * Mp;
     const float* target = e->target_feed;
     CK(mark(e, "bwd:start", main));
-    HCK(hipMemsetAsync(e->ws + e->zf_bytes, 0, e->zb_bytes, main));
-    HCK(hipMemsetAsync(e->grads, 0, (size_t)e->total * sizeof(float), main));
+    if (!e->bwd_zeroed) {      // normally done during the forward pass (below the levels' language work, off the critical path)
+        HCK(hipMemsetAsync(e->ws + e->zf_bytes, 0, e->zb_bytes, main));
+        HCK(hipMemsetAsync(e->grads, 0, (size_t)e->total * sizeof(float), main));
+    }
+    e->bwd_zeroed = false;
     HOSTPROF("memsets");
     cmpc_fold_begin(&e->fold);
     struct FoldGuard { ~FoldGuard() { cmpc_fold_begin(nullptr); } } fold_guard;      // an early error return must not leave the collector on
