@@ -347,6 +347,37 @@ def test_train_steps_match_tf_adam(case):
     assert moved > 0.5 * lr
 
 
+def test_loss_curve_60_steps_follows_oracle():
+    """Training behaviour, not just one step: 60 train steps over four alternating batches (tiny configuration), the product in fp32 and in the
+    default f16 storage against the oracle's TF-Adam loop.  The loss falls by almost half (3386 -> 1806 at step 60) and the two curves stay together: measured max
+    relative difference over all 60 steps 5.4e-5 (fp32) and 1.6e-4 (f16)."""
+    torch.set_num_threads(8)
+    n = 60
+    cfg = U.tiny_cfg(B=2)
+    hp, bp = O.init_head_params(cfg), O.init_backbone_params(cfg)
+    batches = [O.synth_batch(cfg, seed=s) for s in range(4)]
+    feats = [O.backbone_forward(bp, b[1], cfg) for b in batches]
+    hp_o = {k: v.clone() for k, v in hp.items()}
+    opt = O.TFAdam(hp_o)
+    ref = []
+    for step in range(n):
+        w, im, sl, tg = batches[step % 4]
+        ref.append(O.train_step(hp_o, opt, step, feats[step % 4], w, sl, tg, cfg)["loss_all"])
+    assert ref[-1] < 0.6 * ref[0]
+    P = U.pkg()
+    for dtype, tol in (("f32", 3e-4), ("f16", 1e-3)):
+        m = P.LSTM_model(head_params=hp, backbone_params=bp, **U.model_kwargs(cfg, dtype))
+        got = []
+        for step in range(n):
+            w, im, sl, tg = batches[step % 4]
+            got.append(float(m.train_step(w, im, tg, sl)[1]["loss_all"]))
+        torch.cuda.synchronize()
+        rel = max(abs(a - b) / abs(b) for a, b in zip(got, ref))
+        print(f"loss curve {dtype}: max relative difference over {n} steps {rel:.2e} (loss {got[0]:.1f} -> {got[-1]:.1f})")
+        assert rel < tol, (dtype, rel)
+        assert m.grad_nonfinite() == 0
+
+
 def test_one_lane_equals_three_lanes(case):
     """The lane streams only reorder independent stages, and no sum depends on scheduling: the handle with n_lanes = 1 (everything
     on the caller's stream) and with 3 lanes gives bit-identical scalars and parameters after 3 steps with changing feeds."""
